@@ -1,0 +1,248 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by importing the
+read-only reference at /root/reference (build container only; see
+oracle/_refshim.py for the shims).  Run:  python -m oracle.gen_golden [F1 F2 ...]
+
+Fixture ids follow SURVEY.md §8(c).  Inputs are regenerated on the test side
+from the same seeds / formula weights (oracle/weights.py), so the files hold
+only expected outputs (and small inputs where convenient).
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+from oracle import _refshim
+from oracle.weights import fill_formula_weights, seeded_uniform
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def aniso_gaussian_kernel(size=13, s1=2.2, s2=0.9, theta=0.6):
+    """An anisotropic Gaussian *downscaling* kernel (sums to 1), standing in for a
+    KernelGAN-estimated kernel (reference: CEMnet(conf, upscale_kernel=ndarray))."""
+    ax = np.arange(size) - (size - 1) / 2.0
+    xx, yy = np.meshgrid(ax, ax)
+    c, s = np.cos(theta), np.sin(theta)
+    u, v = c * xx + s * yy, -s * xx + c * yy
+    k = np.exp(-0.5 * ((u / s1) ** 2 + (v / s2) ** 2))
+    return k / k.sum()
+
+
+def _reset_kernel_cache():
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+
+
+def _cem(sf, kernel=None, bound=None, **conf_over):
+    import CEM.CEMnet as C
+    _reset_kernel_cache()
+    conf = C.Get_CEM_Conf(sf)
+    if bound is not None:
+        conf.lower_magnitude_bound = bound
+    for k, v in conf_over.items():
+        setattr(conf, k, v)
+    return C.CEMnet(conf, upscale_kernel=kernel)
+
+
+def gen_F1():
+    """CEM taps / margins / strides (pins A6)."""
+    from CEM.imresize_CEM import calc_strides
+    out = {}
+    cases = [('cubic_x2', 2, None, None), ('cubic_x3', 3, None, None), ('cubic_x4', 4, None, None),
+             ('cubic_x8', 8, None, None), ('blurry1.0_x4', 4, 'blurry_cubic_1.0', None),
+             ('blurry2.0_x8', 8, 'blurry_cubic_2.0', None),
+             ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1), ('aniso_x8', 8, aniso_gaussian_kernel(17, 4.0, 1.8, 0.6), 0.1)]
+    for name, sf, kernel, bound in cases:
+        cem = _cem(sf, kernel, bound)
+        pre, post = calc_strides(None, sf)
+        out[name + '/ds_kernel'] = np.asarray(cem.ds_kernel, dtype=np.float64)
+        out[name + '/inv_hTh'] = np.asarray(cem.inv_hTh, dtype=np.float64)
+        out[name + '/ints'] = np.array([sf, cem.ds_kernel_invalidity_half_size_LR, cem.inv_hTh_invalidity_half_size,
+                                        cem.invalidity_margins_LR, cem.invalidity_margins_HR, pre[0], post[0]], dtype=np.int64)
+        print(name, cem.ds_kernel.shape, cem.inv_hTh.shape, out[name + '/ints'])
+    np.savez_compressed(os.path.join(GOLDEN, 'cem_taps.npz'), **out)
+
+
+def gen_F2():
+    """The three Filter_Layer ops + CEM_downsampler individually (pins A7 / index conventions)."""
+    import CEM.CEMnet as C
+    out = {}
+    for name, sf, kernel, bound in [('cubic_x4', 4, None, None), ('cubic_x2', 2, None, None), ('cubic_x3', 3, None, None),
+                                    ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1)]:
+        cem = _cem(sf, kernel, bound)
+        net = cem.WrapArchitecture_PyTorch(generated_image=None)
+        lr = seeded_uniform((2, 3, 20, 24), 11)
+        hr = seeded_uniform((2, 3, 20 * sf, 24 * sf), 12)
+        with torch.no_grad():
+            out[name + '/DownscaleOP'] = net.DownscaleOP(hr).numpy()
+            out[name + '/Conv_LR_with_Inv_hTh_OP'] = net.Conv_LR_with_Inv_hTh_OP(lr).numpy()
+            out[name + '/Upscale_OP'] = net.Upscale_OP(lr).numpy()
+        if kernel is None:
+            _reset_kernel_cache()
+            ds = C.CEM_downsampler(sf)
+            with torch.no_grad():
+                out[name + '/CEM_downsampler'] = ds(hr).numpy()
+            g = C.CEM_downsampler(sf, grayscale=True)
+            with torch.no_grad():
+                out[name + '/CEM_downsampler_gray'] = g(hr[:, :1]).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, 'cem_filter_ops.npz'), **out)
+
+
+def gen_F3():
+    """CEM_PyTorch with generated_image=None (pair input): train/eval, sigmoid-range and
+    decomposed variants; plus the NumPy projections (pins A8)."""
+    out = {}
+    for name, sf, kernel, bound in [('cubic_x4', 4, None, None), ('cubic_x2', 2, None, None), ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1)]:
+        lr = seeded_uniform((2, 3, 12, 16), 21)
+        gen = seeded_uniform((2, 3, 12 * sf, 16 * sf), 22)
+        cem = _cem(sf, kernel, bound)
+        net = cem.WrapArchitecture_PyTorch(generated_image=None)
+        with torch.no_grad():
+            net.train()
+            out[name + '/train'] = net([lr, gen]).numpy()
+            net.eval()
+            out[name + '/eval'] = net([lr, gen]).numpy()
+        # consistency of the train-mode output: downscale(out) vs lr, whole frame
+        with torch.no_grad():
+            net.train()
+            y = net([lr, gen])
+            d = net.DownscaleOP(y)
+            out[name + '/train_consistency_interior_rmse'] = np.array(
+                float(((d - lr)[:, :, cem.invalidity_margins_LR // 2:-(cem.invalidity_margins_LR // 2) or None,
+                                cem.invalidity_margins_LR // 2:-(cem.invalidity_margins_LR // 2) or None] ** 2).mean().sqrt()))
+    # option variants on cubic x4
+    lr = seeded_uniform((2, 3, 12, 16), 21)
+    gen = seeded_uniform((2, 3, 48, 64), 22)
+    cem = _cem(4, sigmoid_range_limit=True, input_range=np.array([0, 1]))
+    net = cem.WrapArchitecture_PyTorch(generated_image=None)
+    with torch.no_grad():
+        net.train()
+        out['cubic_x4_sigmoid/train'] = net([lr, gen]).numpy()
+    cem = _cem(4, decomposed_output=True)
+    net = cem.WrapArchitecture_PyTorch(generated_image=None)
+    with torch.no_grad():
+        net.train()
+        o = net([lr, gen])
+        out['cubic_x4_decomposed/train_ortho'] = o[0].numpy()
+        out['cubic_x4_decomposed/train_NS'] = o[1].numpy()
+        net.eval()
+        out['cubic_x4_decomposed/eval'] = net([lr, gen]).numpy()
+    # NumPy projections
+    cem = _cem(4)
+    rng = np.random.Generator(np.random.PCG64(23))
+    hr_np = rng.random((48, 48, 3))
+    lr_np = rng.random((12, 12, 3))
+    out['numpy/Project_2_ortho_2_NS'] = cem.Project_2_ortho_2_NS(hr_np)
+    out['numpy/DT_Satisfying_Upscale'] = cem.DT_Satisfying_Upscale(lr_np)
+    out['numpy/Enforce_DT_on_Image_Pair'] = cem.Enforce_DT_on_Image_Pair(lr_np, hr_np)
+    from CEM.imresize_CEM import imresize
+    out['numpy/imresize_down4'] = imresize(hr_np, scale_factor=[0.25])
+    out['numpy/imresize_up4'] = imresize(lr_np, scale_factor=[4])
+    np.savez_compressed(os.path.join(GOLDEN, 'cem_forward.npz'), **out)
+
+
+def _param_digest(t):
+    f = t.detach().reshape(-1).double()
+    n = f.numel()
+    idx = torch.linspace(0, n - 1, steps=24).long()
+    return np.concatenate([[float(f.sum()), float(f.norm())], f[idx].numpy()])
+
+
+def gen_F4():
+    """RRDBNet forward + input-grad + weight-grad digests (pins A1-A5 fwd/bwd)."""
+    import models.modules.architecture as arch
+    out = {}
+    cases = [('nb1_x4', 1, 4, 0), ('nb3_x4', 3, 4, 0), ('nb1_x8', 1, 8, 0), ('nb1_x2', 1, 2, 0),
+             ('nb1_x4_lat3', 1, 4, 3), ('nb2_x4_lat3', 2, 4, 3), ('nb1_x2_lat1', 1, 2, 1)]
+    for name, nb, sf, lat in cases:
+        torch.manual_seed(0)
+        net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu',
+                           mode='CNA', upsample_mode='upconv',
+                           latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+        n = fill_formula_weights(net, gain=1.0)
+        h, w = (12, 16) if sf != 8 else (8, 8)
+        x = seeded_uniform((1, 3 + lat * sf * sf, h, w), 31 + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+        if lat:
+            x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+        x.requires_grad_(True)
+        y = net(x)
+        cot = seeded_uniform(tuple(y.shape), 41 + nb + sf + lat, -1.0, 1.0)
+        (y * cot).sum().backward()
+        out[name + '/out'] = y.detach().numpy()
+        out[name + '/dx'] = x.grad.numpy()
+        out[name + '/dparams'] = np.stack([_param_digest(p.grad) for _, p in net.named_parameters()])
+        out[name + '/nparams'] = np.array([n, sum(p.numel() for p in net.parameters())])
+        print(name, tuple(y.shape), float(y.detach().abs().mean()), float(x.grad.abs().mean()))
+    np.savez_compressed(os.path.join(GOLDEN, 'rrdb_fwd_bwd.npz'), **out)
+
+
+def _wrapped_G(nb, sf, lat=0, kernel=None, gain=1.0):
+    import models.modules.architecture as arch
+    cem = _cem(sf, kernel)
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu',
+                       mode='CNA', upsample_mode='upconv',
+                       latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+    G = cem.WrapArchitecture_PyTorch(net)
+    fill_formula_weights(G, gain=gain)
+    return cem, G
+
+
+def gen_F5():
+    """Config 1 exactly: RRDB-3 x4 + CEM eval on [1,3,32,32] (+ an explorable lat=3 variant)."""
+    out = {}
+    cem, G = _wrapped_G(3, 4)
+    x = seeded_uniform((1, 3, 32, 32), 51)
+    G.eval()
+    with torch.no_grad():
+        y = G(x)
+        d = G.LR_unpadder(G.DownscaleOP(G.HR_padder(y)))
+    m = cem.invalidity_margins_LR
+    out['c1/out'] = y.numpy()
+    out['c1/consistency_interior_rmse'] = np.array(float(((d - x)[:, :, m:-m, m:-m] ** 2).mean().sqrt()))
+    out['c1/keys'] = np.array(list(G.state_dict().keys()))
+    out['c1/key_shapes'] = np.array([str(tuple(v.shape)) for v in G.state_dict().values()])
+    print('c1', tuple(y.shape), float(y.mean()), out['c1/consistency_interior_rmse'])
+    # train mode (no pre-pad)
+    G.train()
+    with torch.no_grad():
+        out['c1/out_train_mode'] = G(x).numpy()
+    # explorable: Z given HR-res, packed by view as SRRaGANModel.Prepare_Input does (SRRaGAN_model.py:230-236)
+    cem, G = _wrapped_G(2, 4, lat=3)
+    z = seeded_uniform((1, 3, 128, 128), 52, -1.0, 1.0)
+    xin = torch.cat([z.contiguous().view(1, 3 * 16, 32, 32), x], 1)
+    G.eval()
+    with torch.no_grad():
+        y = G(xin)
+    out['c1_lat3/out'] = y.numpy()
+    out['c1_lat3/keys'] = np.array(list(G.state_dict().keys()))
+    out['c1_lat3/key_shapes'] = np.array([str(tuple(v.shape)) for v in G.state_dict().values()])
+    print('c1_lat3', tuple(y.shape), float(y.mean()))
+    np.savez_compressed(os.path.join(GOLDEN, 'c1_end_to_end.npz'), **out)
+
+
+def gen_F6():
+    """RRDB-23 x4 + CEM on one [1,3,128,128] input: statistics + crops (depth accumulation)."""
+    out = {}
+    cem, G = _wrapped_G(23, 4, gain=0.6)
+    x = seeded_uniform((1, 3, 128, 128), 61)
+    G.eval()
+    with torch.no_grad():
+        y = G(x)
+    out['stats'] = np.stack([y.mean((0, 2, 3)).numpy(), y.std((0, 2, 3)).numpy(), y.amin((0, 2, 3)).numpy(), y.amax((0, 2, 3)).numpy()])
+    out['crop64'] = y[:, :, 200:264, 300:364].numpy()
+    out['stride8'] = y[:, :, 3::8, 5::8].numpy()
+    out['nparams'] = np.array([sum(p.numel() for n, p in G.named_parameters() if 'Filter_OP' not in n),
+                               sum(p.numel() for p in G.parameters())])
+    print('rrdb23', out['stats'], out['nparams'])
+    np.savez_compressed(os.path.join(GOLDEN, 'c2_rrdb23_probe.npz'), **out)
+
+
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6}
+
+if __name__ == '__main__':
+    _refshim.install()
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(GOLDEN, exist_ok=True)
+    for k in (sys.argv[1:] or list(ALL)):
+        print('==', k)
+        ALL[k]()
