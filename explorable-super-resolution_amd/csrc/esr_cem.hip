@@ -1,0 +1,163 @@
+// Consistency Enforcing Module filters (fixed depth-wise taps, fp32 NCHW).
+// Reference: codes/CEM/CEMnet.py:243-252 (Filter_Layer) as wired in CEM_PyTorch.__init__ (:254-281) and used by
+// CEM_PyTorch.forward (:303-311).  The reference runs three dense depth-wise cuDNN convolutions around explicit
+// ReplicationPad2d / zero-stuffing / strided-view tensors; here each op is one kernel that
+//   * applies the replicate padding by clamping indices (no padded copy),
+//   * evaluates the strided downscale only at the kept pixels (1/sf^2 of the reference's MACs),
+//   * evaluates the zero-stuffed upscale polyphase-wise (only taps that hit a non-zero sample),
+//   * fuses  x - D(g)  into the downscale and  g + U(.) / tanh / crop  into the upscale.
+// Index conventions (bit-exact with the reference): LR sample (i,j) sits at HR (sf*i+pre, sf*j+pre), pre = sf - floor(sf/2) - 1
+// (codes/CEM/imresize_CEM.py:99-101); filter centre = floor(k/2); the replicate pad of the zero-stuffed image replicates
+// whatever its first/last row is (a sample row only when pre == 0, i.e. sf == 2).
+// These are HBM/L2-bound streaming kernels (<= 0.1 % of the generator's FLOPs): one output per thread, coalesced along W,
+// taps through the scalar cache.
+#include "esr_common.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ void cem_downscale_kernel(const float* __restrict__ y, int h, int w, int sf, int pre, const float* __restrict__ taps, int k,
+                                     const float* __restrict__ lr, int lr_pad, float* __restrict__ d, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx % w);
+    long long t = idx / w;
+    const int i = (int)(t % h);
+    const long long bc = t / h;
+    const int Hh = h * sf, Wh = w * sf, p = k / 2;
+    const float* src = y + bc * Hh * (long long)Wh;
+    const int Y0 = sf * i + pre - p, X0 = sf * j + pre - p;
+    float acc = 0.f;
+    for (int a = 0; a < k; ++a) {
+        const float* row = src + (long long)clampi(Y0 + a, 0, Hh - 1) * Wh;
+        const float* tr = taps + a * k;
+        if (X0 >= 0 && X0 + k <= Wh) {
+            for (int c = 0; c < k; ++c) acc = fmaf(tr[c], row[X0 + c], acc);
+        } else {
+            for (int c = 0; c < k; ++c) acc = fmaf(tr[c], row[clampi(X0 + c, 0, Wh - 1)], acc);
+        }
+    }
+    if (lr) {
+        const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
+        acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
+    }
+    d[idx] = acc;
+}
+
+__global__ void cem_lrfilter_kernel(const float* __restrict__ x, int h, int w, const float* __restrict__ taps, int k, float* __restrict__ out,
+                                    long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx % w);
+    long long t = idx / w;
+    const int i = (int)(t % h);
+    const long long bc = t / h;
+    const int p = k / 2;
+    const float* src = x + bc * h * (long long)w;
+    float acc = 0.f;
+    for (int a = 0; a < k; ++a) {
+        const float* row = src + (long long)clampi(i + a - p, 0, h - 1) * w;
+        const float* tr = taps + a * k;
+        if (j - p >= 0 && j - p + k <= w) {
+            for (int c = 0; c < k; ++c) acc = fmaf(tr[c], row[j - p + c], acc);
+        } else {
+            for (int c = 0; c < k; ++c) acc = fmaf(tr[c], row[clampi(j + c - p, 0, w - 1)], acc);
+        }
+    }
+    out[idx] = acc;
+}
+
+template <bool TWO>
+__global__ void cem_upscale_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf, int pre,
+                                   const float* __restrict__ taps, int k, const float* __restrict__ g, int crop, int mode, float range,
+                                   float* __restrict__ out, float* __restrict__ out2, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
+    const int xo = (int)(idx % Wo);
+    long long t = idx / Wo;
+    const int yo = (int)(t % Ho);
+    const long long bc = t / Ho;
+    const int Y = yo + crop, X = xo + crop;
+    const float* s1 = f + bc * h * (long long)w;
+    const float* s2 = TWO ? f2 + bc * h * (long long)w : nullptr;
+    float u1 = 0.f, u2 = 0.f;
+    // first tap index whose stuffed coordinate lands on a sample:  Y + a - p == pre (mod sf)
+    int a0 = (pre + p - Y) % sf; if (a0 < 0) a0 += sf;
+    int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
+    auto row_accum = [&](int a, int i) {
+        const float* tr = taps + a * k;
+        const float* r1 = s1 + (long long)i * w;
+        const float* r2 = TWO ? s2 + (long long)i * w : nullptr;
+        for (int b = b0; b < k; b += sf) {
+            const int xx = X + b - p;
+            if (xx < 0 || xx >= Wh) continue;
+            const int j = (xx - pre) / sf;
+            u1 = fmaf(tr[b], r1[j], u1);
+            if (TWO) u2 = fmaf(tr[b], r2[j], u2);
+        }
+        if (pre == 0) {   // replicate pad replicates sample column 0 (only sf == 2): every tap left of the frame hits column 0
+            for (int b = 0; X + b - p < 0 && b < k; ++b) {
+                u1 = fmaf(tr[b], r1[0], u1);
+                if (TWO) u2 = fmaf(tr[b], r2[0], u2);
+            }
+        }
+    };
+    for (int a = a0; a < k; a += sf) {
+        const int yy = Y + a - p;
+        if (yy < 0 || yy >= Hh) continue;
+        row_accum(a, (yy - pre) / sf);
+    }
+    if (pre == 0)
+        for (int a = 0; Y + a - p < 0 && a < k; ++a) row_accum(a, 0);
+
+    const long long go = (bc * Hh + Y) * (long long)Wh + X;
+    float r;
+    if (mode == 0) r = u1;
+    else if (mode == 1) r = g[go] + u1;
+    else if (mode == 2) r = u1 + tanhf(g[go] - u2) * range;
+    else { r = u1; out2[idx] = g[go] - u2; }
+    out[idx] = r;
+}
+
+}  // namespace
+
+extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k, const float* lr,
+                                 int lr_pad, float* d, esr_stream_t stream) {
+    if (!y || !taps || !d || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 1 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
+    if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
+    const long long total = (long long)B * C * h * w;
+    hipLaunchKernelGGL(cem_downscale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, h, w, sf, pre, taps, k,
+                       lr, lr_pad, d, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+extern "C" int esr_cem_lrfilter(const float* x, int B, int C, int h, int w, const float* taps, int k, float* out, esr_stream_t stream) {
+    if (!x || !taps || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || k < 1 || !(k & 1)) return ESR_E_ARG;
+    const long long total = (long long)B * C * h * w;
+    hipLaunchKernelGGL(cem_lrfilter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, h, w, taps, k, out,
+                       total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+extern "C" int esr_cem_upscale(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* taps, int k,
+                               const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream) {
+    if (!f || !taps || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 2 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
+    if (mode < 0 || mode > 3 || crop < 0 || 2 * crop >= h * sf || 2 * crop >= w * sf) return ESR_E_ARG;
+    if (mode >= 1 && !g) return ESR_E_ARG;
+    if (mode >= 2 && !f2) return ESR_E_ARG;
+    if (mode == 3 && !out2) return ESR_E_ARG;
+    const long long total = (long long)B * C * (h * sf - 2 * crop) * (w * sf - 2 * crop);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (mode >= 2)
+        hipLaunchKernelGGL(cem_upscale_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode, range,
+                           out, out2, total);
+    else
+        hipLaunchKernelGGL(cem_upscale_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode, range,
+                           out, out2, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 kernels of libesr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/esr_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// float -> bf16 bits, round to nearest even (finite inputs; NaN stays NaN-ish, never produced on this path)
+__device__ __forceinline__ uint32_t f2bf(float x) {
+    uint32_t u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+
+// split x into hi = bf16(x), lo = bf16(x - hi); hi + lo carries ~16 mantissa bits of x
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+
+// device-side mirror of esr_act_view (strides in 16-byte vectors)
+struct DView {
+    const uint4* hi;
+    const uint4* lo;
+    long long bs, cs;
+    int ncg;
+};
+
+static inline DView to_dview(const esr_act_view& v) {
+    DView d;
+    d.hi = (const uint4*)v.hi;
+    d.lo = (const uint4*)v.lo;
+    d.bs = v.batch_stride;
+    d.cs = v.cg_stride;
+    d.ncg = v.hi ? v.ncg : 0;
+    return d;
+}
+
+#define ESR_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return ESR_E_LAUNCH;          \
+    } while (0)

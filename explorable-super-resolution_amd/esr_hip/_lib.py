@@ -1,0 +1,90 @@
+"""Loads libesr_hip.so (built in-tree by csrc/Makefile) and declares the C-ABI of include/esr_hip.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = 'libesr_hip.so'
+
+
+class EsrError(RuntimeError):
+    pass
+
+
+class ActView(C.Structure):
+    """esr_act_view (include/esr_hip.h)."""
+    _fields_ = [('hi', C.c_void_p), ('lo', C.c_void_p), ('ncg', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('batch_stride', C.c_int64), ('cg_stride', C.c_int64)]
+
+
+class Conv3x3Desc(C.Structure):
+    """esr_conv3x3_desc (include/esr_hip.h)."""
+    _fields_ = [('in0', ActView), ('in1', ActView), ('upsample', C.c_int32), ('wpack', C.c_void_p), ('bias', C.c_void_p),
+                ('cout', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('act_slope', C.c_float), ('alpha', C.c_float),
+                ('res1', ActView), ('beta1', C.c_float), ('res2', ActView), ('beta2', C.c_float),
+                ('out', ActView), ('out2', ActView), ('out_nchw', C.c_void_p),
+                ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float)]
+
+
+_SIGS = {
+    'esr_version': (C.c_int, []),
+    'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
+    'esr_conv_wpack_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'esr_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    'esr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(ActView), C.c_void_p]),
+    'esr_unpack_nchw': (C.c_int, [C.POINTER(ActView), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_zero': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_cem_upscale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def load_library():
+    """Load the in-tree shared library; raises EsrError (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EsrError('%s not found: build it with `make -C explorable-super-resolution_amd/csrc` (or __graft_entry__.build()). '
+                       'There is no CPU fallback for the RRDB/CEM kernels.' % path)
+    try:
+        h = C.CDLL(path)
+    except OSError as e:
+        raise EsrError('cannot load %s: %s' % (path, e))
+    for name, (res, args) in _SIGS.items():
+        try:
+            f = getattr(h, name)
+        except AttributeError:
+            raise EsrError('%s does not export %s (stale build?)' % (path, name))
+        f.restype = res
+        f.argtypes = args
+    _lib = h
+    return h
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load_library(), name)
+
+
+lib = _LazyLib()
+
+_ERR = {-1: 'ESR_E_ARG (bad argument)', -2: 'ESR_E_UNSUPPORTED (unsupported shape)', -3: 'ESR_E_LAUNCH (HIP launch error)'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EsrError('%s failed: %s' % (what, _ERR.get(rc, rc)))

@@ -1,0 +1,175 @@
+"""Device-side containers used by the launch planner: activation buffers in the kernels' channel-group layout
+and packed conv weights.  PyTorch is only the allocator / stream provider here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ActView, EsrError, check
+
+
+def require_gpu(t, what='tensor'):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise EsrError('%s must live on an AMD GPU: the RRDB/CEM kernels have no CPU fallback' % what)
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ActBuf:
+    """[B][CG][H+2][W+2][8] bf16 `hi` (+ `lo`) planes.  Allocated zeroed, so the 1-pixel border the conv kernels
+    rely on is zero from the start; producers never write it."""
+
+    def __init__(self, B, ncg, H, W, device, split=True):
+        self.B, self.ncg, self.H, self.W, self.split = B, ncg, H, W, split
+        self.hi = torch.zeros(B, ncg, H + 2, W + 2, 8, dtype=torch.int16, device=device)
+        self.lo = torch.zeros_like(self.hi) if split else None
+        self.cg_stride = (H + 2) * (W + 2)
+        self.batch_stride = ncg * self.cg_stride
+
+    def view(self, cg0=0, ncg=None):
+        ncg = self.ncg - cg0 if ncg is None else ncg
+        assert 0 <= cg0 and cg0 + ncg <= self.ncg
+        off = cg0 * self.cg_stride * 16
+        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.split else None, ncg, self.H, self.W,
+                       self.batch_stride, self.cg_stride)
+
+    def nbytes(self):
+        return self.hi.numel() * 2 * (2 if self.split else 1)
+
+    def to_nchw(self, nc, cg0=0):
+        """Debug/test helper: unpack channels [cg0*8, cg0*8+nc) to fp32 NCHW."""
+        out = torch.empty(self.B, nc, self.H, self.W, dtype=torch.float32, device=self.hi.device)
+        v = self.view(cg0, (nc + 7) // 8)
+        check(_lib.lib.esr_unpack_nchw(C.byref(v), self.B, nc, out.data_ptr(), stream_ptr()), 'esr_unpack_nchw')
+        return out
+
+
+NO_VIEW = ActView(None, None, 0, 0, 0, 0, 0)
+
+
+def pack_nchw(src, dst_view, c0, nc, pad=0, down=1, hw=None, batch_stride=0, channels=None):
+    """fp32 NCHW (or a raw HR `view` of it: hw/batch_stride/channels given explicitly) -> act view."""
+    require_gpu(src, 'input')
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    B = src.shape[0]
+    Cc = src.shape[1] if channels is None else channels
+    h, w = (src.shape[2], src.shape[3]) if hw is None else hw
+    check(_lib.lib.esr_pack_nchw(src.data_ptr(), batch_stride, B, Cc, h, w, c0, nc, pad, down, C.byref(dst_view), stream_ptr()),
+          'esr_pack_nchw')
+
+
+class PackedConv:
+    """MFMA-fragment-ordered copy of one nn.Conv2d(k=3) weight (+ zero-padded bias), re-packed on demand when the
+    parameter changes (torch bumps `_version` on every in-place update, e.g. an optimizer step or load_state_dict)."""
+
+    def __init__(self, weight, bias, lat, split=True, transposed=False):
+        self.weight, self.bias_p, self.lat, self.split, self.transposed = weight, bias, lat, split, transposed
+        self._key = None
+        self.wpack = None
+        self.bias = None
+
+    def _maps(self, dev):
+        w = self.weight
+        cout_w, cin_w = w.shape[0], w.shape[1]
+        lat = self.lat
+        main = cin_w - lat
+        if not self.transposed:
+            # K axis = input channels [lat | main]: the latent gets its own (zero padded) group so that the main
+            # channels stay 8-aligned with the dense-block buffers
+            kmap = []
+            if lat:
+                kmap += [e if e < lat else -1 for e in range(8)]
+            ncg_main = (main + 7) // 8
+            kmap += [lat + c if c < main else -1 for c in range(ncg_main * 8)]
+            mt = (cout_w + 31) // 32
+            mmap = [m if m < cout_w else -1 for m in range(mt * 32)]
+        else:
+            # data-gradient: K axis = cout_w (upstream gradient channels), M axis = input channels laid out
+            # [main groups | latent group]
+            ncg_k = (cout_w + 7) // 8
+            kmap = [c if c < cout_w else -1 for c in range(ncg_k * 8)]
+            mlist = [lat + c for c in range(main)]
+            mlist += [-1] * ((-len(mlist)) % 8)
+            if lat:
+                mlist += [e if e < lat else -1 for e in range(8)]
+            mt = (len(mlist) + 31) // 32
+            mmap = mlist + [-1] * (mt * 32 - len(mlist))
+        self.ncg_in = len(kmap) // 8
+        self.mtiles = mt
+        self.m_channels = len([m for m in mmap if m >= 0])
+        return (torch.tensor(kmap, dtype=torch.int32, device=dev), torch.tensor(mmap, dtype=torch.int32, device=dev))
+
+    def get(self):
+        w = self.weight
+        require_gpu(w, 'conv weight')
+        key = (w.data_ptr(), w._version, None if self.bias_p is None else (self.bias_p.data_ptr(), self.bias_p._version))
+        if key == self._key:
+            return self
+        dev = w.device
+        wd = w.detach()
+        if wd.dtype != torch.float32 or not wd.is_contiguous():
+            wd = wd.float().contiguous()
+        if self.wpack is None:
+            self.kmap, self.mmap = self._maps(dev)
+            nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, 1 if self.split else 0)
+            self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.bias = torch.zeros(self.mtiles * 32, dtype=torch.float32, device=dev)
+        check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], self.kmap.data_ptr(), self.ncg_in,
+                                             self.mmap.data_ptr(), self.mtiles, 1 if self.transposed else 0, 1 if self.split else 0,
+                                             self.wpack.data_ptr(), stream_ptr()), 'esr_pack_conv_weights')
+        if self.bias_p is not None and not self.transposed:
+            self.bias[:w.shape[0]].copy_(self.bias_p.detach().float())
+        self._key = key
+        return self
+
+
+def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
+            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2):
+    d = _lib.Conv3x3Desc()
+    d.in0 = in0 if in0 is not None else NO_VIEW
+    d.in1 = in1
+    d.upsample = upsample
+    d.wpack = pc.wpack.data_ptr()
+    d.bias = pc.bias.data_ptr() if use_bias else None
+    d.cout = cout
+    d.B, d.H, d.W = B, H, W
+    d.act_slope, d.alpha = act_slope, alpha
+    d.res1 = res1 if res1 is not None else NO_VIEW
+    d.beta1 = beta1
+    d.res2 = res2 if res2 is not None else NO_VIEW
+    d.beta2 = beta2
+    d.out = out if out is not None else NO_VIEW
+    d.out2 = out2 if out2 is not None else NO_VIEW
+    d.out_nchw = out_nchw.data_ptr() if out_nchw is not None else None
+    d.mask_src = mask_src if mask_src is not None else NO_VIEW
+    d.mask_cg0, d.mask_cg1 = mask_cg
+    d.mask_slope = mask_slope
+    check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
+
+
+def conv3x3_nchw(x, weight, bias, act_slope=1.0, split=True):
+    """Stand-alone conv3x3 on fp32 NCHW tensors (pack -> MFMA conv -> fp32 NCHW).  Used by block-level calls and tests; the
+    whole-generator path keeps activations in the kernels' layout instead (engine.py)."""
+    require_gpu(x, 'conv input')
+    x = x.detach()
+    x = (x if x.dtype == torch.float32 else x.float()).contiguous()
+    B, Cin, H, W = x.shape
+    cout = weight.shape[0]
+    assert weight.shape[1] == Cin
+    ncg = (Cin + 7) // 8
+    src = ActBuf(B, ncg, H, W, x.device, split)
+    pack_nchw(x, src.view(), 0, Cin)
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    if cout <= 64:
+        pc = PackedConv(weight, bias, 0, split=split).get()
+        conv3x3(pc, src.view(), B, H, W, cout, act_slope=act_slope, out_nchw=out)
+        return out
+    for m0 in range(0, cout, 64):      # the kernel produces up to 64 output channels per launch
+        mc = min(64, cout - m0)
+        sub = PackedConv(weight.detach()[m0:m0 + mc].contiguous(), None if bias is None else bias.detach()[m0:m0 + mc].contiguous(), 0, split=split).get()
+        tmp = torch.empty(B, mc, H, W, dtype=torch.float32, device=x.device)
+        conv3x3(sub, src.view(), B, H, W, mc, act_slope=act_slope, out_nchw=tmp)
+        out[:, m0:m0 + mc] = tmp
+    return out

@@ -1,0 +1,112 @@
+"""Host wrappers of the CEM kernels (csrc/esr_cem.hip).  fp32 NCHW in/out.  Differentiable: every op is linear with
+fixed taps, so its backward is the adjoint filter (esr_hip/autograd.py)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .act import require_gpu, stream_ptr
+
+
+def _prep(x, what):
+    require_gpu(x, what)
+    x = x if x.dtype == torch.float32 else x.float()
+    return x.contiguous()
+
+
+def _taps(t, dev):
+    t = t.detach()
+    if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+    assert t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1, 'CEM filters are odd square 2-D arrays'
+    return t
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
+
+
+def downscale_raw(y, taps, sf, pre, lr=None, lr_pad=0):
+    y = _prep(y, 'HR image')
+    taps = _taps(taps, y.device)
+    B, Cc, Hh, Wh = y.shape
+    assert Hh % sf == 0 and Wh % sf == 0, 'HR size must be divisible by the scale factor'
+    h, w = Hh // sf, Wh // sf
+    out = torch.empty(B, Cc, h, w, dtype=torch.float32, device=y.device)
+    if lr is not None:
+        lr = _prep(lr, 'LR image')
+        assert lr.shape == (B, Cc, h - 2 * lr_pad, w - 2 * lr_pad), 'LR / HR sizes do not match'
+    check(_lib.lib.esr_cem_downscale(y.data_ptr(), B, Cc, h, w, sf, pre, taps.data_ptr(), taps.shape[0],
+                                     lr.data_ptr() if lr is not None else None, lr_pad, out.data_ptr(), stream_ptr()), 'esr_cem_downscale')
+    return out
+
+
+def lr_filter_raw(x, taps):
+    x = _prep(x, 'LR image')
+    taps = _taps(taps, x.device)
+    B, Cc, h, w = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib.esr_cem_lrfilter(x.data_ptr(), B, Cc, h, w, taps.data_ptr(), taps.shape[0], out.data_ptr(), stream_ptr()), 'esr_cem_lrfilter')
+    return out
+
+
+def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0):
+    f = _prep(f, 'LR image')
+    taps = _taps(taps, f.device)
+    B, Cc, h, w = f.shape
+    Ho, Wo = sf * h - 2 * crop, sf * w - 2 * crop
+    out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=f.device)
+    out2 = torch.empty_like(out) if mode == 3 else None
+    if f2 is not None:
+        f2 = _prep(f2, 'LR image')
+    if g is not None:
+        g = _prep(g, 'generated image')
+        assert g.shape == (B, Cc, sf * h, sf * w)
+    check(_lib.lib.esr_cem_upscale(f.data_ptr(), f2.data_ptr() if f2 is not None else None, B, Cc, h, w, sf, pre, taps.data_ptr(), taps.shape[0],
+                                   g.data_ptr() if g is not None else None, crop, mode, float(rng), out.data_ptr(),
+                                   out2.data_ptr() if out2 is not None else None, stream_ptr()), 'esr_cem_upscale')
+    return (out, out2) if mode == 3 else out
+
+
+# ---- public, differentiable entry points -------------------------------------------------------------------------
+def downscale(y, taps, sf, pre):
+    if _needs_grad(y):
+        from . import autograd as AG
+        return AG.CemLinear.apply(y, taps, 'downscale', sf, pre)
+    return downscale_raw(y, taps, sf, pre)
+
+
+def lr_filter(x, taps):
+    if _needs_grad(x):
+        from . import autograd as AG
+        return AG.CemLinear.apply(x, taps, 'lr_filter', 1, 0)
+    return lr_filter_raw(x, taps)
+
+
+def upscale(x, taps, sf, pre):
+    if _needs_grad(x):
+        from . import autograd as AG
+        return AG.CemLinear.apply(x, taps, 'upscale', sf, pre)
+    return upscale_raw(x, taps, sf, pre)
+
+
+def project(lr, g, taps_down, taps_inv, taps_up, sf, pre, lr_pad=0, crop=0, sigmoid_range=None, decomposed=False):
+    """CEM_PyTorch.forward after the generator call (reference CEMnet.py:303-311).
+    lr: un-padded LR [B,C,h0,w0]; g: generator output on the (replicate-padded by lr_pad) LR frame."""
+    if _needs_grad(lr, g):
+        from . import autograd as AG
+        return AG.cem_project_with_grad(lr, g, taps_down, taps_inv, taps_up, sf, pre, lr_pad, crop, sigmoid_range, decomposed)
+    if sigmoid_range is None and not decomposed:
+        e = downscale_raw(g, taps_down, sf, pre, lr=lr, lr_pad=lr_pad)       # x - D(g) on the padded frame
+        f = lr_filter_raw(e, taps_inv)                                        # K (x - D g)
+        return upscale_raw(f, taps_up, sf, pre, g=g, crop=crop, mode=1)       # crop(g + U(.))
+    lr_p = torch.nn.functional.pad(lr, (lr_pad,) * 4, mode='replicate') if lr_pad else lr
+    fx = lr_filter_raw(lr_p, taps_inv)
+    fg = lr_filter_raw(downscale_raw(g, taps_down, sf, pre), taps_inv)
+    if decomposed:
+        ortho, ns = upscale_raw(fx, taps_up, sf, pre, f2=fg, g=g, crop=crop, mode=3)
+        if sigmoid_range is not None:
+            ns = torch.tanh(ns) * sigmoid_range
+        return [ortho, ns]
+    return upscale_raw(fx, taps_up, sf, pre, f2=fg, g=g, crop=crop, mode=2, rng=sigmoid_range)

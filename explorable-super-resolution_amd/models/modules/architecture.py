@@ -1,0 +1,88 @@
+"""RRDBNet — the ESRGAN-style generator of the reference (codes/models/modules/architecture.py:228-302) with the
+same constructor, attributes, module tree and state_dict keys, executed by the gfx950 engine (esr_hip/engine.py).
+
+Only the generator lives here; discriminators / feature extractors of the reference's architecture.py are outside the
+RRDB+CEM hot path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import block as B
+from esr_hip.engine import RRDBEngine
+
+
+class RRDBNet(nn.Module):
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32, upscale=4, norm_type=None, act_type='leakyrelu', mode='CNA',
+                 upsample_mode='upconv', latent_input=None, num_latent_channels=None):
+        super(RRDBNet, self).__init__()
+        self.latent_input = None
+        num_latent_channels = 0 if num_latent_channels is None else num_latent_channels   # (the reference raises TypeError on None)
+        num_latent_channels_HR = 0
+        if num_latent_channels > 0:
+            self.latent_input = latent_input
+            num_latent_channels_HR = 1 * num_latent_channels
+            if 'HR_rearranged' in latent_input:
+                num_latent_channels *= upscale ** 2
+        self.num_latent_channels = 1 * num_latent_channels
+        self.upscale = upscale
+        n_upscale = int(math.log(upscale, 2))
+        if upscale == 3:
+            n_upscale = 1
+        if latent_input is not None:
+            in_nc += num_latent_channels
+        if latent_input is None or 'all_layers' not in latent_input:
+            num_latent_channels, num_latent_channels_HR = 0, 0
+        if norm_type is not None:
+            raise NotImplementedError('RRDBNet with normalisation layers is not on the RRDB+CEM path (reference default: norm_type=null)')
+
+        fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, return_module_list=True)
+        # NB: like the reference (architecture.py:250) the `gc` argument is ignored: growth channels are 32.
+        rb_blocks = [B.RRDB(nf, kernel_size=3, gc=32, stride=1, bias=True, pad_type='zero', norm_type=norm_type, act_type=act_type,
+                            mode='CNA', latent_input_channels=num_latent_channels) for _ in range(nb)]
+        LR_conv = B.conv_block(nf + num_latent_channels, nf, kernel_size=3, norm_type=norm_type, act_type=None, mode=mode,
+                               return_module_list=True)
+        if upsample_mode == 'upconv':
+            upsample_block = B.upconv_blcok
+        elif upsample_mode == 'pixelshuffle':
+            upsample_block = B.pixelshuffle_block
+        else:
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
+        if upscale == 3:
+            # the reference builds a bare Sequential here and then fails to concatenate it (architecture.py:260-261,271);
+            # wrapping it in a list is the evident intent
+            upsampler = [upsample_block(nf, nf, 3, act_type=act_type)]
+        else:
+            upsampler = [upsample_block(nf, nf, act_type=act_type) for _ in range(n_upscale)]
+        HR_conv0 = B.conv_block(nf + num_latent_channels_HR, nf, kernel_size=3, norm_type=None, act_type=act_type, return_module_list=True)
+        HR_conv1 = B.conv_block(nf + num_latent_channels_HR, out_nc, kernel_size=3, norm_type=None, act_type=None, return_module_list=True)
+        self.model = nn.ModuleList(fea_conv + [B.ShortcutBlock(B.sequential(*(rb_blocks + LR_conv), return_module_list=True),
+                                                               latent_input_channels=num_latent_channels, use_module_list=True)]
+                                   + upsampler + HR_conv0 + HR_conv1)
+        self.upsample_mode = upsample_mode
+        self.nb, self.nf, self.out_nc = nb, nf, out_nc
+        self._lat_all_layers = num_latent_channels
+        self._engine = None
+
+    # ---- engine plumbing
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = RRDBEngine(self)
+        return self._engine
+
+    def set_precision(self, precision):
+        """'split' (default; bf16x3 MFMA, fp32-class accuracy) or 'bf16' (plain bf16 operands, fp32 accumulate)."""
+        assert precision in ('split', 'bf16')
+        self.engine.set_precision(precision)
+
+    def forward(self, x, pad=0):
+        """x: [B, num_latent_channels*upscale^2 + 3, h, w] (Z packed by the raw view of SRRaGAN_model.py:233, LR image last).
+        `pad` > 0 evaluates the generator on the replicate-padded input (CEM eval mode, CEMnet.py:286-295) without
+        materialising the padded tensors."""
+        if self.latent_input is not None and 'HR_downscaled' not in self.latent_input:
+            if 'HR_rearranged' in self.latent_input and 'all_layers' in self.latent_input:
+                raise Exception('Unsupported yet')          # same behaviour as architecture.py:295
+            raise NotImplementedError("latent_input '%s': only '<all_layers|first_layer>_HR_downscaled' is implemented" % self.latent_input)
+        return self.engine.forward(x, pad=pad)

@@ -1,0 +1,198 @@
+"""Building blocks of the RRDB generator — same names, signatures, module tree and state_dict keys as the reference's
+codes/models/modules/block.py, re-implemented over the gfx950 kernels of libesr_hip.so.
+
+The classes here are parameter containers with the reference's structure; a stand-alone call of a block
+(`RRDB(...)(x)`) runs layer by layer through `HipConv2d` (one HIP conv launch per layer, layout conversion at both
+ends).  The fast path is `architecture.RRDBNet.forward`, which plans the whole generator with zero-copy dense-block
+buffers and fused epilogues (esr_hip/engine.py).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from esr_hip import act as _act
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d(k=3, s=1, p=1) whose forward is the MFMA implicit-GEMM kernel (reference: block.py:141-142).
+    Keeps nn.Conv2d's parameters/keys so checkpoints and `init_weights` (networks.py:29-42) work unchanged."""
+    precision = 'split'      # 'split' (fp32-class, bf16x3) or 'bf16'
+
+    def forward(self, x, act_slope=1.0):
+        if self.kernel_size != (3, 3) or self.stride != (1, 1) or self.padding != (1, 1) or self.groups != 1 or self.dilation != (1, 1):
+            raise NotImplementedError('HipConv2d implements the RRDB path only: 3x3, stride 1, zero pad 1')
+        _act.require_gpu(x, 'conv input')
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            from esr_hip import autograd as _ag
+            return _ag.conv3x3_function(x, self.weight, self.bias, act_slope, self.precision == 'split')
+        return _act.conv3x3_nchw(x, self.weight, self.bias, act_slope, self.precision == 'split')
+
+
+def act(act_type, inplace=True, neg_slope=0.2, n_prelu=1):
+    act_type = act_type.lower()
+    if act_type == 'relu':
+        layer = nn.ReLU(inplace)
+    elif act_type == 'leakyrelu':
+        layer = nn.LeakyReLU(neg_slope, inplace)
+    elif act_type == 'prelu':
+        layer = nn.PReLU(num_parameters=n_prelu, init=neg_slope)
+    else:
+        raise NotImplementedError('activation layer [{:s}] is not found'.format(act_type))
+    return layer
+
+
+def norm(norm_type, nc):
+    norm_type = norm_type.lower()
+    if norm_type == 'batch':
+        return nn.BatchNorm2d(nc, affine=True)
+    if norm_type == 'instance':
+        return nn.InstanceNorm2d(nc, affine=False)
+    raise NotImplementedError('normalization layer [{:s}] is not found'.format(norm_type))
+
+
+def pad(pad_type, padding):
+    pad_type = pad_type.lower()
+    if padding == 0:
+        return None
+    if pad_type == 'reflect':
+        return nn.ReflectionPad2d(padding)
+    if pad_type == 'replicate':
+        return nn.ReplicationPad2d(padding)
+    raise NotImplementedError('padding layer [{:s}] is not implemented'.format(pad_type))
+
+
+def get_valid_padding(kernel_size, dilation):
+    kernel_size = kernel_size + (kernel_size - 1) * (dilation - 1)
+    return (kernel_size - 1) // 2
+
+
+def sequential(*args, return_module_list=False):
+    """Flatten Sequential (reference block.py:106-126)."""
+    if len(args) == 1:
+        if isinstance(args[0], OrderedDict):
+            raise NotImplementedError('sequential does not support OrderedDict input.')
+        return args[0]
+    modules = []
+    for module in args:
+        if isinstance(module, nn.Sequential):
+            modules.extend(module.children())
+        elif isinstance(module, nn.Module):
+            modules.append(module)
+    return modules if return_module_list else nn.Sequential(*modules)
+
+
+def conv_block(in_nc, out_nc, kernel_size, stride=1, dilation=1, groups=1, bias=True, pad_type='zero', norm_type=None,
+               act_type='relu', mode='CNA', return_module_list=False):
+    """Conv (+norm) (+act), reference block.py:129-155.  Only what the RRDB path uses is backed by HIP kernels."""
+    assert mode in ['CNA', 'NAC', 'CNAC'], 'Wong conv mode [{:s}]'.format(mode)
+    padding = get_valid_padding(kernel_size, dilation)
+    p = pad(pad_type, padding) if pad_type and pad_type != 'zero' else None
+    padding = padding if pad_type == 'zero' else 0
+    c = HipConv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=bias, groups=groups)
+    a = act(act_type) if act_type else None
+    if 'CNA' in mode:
+        n = norm(norm_type, out_nc) if norm_type else None
+        return sequential(p, c, n, a, return_module_list=return_module_list)
+    if norm_type is None and act_type is not None:
+        a = act(act_type, inplace=False)
+    n = norm(norm_type, in_nc) if norm_type else None
+    return sequential(n, a, p, c)
+
+
+class ShortcutBlock(nn.Module):
+    """Elementwise sum of a sub-module chain's output and its input (reference block.py:76-103), with the latent
+    channels re-prepended before every sub-module."""
+
+    def __init__(self, submodule, latent_input_channels=0, use_module_list=False):
+        super(ShortcutBlock, self).__init__()
+        if use_module_list:
+            submodule = nn.ModuleList(submodule)
+        self.sub = submodule
+        self.num_latent_channels = latent_input_channels
+
+    def forward(self, x):
+        if isinstance(self.sub, nn.ModuleList):
+            if self.num_latent_channels > 0:
+                latent_input = x[:, :self.num_latent_channels, ...]
+            output = x
+            for i, module in enumerate(self.sub):
+                if i > 0 and self.num_latent_channels > 0:
+                    output = torch.cat([latent_input, output], 1)
+                output = module(output)
+        else:
+            output = self.sub(x)
+        return x[:, self.num_latent_channels:, ...] + output
+
+    def __repr__(self):
+        return 'Identity + \n|' + self.sub.__repr__().replace('\n', '\n|')
+
+
+class ResidualDenseBlock_5C(nn.Module):
+    """Residual dense block, 5 convs (reference block.py:196-242)."""
+
+    def __init__(self, nc, kernel_size=3, gc=32, stride=1, bias=True, pad_type='zero', norm_type=None, act_type='leakyrelu',
+                 mode='CNA', latent_input_channels=0):
+        super(ResidualDenseBlock_5C, self).__init__()
+        self.USE_MODULE_LIST = True
+        last_act = None if mode == 'CNA' else act_type
+        self.convs = nn.ModuleList([
+            conv_block(nc + i * gc + latent_input_channels, gc if i < 4 else nc, kernel_size if i < 4 else 3, stride, bias=bias,
+                       pad_type=pad_type, norm_type=norm_type, act_type=act_type if i < 4 else last_act, mode=mode)
+            for i in range(5)])
+
+    def forward(self, x):
+        outputs = [x]
+        for layer in self.convs:
+            outputs.append(layer(torch.cat(outputs, 1)))
+        return outputs[-1].mul(0.2) + outputs[0][:, -outputs[-1].size()[1]:, ...]
+
+
+class RRDB(nn.Module):
+    """Residual in residual dense block (reference block.py:245-270)."""
+
+    def __init__(self, nc, kernel_size=3, gc=32, stride=1, bias=True, pad_type='zero', norm_type=None, act_type='leakyrelu',
+                 mode='CNA', latent_input_channels=0):
+        super(RRDB, self).__init__()
+        self.num_latent_channels = latent_input_channels
+        self.RDB1 = ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias, pad_type, norm_type, act_type, mode, latent_input_channels)
+        self.RDB2 = ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias, pad_type, norm_type, act_type, mode, latent_input_channels)
+        self.RDB3 = ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias, pad_type, norm_type, act_type, mode, latent_input_channels)
+
+    def forward(self, x):
+        z = x[:, :self.num_latent_channels, ...]
+        out = self.RDB1(x)
+        if self.num_latent_channels > 0:
+            out = torch.cat([z, out], 1)
+        out = self.RDB2(out)
+        if self.num_latent_channels > 0:
+            out = torch.cat([z, out], 1)
+        out = self.RDB3(out)
+        return out.mul(0.2) + x[:, -out.size()[1]:, ...]
+
+
+def pixelshuffle_block(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True, pad_type='zero', norm_type=None,
+                       act_type='relu'):
+    """Pixel-shuffle upsampler (reference block.py:278-291); reachable through RRDBNet(upsample_mode='pixelshuffle')."""
+    conv = conv_block(in_nc, out_nc * (upscale_factor ** 2), kernel_size, stride, bias=bias, pad_type=pad_type, norm_type=None, act_type=None)
+    n = norm(norm_type, out_nc) if norm_type else None
+    a = act(act_type) if act_type else None
+    return sequential(conv, nn.PixelShuffle(upscale_factor), n, a)
+
+
+class Upsampler(nn.Module):
+    def __init__(self, upscale_factor, mode):
+        super(Upsampler, self).__init__()
+        self.upscale_factor = upscale_factor
+        self.mode = mode
+
+    def forward(self, input):
+        return nn.functional.interpolate(input, scale_factor=self.upscale_factor, mode=self.mode)
+
+
+def upconv_blcok(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True, pad_type='zero', norm_type=None,
+                 act_type='relu', mode='nearest'):
+    """nearest upsample + conv (+act), reference block.py:302-309 (the reference's spelling of the name is kept)."""
+    upsample = Upsampler(upscale_factor, mode)
+    conv = conv_block(in_nc, out_nc, kernel_size, stride, bias=bias, pad_type=pad_type, norm_type=norm_type, act_type=act_type)
+    return sequential(upsample, conv)

@@ -1,0 +1,146 @@
+/*
+ * esr_hip.h — C-ABI of libesr_hip.so: the MI355X (gfx950) kernels behind the reference's
+ * RRDB generator + Consistency Enforcing Module (CEM) hot path.
+ *
+ * The reference (YuvalBahat/Explorable-Super-Resolution) is pure Python/PyTorch and has no FFI of
+ * its own; the operators it reaches through torch.nn are listed next to each entry point, with
+ * the reference file:line they replace.  A maintainer binds these with ctypes;
+ * the in-tree binding is explorable-super-resolution_amd/esr_hip/_lib.py.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only; every pointer is a caller-owned DEVICE pointer unless it is a
+ *     descriptor struct (host memory, read during the call).
+ *   - return 0 on success, <0 on bad argument / unsupported shape (ESR_E_*); never throws, never
+ *     allocates device memory, never synchronises: work is enqueued on `stream` (hipStream_t).
+ *   - stateless and thread-safe: one process per GPU or several host threads may call concurrently.
+ *
+ * Internal activation layout ("act view"), used between the conv kernels so that dense-block
+ * concatenation is zero-copy and every MFMA operand fragment is one aligned 16-byte read:
+ *     [B][CG][H+2][W+2][8]  of bf16, i.e. channels in groups of 8 ("cg"), one 16-byte vector per
+ *     pixel per group, with a ONE-PIXEL ZERO BORDER stored in memory (conv zero padding costs no
+ *     bounds logic; producers never write the border).
+ *   `hi` holds bf16(x); `lo` (optional) holds bf16(x - hi): together ~16 mantissa bits.  With both
+ *   planes the conv kernels evaluate hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe with fp32
+ *   accumulation ("split-bf16", rel. error ~1e-5 vs fp32); with lo == NULL they run plain bf16.
+ */
+#ifndef ESR_HIP_H
+#define ESR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESR_OK 0
+#define ESR_E_ARG (-1)        /* NULL / inconsistent argument */
+#define ESR_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define ESR_E_LAUNCH (-3)      /* HIP reported a launch error */
+
+typedef void* esr_stream_t;   /* hipStream_t */
+
+/* A view of `ncg` consecutive channel groups inside an activation buffer. */
+typedef struct {
+    void* hi;                /* bf16 planes, NULL = view absent */
+    void* lo;                /* bf16 residual planes or NULL (plain-bf16 mode) */
+    int32_t ncg;             /* number of 8-channel groups in this view */
+    int32_t H, W;            /* interior size; the buffer holds (H+2) x (W+2) pixels per group */
+    int64_t batch_stride;    /* in 16-byte pixel vectors */
+    int64_t cg_stride;       /* in 16-byte pixel vectors (normally (H+2)*(W+2)) */
+} esr_act_view;
+
+/* ---- conv3x3 (+bias, +LeakyReLU, +scaled residuals, + fused nearest upsample of the input) ----
+ * Replaces, per call, the reference chain
+ *     torch.cat(inputs) -> nn.Conv2d(k=3,s=1,p=1,bias) -> LeakyReLU(0.2) -> .mul(0.2) + residual
+ *   codes/models/modules/block.py:129-146 (conv_block), :230-235 (ResidualDenseBlock_5C.forward),
+ *   :262-270 (RRDB.forward), :85-97 (ShortcutBlock.forward), :293-309 (Upsampler + upconv_blcok),
+ *   codes/models/modules/architecture.py:288-301 (latent re-concatenation before every conv).
+ * Also used as the data-gradient of the same conv (weights packed transposed+flipped).
+ *
+ *   out = alpha * act(conv(in0 ++ in1) + bias) + beta1*res1 + beta2*res2
+ */
+typedef struct {
+    esr_act_view in0;        /* optional leading segment (latent Z group); ncg = 0 when absent */
+    esr_act_view in1;        /* main segment; with upsample>1 it is read as in1[y/upsample][x/upsample] */
+    int32_t upsample;        /* 1, 2 or 3 */
+    const void* wpack;       /* weights packed by esr_pack_conv_weights for (in0.ncg + in1.ncg) groups */
+    const float* bias;       /* [mtiles*32] fp32, zero padded; NULL = no bias */
+    int32_t cout;            /* real output channels */
+    int32_t B, H, W;         /* output interior size (= input size * upsample) */
+    float act_slope;         /* 1.0f: identity; 0.2f: LeakyReLU(0.2) */
+    float alpha;
+    esr_act_view res1; float beta1;   /* optional (hi == NULL: absent); same H, W as the output */
+    esr_act_view res2; float beta2;
+    esr_act_view out;        /* act-layout destination (ncg*8 >= cout), or hi == NULL */
+    esr_act_view out2;       /* optional second destination (same values) */
+    float* out_nchw;         /* optional fp32 [B][cout][H][W] destination */
+    /* data-gradient helper: multiply the result for output groups [mask_cg0, mask_cg1) by
+     * act'(mask_src) = (mask_src > 0 ? 1 : mask_slope) AFTER the residual add (LeakyReLU backward of
+     * the layer that produced those channels; block.py:18). mask_src.hi == NULL: disabled. */
+    esr_act_view mask_src; int32_t mask_cg0, mask_cg1; float mask_slope;
+} esr_conv3x3_desc;
+
+int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
+
+/* Packed-weight size in bytes for `ncg_in` input groups and `cout` output channels
+ * (`split` = 1: hi+lo planes, 0: hi only). */
+size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split);
+
+/* Pack nn.Conv2d weights [cout_w][cin_w][3][3] (fp32, device) into MFMA fragment order.
+ *   kmap[ncg_in*8]  : for each (group, lane-in-group) the index into the tensor's "K" channel axis, or -1 (zero)
+ *   mmap[mtiles*32] : for each output row the index into the "M" channel axis, or -1 (zero)
+ *   transposed = 0 : forward     — M axis = dim 0 (cout_w), K axis = dim 1 (cin_w), tap (dy,dx) as stored
+ *   transposed = 1 : data-grad   — M axis = dim 1 (cin_w),  K axis = dim 0 (cout_w), tap flipped (2-dy,2-dx)
+ * kmap/mmap are device int32 arrays. */
+int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* kmap, int ncg_in,
+                          const int32_t* mmap, int mtiles, int transposed, int split, void* wpack,
+                          esr_stream_t stream);
+
+/* ---- layout conversion at the module boundary ----
+ * fp32 NCHW -> act view.  Writes channels [c0, c0+nc) of `src` ([B][C][h][w]; image b starts at
+ * src + b*src_batch_stride floats, 0 = C*h*w — lets the HR-resolution latent be read through the raw
+ * `view` the reference applies to it, SRRaGAN_model.py:233 / architecture.py:283) into group 0.. of `dst`
+ * (zero-filling unused lanes of the last group and the 1-px border), with
+ *   pad  : replicate padding by `pad` pixels on every side (CEM_PyTorch.forward eval-mode LR_padder /
+ *          HR_padder, codes/CEM/CEMnet.py:286-295), dst interior = (h+2*pad)/down x (w+2*pad)/down
+ *   down : 1, or the bilinear /down of architecture.py:284 (F.interpolate(scale_factor=1/sf,'bilinear',
+ *          align_corners=False)) applied AFTER the padding (down divides h+2*pad). */
+int esr_pack_nchw(const float* src, int64_t src_batch_stride, int B, int C, int h, int w, int c0, int nc, int pad, int down,
+                  const esr_act_view* dst, esr_stream_t stream);
+/* act view -> fp32 NCHW [B][nc][H][W] (hi + lo); used by tests and by callers that want features. */
+int esr_unpack_nchw(const esr_act_view* src, int B, int nc, float* dst, esr_stream_t stream);
+/* zero `n16` 16-byte vectors (border initialisation of freshly allocated activation buffers) */
+int esr_zero(void* p, int64_t n16, esr_stream_t stream);
+
+/* ---- Consistency Enforcing Module filters (fixed depth-wise taps, fp32, NCHW) ----
+ * codes/CEM/CEMnet.py:243-252 (Filter_Layer) x3 as built in CEM_PyTorch.__init__ (:254-281).
+ * `taps` are device fp32 [k][k] arrays exactly as the reference stores them in Filter_OP.weight[0,0]. */
+
+/* DownscaleOP (CEMnet.py:272-275): replicate-pad floor(k/2), correlate with taps (= rot90(ds_kernel,2)),
+ * keep [pre::sf, pre::sf].  y: [B][C][sf*h][sf*w] -> d: [B][C][h][w].
+ * If lr != NULL the kernel writes  lr_pad - d  instead, where lr_pad is `lr` ([B][C][h-2*lr_pad][w-2*lr_pad])
+ * replicate-padded by lr_pad (fuses the LR_padder and the x - D(g) of the projection). */
+int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k,
+                      const float* lr, int lr_pad, float* d, esr_stream_t stream);
+/* Conv_LR_with_Inv_hTh_OP (CEMnet.py:261-263): replicate-pad floor(k/2), correlate. [B][C][h][w] -> same. */
+int esr_cem_lrfilter(const float* x, int B, int C, int h, int w, const float* taps, int k, float* out,
+                     esr_stream_t stream);
+/* Upscale_OP (CEMnet.py:264-271): zero-stuff at (pre,pre), replicate-pad floor(k/2), correlate with taps
+ * (= ds_kernel*sf^2).  f: [B][C][h][w] -> [B][C][sf*h][sf*w], restricted to the crop window
+ * [crop, sf*h-crop) x [crop, sf*w-crop) (HR_unpadder, CEMnet.py:311).
+ *   mode 0: out = U(f)
+ *   mode 1: out = g + U(f)                      (projection  g + U(K(x - D(g))), CEMnet.py:305-310)
+ *   mode 2: out = U(f_x) + tanh(g - U(f_g)) * range      (sigmoid_range_limit; f = f_x, f2 = f_g)
+ *   mode 3: out = U(f_x), out2 = g - U(f_g)              (decomposed_output)
+ * g/out/out2 are [B][C][sf*h][sf*w] and [B][C][sf*h-2crop][sf*w-2crop] respectively. */
+int esr_cem_upscale(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre,
+                    const float* taps, int k, const float* g, int crop, int mode, float range,
+                    float* out, float* out2, esr_stream_t stream);
+
+int esr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESR_HIP_H */

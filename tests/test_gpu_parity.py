@@ -1,0 +1,191 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI of libesr_hip.so, against the CPU
+oracle on the same seeded inputs and against the golden vectors generated from the reference.
+
+Tolerances (stated per the north star): generator outputs within 1e-3 relative of the fp32 CPU path (split-bf16 operands give
+~1e-5); CEM filter ops are plain fp32 (<= 2e-6 abs on O(1) data); integer conventions (sizes, margins, strides) exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cem_oracle as co
+from oracle import rrdb_oracle as ro
+from oracle.check_golden import load, rel_l2, rel_max
+from oracle.weights import fill_formula_weights, seeded_uniform
+from oracle.gen_golden import aniso_gaussian_kernel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_library_loaded_on_gpu_box():
+    from esr_hip import load_library, library_path
+    assert load_library().esr_version() >= 100
+    import os
+    assert os.path.exists(library_path())
+
+
+def test_pack_unpack_roundtrip():
+    from esr_hip import act as A
+    x = seeded_uniform((2, 11, 9, 13), 1, -2.0, 2.0).to(DEV)
+    buf = A.ActBuf(2, 2, 9, 13, DEV, split=True)
+    A.pack_nchw(x, buf.view(), 0, 11)
+    y = buf.to_nchw(11)
+    assert (y - x).abs().max().item() < 2e-5           # hi+lo carries ~16 mantissa bits
+    hi = buf.hi.cpu()
+    assert hi[:, :, 0].abs().sum() == 0 and hi[:, :, -1].abs().sum() == 0 and hi[:, :, :, 0].abs().sum() == 0 and hi[:, :, :, -1].abs().sum() == 0
+    # replicate padding folded into the pack
+    buf2 = A.ActBuf(2, 2, 9 + 6, 13 + 6, DEV, split=True)
+    A.pack_nchw(x, buf2.view(), 0, 11, pad=3)
+    ref = torch.nn.functional.pad(x, (3,) * 4, mode='replicate')
+    assert (buf2.to_nchw(11) - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout,H,W,slope', [(3, 64, 12, 16, 1.0), (64, 32, 17, 23, 0.2), (67, 32, 9, 40, 0.2), (192, 64, 33, 21, 1.0),
+                                                (64, 3, 40, 37, 1.0), (96, 128, 10, 10, 0.2)])
+def test_conv3x3_matches_torch_cpu(cin, cout, H, W, slope):
+    from esr_hip import act as A
+    x = seeded_uniform((2, cin, H, W), cin + cout, -1.0, 1.0)
+    w = seeded_uniform((cout, cin, 3, 3), cin * 7 + cout, -1.0, 1.0) * float(np.sqrt(2.0 / (9 * cin)))
+    b = seeded_uniform((cout,), cout, -0.1, 0.1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1), slope)
+    y = A.conv3x3_nchw(x.to(DEV), w.to(DEV), b.to(DEV), slope, split=True).cpu()
+    assert rel_l2(y.numpy(), ref.numpy()) < 5e-5 and rel_max(y.numpy(), ref.numpy()) < 1e-4
+    yb = A.conv3x3_nchw(x.to(DEV), w.to(DEV), b.to(DEV), slope, split=False).cpu()     # plain bf16 operands
+    assert rel_l2(yb.numpy(), ref.numpy()) < 1.5e-2
+
+
+F2_CASES = [('cubic_x4', 4, None, None), ('cubic_x2', 2, None, None), ('cubic_x3', 3, None, None), ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1)]
+
+
+def _cem(sf, kernel, bound):
+    import CEM.CEMnet as C
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    conf = C.Get_CEM_Conf(sf)
+    if bound:
+        conf.lower_magnitude_bound = bound
+    return C.CEMnet(conf, upscale_kernel=kernel)
+
+
+@pytest.mark.parametrize('name,sf,kernel,bound', F2_CASES, ids=[c[0] for c in F2_CASES])
+def test_cem_filter_ops_match_reference_golden(name, sf, kernel, bound):
+    g = load('cem_filter_ops.npz')
+    net = _cem(sf, kernel, bound).WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    lr = seeded_uniform((2, 3, 20, 24), 11).to(DEV)
+    hr = seeded_uniform((2, 3, 20 * sf, 24 * sf), 12).to(DEV)
+    with torch.no_grad():
+        np.testing.assert_allclose(net.DownscaleOP(hr).cpu().numpy(), g[name + '/DownscaleOP'], atol=3e-6)
+        np.testing.assert_allclose(net.Conv_LR_with_Inv_hTh_OP(lr).cpu().numpy(), g[name + '/Conv_LR_with_Inv_hTh_OP'], atol=6e-6)
+        np.testing.assert_allclose(net.Upscale_OP(lr).cpu().numpy(), g[name + '/Upscale_OP'], atol=3e-6)
+    if kernel is None:
+        import CEM.CEMnet as C
+        from CEM.imresize_CEM import imresize
+        imresize.kernels = {}
+        with torch.no_grad():
+            np.testing.assert_allclose(C.CEM_downsampler(sf).to(DEV)(hr).cpu().numpy(), g[name + '/CEM_downsampler'], atol=3e-6)
+            np.testing.assert_allclose(C.CEM_downsampler(sf, grayscale=True).to(DEV)(hr[:, :1].contiguous()).cpu().numpy(),
+                                       g[name + '/CEM_downsampler_gray'], atol=3e-6)
+
+
+def test_cem_pair_forward_matches_reference_golden():
+    g = load('cem_forward.npz')
+    for name, sf, kernel, bound in [('cubic_x4', 4, None, None), ('cubic_x2', 2, None, None), ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1)]:
+        net = _cem(sf, kernel, bound).WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+        lr = seeded_uniform((2, 3, 12, 16), 21).to(DEV)
+        gen = seeded_uniform((2, 3, 12 * sf, 16 * sf), 22).to(DEV)
+        with torch.no_grad():
+            net.train()
+            np.testing.assert_allclose(net([lr, gen]).cpu().numpy(), g[name + '/train'], atol=2e-5)
+            net.eval()
+            np.testing.assert_allclose(net([lr, gen]).cpu().numpy(), g[name + '/eval'], atol=2e-5)
+    import CEM.CEMnet as C
+    lr = seeded_uniform((2, 3, 12, 16), 21).to(DEV)
+    gen = seeded_uniform((2, 3, 48, 64), 22).to(DEV)
+    cem = _cem(4, None, None)
+    cem.conf.sigmoid_range_limit = True
+    cem.conf.input_range = np.array([0, 1])
+    net = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    with torch.no_grad():
+        np.testing.assert_allclose(net.train()([lr, gen]).cpu().numpy(), g['cubic_x4_sigmoid/train'], atol=2e-5)
+    cem = _cem(4, None, None)
+    cem.conf.decomposed_output = True
+    net = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    with torch.no_grad():
+        o = net.train()([lr, gen])
+        np.testing.assert_allclose(o[0].cpu().numpy(), g['cubic_x4_decomposed/train_ortho'], atol=2e-5)
+        np.testing.assert_allclose(o[1].cpu().numpy(), g['cubic_x4_decomposed/train_NS'], atol=2e-5)
+        np.testing.assert_allclose(net.eval()([lr, gen]).cpu().numpy(), g['cubic_x4_decomposed/eval'], atol=2e-5)
+
+
+F4_CASES = [('nb1_x4', 1, 4, 0), ('nb3_x4', 3, 4, 0), ('nb1_x8', 1, 8, 0), ('nb1_x2', 1, 2, 0),
+            ('nb1_x4_lat3', 1, 4, 3), ('nb2_x4_lat3', 2, 4, 3), ('nb1_x2_lat1', 1, 2, 1)]
+
+
+def _rrdb(nb, sf, lat):
+    import models.modules.architecture as arch
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA',
+                       upsample_mode='upconv', latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+    fill_formula_weights(net, gain=1.0)
+    return net
+
+
+def _f4_input(nb, sf, lat):
+    h, w = (12, 16) if sf != 8 else (8, 8)
+    x = seeded_uniform((1, 3 + lat * sf * sf, h, w), 31 + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+    if lat:
+        x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+    return x
+
+
+@pytest.mark.parametrize('name,nb,sf,lat', F4_CASES, ids=[c[0] for c in F4_CASES])
+def test_rrdb_forward_matches_reference_golden(name, nb, sf, lat):
+    g = load('rrdb_fwd_bwd.npz')
+    net = _rrdb(nb, sf, lat)
+    assert sum(p.numel() for p in net.parameters()) == int(g[name + '/nparams'][1])
+    net = net.to(DEV)
+    x = _f4_input(nb, sf, lat)
+    with torch.no_grad():
+        y = net(x.to(DEV)).cpu().numpy()
+    # 1e-3 relative is the contract; split-bf16 lands around 1e-5
+    assert rel_l2(y, g[name + '/out']) < 1e-4 and rel_max(y, g[name + '/out']) < 3e-4, (rel_l2(y, g[name + '/out']), rel_max(y, g[name + '/out']))
+    # and against the CPU oracle evaluated here on the same weights
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = ro.rrdb_forward(sd, x, nb, sf, lat).numpy()
+    assert rel_l2(y, ref) < 1e-4
+
+
+def test_c1_end_to_end_matches_reference_golden():
+    """BASELINE config 1 (RRDB-3 x4 + CEM, eval, [1,3,32,32]) and its explorable (lat=3) variant."""
+    g = load('c1_end_to_end.npz')
+    import CEM.CEMnet as C
+    cem = _cem(4, None, None)
+    G = cem.WrapArchitecture_PyTorch(_rrdb(3, 4, 0))
+    fill_formula_weights(G, gain=1.0)
+    assert list(G.state_dict().keys()) == [str(k) for k in g['c1/keys']]
+    assert [str(tuple(v.shape)) for v in G.state_dict().values()] == [str(s) for s in g['c1/key_shapes']]
+    G = G.to(DEV)
+    x = seeded_uniform((1, 3, 32, 32), 51).to(DEV)
+    with torch.no_grad():
+        y = G.eval()(x)
+        assert y.shape == (1, 3, 128, 128)
+        yt = G.train()(x)
+    assert rel_l2(y.cpu().numpy(), g['c1/out']) < 1e-4 and rel_max(y.cpu().numpy(), g['c1/out']) < 3e-4
+    assert rel_l2(yt.cpu().numpy(), g['c1/out_train_mode']) < 1e-4
+    # downsample-consistency of the CEM output (interior), measured with the HIP CEM_downsampler-equivalent
+    with torch.no_grad():
+        d = G.DownscaleOP(y)
+    m = int(cem.invalidity_margins_LR)
+    rmse = float(((d - x)[:, :, m:-m, m:-m] ** 2).mean().sqrt())
+    assert rmse < 5e-5, rmse     # the reference itself measures 1.0e-5 on these O(3)-amplitude formula weights (golden)
+    assert abs(rmse - float(g['c1/consistency_interior_rmse'])) < 3e-5
+
+    G = cem.WrapArchitecture_PyTorch(_rrdb(2, 4, 3))
+    fill_formula_weights(G, gain=1.0)
+    assert list(G.state_dict().keys()) == [str(k) for k in g['c1_lat3/keys']]
+    G = G.to(DEV)
+    z = seeded_uniform((1, 3, 128, 128), 52, -1.0, 1.0).to(DEV)
+    xin = torch.cat([z.contiguous().view(1, 48, 32, 32), x], 1)
+    with torch.no_grad():
+        y = G.eval()(xin)
+    assert rel_l2(y.cpu().numpy(), g['c1_lat3/out']) < 1e-4
