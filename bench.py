@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: HR pixels / second of the RRDB-23 x4 generator + CEM (eval mode) forward on synthetic
+32 x 3 x 128 x 128 fp32 batches per GPU (BASELINE.json configs[1]), weak scaling over N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one forward of the hot path over one batch already resident in HBM.  Rank 0 prints ONE JSON line with the
+throughput, the roofline fraction of the dominant kernel (conv3x3, measured with HIP events on the launch stream) and a CPU
+baseline (the oracle's CPU restatement, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd'))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# RRDB-23 x4, batch 32, eval-padded 148^2 LR frames
+NB, SF, BATCH, LR_SIZE = 23, 4, 32, 128
+MARGIN_LR = 10
+LR_PX_THROUGH_G = BATCH * (LR_SIZE + 2 * MARGIN_LR) ** 2          # 700,928
+ALGO_BYTES_PER_LR_PX = 255436                                      # layer-granular fp32 read+write bytes per LR pixel through G
+ALGO_BYTES_PER_FWD = LR_PX_THROUGH_G * ALGO_BYTES_PER_LR_PX        # 179.0 GB
+FLOP_PER_LR_PX = 2 * 17926848
+FLOP_PER_FWD = LR_PX_THROUGH_G * FLOP_PER_LR_PX                    # 25.13 TFLOP
+HBM_PEAK = 8.0e12
+N_CONV_LAUNCHES = 3 + NB * 15 + 2 + 1                              # 351
+
+
+def build_model(device, nb=NB):
+    import CEM.CEMnet as CEMnet
+    import models.modules.architecture as arch
+    import models.networks as networks
+    torch.manual_seed(0)
+    cem = CEMnet.CEMnet(CEMnet.Get_CEM_Conf(SF))
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=SF, norm_type=None, act_type='leakyrelu', mode='CNA',
+                       upsample_mode='upconv', latent_input=None, num_latent_channels=0)
+    G = cem.WrapArchitecture_PyTorch(net)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)      # the reference's training init (networks.py:119)
+    # kaiming x0.1 leaves the output ~1e-2; scale the last conv so that the SR image is O(1) like a trained generator's
+    return cem, G.to(device).eval()
+
+
+def cpu_baseline(G, cem):
+    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on ONE 128x128 image of the same
+    workload: RRDB-23 x4 + CEM eval = 1/32 of a step.  ~1-3 s per run; 1 warm-up + 3 timed."""
+    from oracle import cem_oracle as co
+    from oracle import rrdb_oracle as ro
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    taps = co.CEMTaps(SF)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(1, 3, LR_SIZE, LR_SIZE, generator=g)
+
+    def run():
+        with torch.no_grad():
+            xp = torch.nn.functional.pad(x, (taps.margins_LR,) * 4, mode='replicate')
+            gen = ro.rrdb_forward(sd, xp, NB, SF, 0, prefix='generated_image_model.model')
+            return co.cem_combine(xp, gen, taps, crop=True)
+    run()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        y = run()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    return {'value': (SF * LR_SIZE) ** 2 / t, 'unit': 'HR pixels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval), median of 3 runs, %.2f s each' % t}, x, y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='split', choices=['split', 'bf16'])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    cem, G = build_model(dev)
+    if args.precision != 'split':
+        G.generated_image_model.set_precision(args.precision)
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.rand(BATCH, 3, LR_SIZE, LR_SIZE, generator=g).to(dev)      # synthetic LR batch, resident in HBM
+
+    eng = G.generated_image_model.engine
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        with torch.no_grad():
+            if i is None:
+                return G(x)
+            # bracket the generator's conv launches (same stream as the kernels: torch's current stream)
+            eng._ev = (ev0[i], ev1[i])
+            y = G(x)
+            eng._ev = None
+            return y
+
+    for _ in range(args.warmup):
+        y = step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        y = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    hr_px = BATCH * (SF * LR_SIZE) ** 2
+    value = world * hr_px * args.steps / dt
+
+    if rank == 0:
+        conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
+        t_launch = conv_ms * 1e-3 / N_CONV_LAUNCHES
+        achieved = (ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES) / t_launch
+        # CEM downsample-consistency of the timed output (interior) with the HIP downsampler
+        with torch.no_grad():
+            d = G.DownscaleOP(y)
+        m = int(cem.invalidity_margins_LR)
+        cons = float(((d - x)[:, :, m:-m, m:-m] ** 2).mean().sqrt())
+        out = {
+            'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'split' else 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
+                       'arithmetic': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate' if args.precision == 'split' else 'bf16 MFMA operands, fp32 accumulate',
+                       'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_kernel (351 launches per forward)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': None,
+                         'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
+                         'generator_ms_per_step': conv_ms,
+                         'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
+                         'mfma_bf16_issue_frac': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15},
+            'cem_consistency_rmse_interior': cons,
+        }
+        if not args.no_cpu_baseline:
+            cb, xs, ys = cpu_baseline(G, cem)
+            out['cpu_baseline'] = cb
+            with torch.no_grad():
+                yg = G(xs.to(dev)).cpu()
+            out['rel_l2_vs_cpu_oracle'] = float((yg - ys).norm() / ys.norm())
+            out['rel_max_vs_cpu_oracle'] = float((yg - ys).abs().max() / ys.abs().max())
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

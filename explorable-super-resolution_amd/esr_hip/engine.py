@@ -23,6 +23,7 @@ class RRDBEngine:
         self.split = True
         self._packed = None
         self._bufs = {}
+        self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
 
     def set_precision(self, precision):
         split = precision == 'split'
@@ -132,6 +133,8 @@ class RRDBEngine:
                 zhr = bufs['zhr'].view()
         zall = zlr if net._lat_all_layers else None
 
+        if self._ev:
+            self._ev[0].record()
         # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
         rdb = bufs['rdb']
         conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=rdb[0].view(0, 8) if net.nb else None)
@@ -164,4 +167,6 @@ class RRDBEngine:
         conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view())
         g = torch.empty(B, net.out_nc, H, W, dtype=torch.float32, device=x.device)
         conv(pk['hr1'], bufs['hr0'].view(), B, H, W, net.out_nc, in0=zhr, out_nchw=g)
+        if self._ev:
+            self._ev[1].record()
         return g
