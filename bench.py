@@ -53,7 +53,8 @@ def cpu_baseline(G, cem):
     workload: RRDB-23 x4 + CEM eval = 1/32 of a step.  ~1-3 s per run; 1 warm-up + 3 timed."""
     from oracle import cem_oracle as co
     from oracle import rrdb_oracle as ro
-    torch.set_num_threads(os.cpu_count())
+    ncores = min(len(os.sched_getaffinity(0)), 64)     # cores this process may actually use (cgroup/affinity aware)
+    torch.set_num_threads(ncores)
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
     taps = co.CEMTaps(SF)
     g = torch.Generator().manual_seed(1)

@@ -128,6 +128,7 @@ extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int
     if (!y || !taps || !d || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 1 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
     if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
     const long long total = (long long)B * C * h * w;
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(cem_downscale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, h, w, sf, pre, taps, k,
                        lr, lr_pad, d, total);
     ESR_CHECK_LAUNCH();
@@ -137,6 +138,7 @@ extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int
 extern "C" int esr_cem_lrfilter(const float* x, int B, int C, int h, int w, const float* taps, int k, float* out, esr_stream_t stream) {
     if (!x || !taps || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || k < 1 || !(k & 1)) return ESR_E_ARG;
     const long long total = (long long)B * C * h * w;
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(cem_lrfilter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, h, w, taps, k, out,
                        total);
     ESR_CHECK_LAUNCH();
@@ -152,6 +154,7 @@ extern "C" int esr_cem_upscale(const float* f, const float* f2, int B, int C, in
     if (mode == 3 && !out2) return ESR_E_ARG;
     const long long total = (long long)B * C * (h * sf - 2 * crop) * (w * sf - 2 * crop);
     const dim3 grid((unsigned)((total + 255) / 256));
+    ESR_CLEAR_ERR();
     if (mode >= 2)
         hipLaunchKernelGGL(cem_upscale_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode, range,
                            out, out2, total);

@@ -39,6 +39,9 @@ static inline DView to_dview(const esr_act_view& v) {
     return d;
 }
 
+// hipGetLastError() is sticky-until-read and shared with the host framework: drop whatever an earlier, unrelated call left
+// behind before launching, so that ESR_CHECK_LAUNCH reports only our own launch
+#define ESR_CLEAR_ERR() (void)hipGetLastError()
 #define ESR_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

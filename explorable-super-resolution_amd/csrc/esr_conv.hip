@@ -326,6 +326,7 @@ int launch(const ConvArgs& a, int B, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y * B), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
@@ -343,6 +344,7 @@ extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, cons
     if (!w || !kmap || !mmap || !wpack || ncg_in <= 0 || mtiles <= 0) return ESR_E_ARG;
     const int ncp = (ncg_in + 1) / 2;
     const int total = ncp * 9 * mtiles * 64;
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w, kmap,
                        ncg_in, mmap, mtiles, transposed, split ? 2 : 1, (uint4*)wpack, total);
     ESR_CHECK_LAUNCH();

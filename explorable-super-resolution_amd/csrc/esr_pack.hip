@@ -90,6 +90,7 @@ extern "C" int esr_pack_nchw(const float* src, int64_t src_batch_stride, int B, 
     const int Hd = (h + 2 * pad) / down, Wd = (w + 2 * pad) / down;
     if (dst->H != Hd || dst->W != Wd || dst->ncg * 8 < nc) return ESR_E_ARG;
     const long long total = (long long)B * dst->ncg * (Hd + 2) * (Wd + 2);
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long long)(src_batch_stride ? src_batch_stride : (int64_t)C * h * w), C, h, w, c0, nc, pad,
                        down, (uint4*)dst->hi, (uint4*)dst->lo, (long long)dst->batch_stride, (long long)dst->cg_stride, dst->ncg, Hd, Wd, total);
@@ -100,6 +101,7 @@ extern "C" int esr_pack_nchw(const float* src, int64_t src_batch_stride, int B, 
 extern "C" int esr_unpack_nchw(const esr_act_view* src, int B, int nc, float* dst, esr_stream_t stream) {
     if (!src || !src->hi || !dst || B <= 0 || nc <= 0 || src->ncg * 8 < nc) return ESR_E_ARG;
     const long long total = (long long)B * ((nc + 7) / 8) * src->H * src->W;
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(unpack_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src->hi,
                        (const uint4*)src->lo, (long long)src->batch_stride, (long long)src->cg_stride, src->H, src->W, nc, dst, total);
     ESR_CHECK_LAUNCH();
@@ -111,6 +113,7 @@ extern "C" int esr_zero(void* p, int64_t n16, esr_stream_t stream) {
     if (n16 == 0) return ESR_OK;
     long long blocks = (n16 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    ESR_CLEAR_ERR();
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)p, (long long)n16);
     ESR_CHECK_LAUNCH();
     return ESR_OK;

@@ -56,6 +56,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; whichever copy of that SONAME is loaded first serves the whole process, and device
+    # pointers / streams are only meaningful inside ONE runtime instance — so torch's must be in place before ours is resolved
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise EsrError('%s not found: build it with `make -C explorable-super-resolution_amd/csrc` (or __graft_entry__.build()). '
