@@ -24,7 +24,7 @@ namespace {
 
 constexpr int NW = 4;          // waves per workgroup
 constexpr int NTHREADS = 256;
-constexpr int NIT = 3;         // staging iterations: (TH+2)*P <= NIT*256
+constexpr int MAXS = 3;        // activation DMA slots per wave per plane: NPIX_L <= MAXS*NW*64
 
 struct ConvArgs {
     DView in0, in1;
@@ -32,7 +32,7 @@ struct ConvArgs {
     const uint4* wpack;
     const float* bias;
     int cout, H, W;                 // output interior
-    int TH, TW, P, NT, NPIX_T, NPIX_L, tiles_x, tiles_y, ncp;
+    int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y, ncp;
     float act_slope, alpha, beta1, beta2;
     DView res1, res2, out, out2, mask;
     float* out_nchw;
@@ -44,6 +44,11 @@ __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// async global -> LDS copy of 16 bytes per lane; LDS destination = (wave-uniform) dst + lane*16
+__device__ __forceinline__ void glds16(const uint4* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
 // (their packed weights are zero, the data only has to be finite)
 __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b, bool lo) {
@@ -53,10 +58,14 @@ __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b
     return (lo ? a.in1.lo : a.in1.hi) + b * a.in1.bs + g1 * a.in1.cs;
 }
 
-template <int NTERMS, int MT, int R>
-__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel(const ConvArgs a) {
+// One workgroup = one TH x TW output tile, all output channels.  K loop over chunks of 2 channel groups x 9 taps:
+//   DMA (global_load_lds) the chunk's input tile and its 9*MT weight fragments into LDS -> barrier -> 9*MT*R*(3|1) MFMAs
+//   per wave straight out of LDS -> barrier.  The LDS stage is single-buffered on purpose: 2-3 workgroups share a CU
+//   (launch bounds + LDS budget), so one workgroup's DMA wait is covered by its neighbours' MFMAs, no staging
+//   registers or ds_writes exist, and every global access of the loop is an asynchronous 1 KiB-per-wave DMA.
+template <int NPL, int MT, int R>
+__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NPL = (NTERMS == 3) ? 2 : 1;   // planes per channel group (hi, lo)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,48 +78,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel(const ConvArgs a) 
     const int x0 = tx * a.TW, y0 = ty * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
-    const int stage_bytes = plane_bytes * 2 * NPL;
+    unsigned char* const s_act = smem;                              // [2 groups][NPL][NPIX_L] pixel vectors
+    unsigned char* const s_w = smem + 2 * NPL * plane_bytes;        // [9 taps][MT][NPL] fragments of 1 KiB
+    constexpr int NWI = 9 * MT * NPL;                               // weight DMA instructions per chunk
 
-    // ---- per-thread staging geometry (chunk independent)
-    int soff[NIT];     // source vector offset inside a plane, or -1 (zero fill)
-    int sdst[NIT];     // LDS byte offset inside a plane, or -1
+    // ---- per-lane source offsets of the activation DMA slots this wave issues (chunk independent).
+    // slot s covers LDS pixels [(wave + s*NW)*64, +64); out-of-image pixels read the plane's (0,0) border vector (zero).
+    int soff[MAXS];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int p = tid + it * NTHREADS;
+    for (int s = 0; s < MAXS; ++s) {
+        const int p = (wave + s * NW) * 64 + lane;
         const int rr = p / P, cc = p - rr * P;
         const int Yp = y0 + rr, Xp = x0 + cc;
         const bool inb = (p < a.NPIX_T) && (Yp < a.H + 2) && (Xp < a.W + 2);
         int sy = Yp, sx = Xp;
         if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
         else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-        soff[it] = inb ? sy * a.Win_p + sx : -1;
-        sdst[it] = (p < a.NPIX_T) ? p * 16 : -1;
+        soff[s] = (p < a.NPIX_L) ? (inb ? sy * a.Win_p + sx : 0) : -1;
     }
-
-    uint4 st[NIT][2 * NPL];
-    auto load_chunk = [&](int cp) {
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            const uint4* ph = in_plane(a, 2 * cp + cg, b, false);
-            const uint4* pl = (NPL == 2) ? in_plane(a, 2 * cp + cg, b, true) : nullptr;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                st[it][cg * NPL] = soff[it] >= 0 ? ph[soff[it]] : z;
-                if (NPL == 2) st[it][cg * NPL + 1] = soff[it] >= 0 ? pl[soff[it]] : z;
-            }
-        }
-    };
-    auto store_chunk = [&](int stage) {
-        unsigned char* base = smem + stage * stage_bytes;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (sdst[it] >= 0) {
-#pragma unroll
-                for (int pl = 0; pl < 2 * NPL; ++pl) *(uint4*)(base + pl * plane_bytes + sdst[it]) = st[it][pl];
-            }
-        }
-    };
 
     f32x16 acc[MT][R];
 #pragma unroll
@@ -120,48 +105,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel(const ConvArgs a) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
 
-    // lane's B-fragment base inside a stage: channel group = lane>>5, pixel column = lane&31
-    const int lane_b = (lane >> 5) * NPL * plane_bytes + (lane & 31) * 16;
+    // lane's B-fragment base: channel group = lane>>5, pixel column = lane&31, N-tile = wave + r*NW
+    const unsigned char* const sb = s_act + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
+    const unsigned char* const sa = s_w + lane * 16;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-
-    const uint4* wp = a.wpack + lane;
     for (int cp = 0; cp < a.ncp; ++cp) {
-        const int stage = cp & 1;
-        const bool more = cp + 1 < a.ncp;
-        if (more) load_chunk(cp + 1);
-        const unsigned char* sb = smem + stage * stage_bytes + lane_b;
+        // ---- stage chunk cp
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const uint4* src = in_plane(a, 2 * cp + cg, b, pl == 1);
+                unsigned char* dst = s_act + (cg * NPL + pl) * plane_bytes + wave * 1024;
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s)
+                    if (soff[s] >= 0) glds16(src + soff[s], dst + s * NW * 1024);
+            }
+        }
+        {
+            const uint4* wsrc = a.wpack + (size_t)cp * NWI * 64 + lane;
+#pragma unroll
+            for (int j0 = 0; j0 < NWI; j0 += NW) {
+                const int j = j0 + wave;
+                if (j < NWI) glds16(wsrc + j * 64, s_w + j * 1024);
+            }
+        }
+        __syncthreads();   // (drains this wave's DMA first: the compiler puts s_waitcnt vmcnt(0) in front of the barrier)
+
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int tapoff = ((t / 3) * P + (t % 3)) * 16;
             uint4 ah[MT], al[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const uint4* w = wp + (size_t)((cp * 9 + t) * MT + m) * NPL * 64;
-                ah[m] = w[0];
-                if (NPL == 2) al[m] = w[64];
+                ah[m] = *(const uint4*)(sa + ((t * MT + m) * NPL) * 1024);
+                if (NPL == 2) al[m] = *(const uint4*)(sa + ((t * MT + m) * NPL + 1) * 1024);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int nt = wave + r * NW;
-                if (nt < a.NT) {
-                    const unsigned char* pb = sb + nt * 512 + tapoff;
-                    const uint4 bh = *(const uint4*)pb;
-                    if (NPL == 2) {
-                        const uint4 bl = *(const uint4*)(pb + plane_bytes);
+                const unsigned char* pb = sb + r * NW * 512 + tapoff;
+                const uint4 bh = *(const uint4*)pb;
+                if (NPL == 2) {
+                    const uint4 bl = *(const uint4*)(pb + plane_bytes);
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[m][r] = mfma(al[m], bh, acc[m][r]);
+                    for (int m = 0; m < MT; ++m) acc[m][r] = mfma(al[m], bh, acc[m][r]);
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bl, acc[m][r]);
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bh, acc[m][r]);
+                    for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bl, acc[m][r]);
                 }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bh, acc[m][r]);
             }
         }
-        if (more) store_chunk(stage ^ 1);
         __syncthreads();
     }
 
@@ -173,7 +167,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel(const ConvArgs a) 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int nt = wave + r * NW;
-        if (nt >= a.NT) continue;
         const int q = nt * 32 + (lane & 31);
         const int rr = q / P, cc = q - rr * P;
         const int Y = y0 + rr, X = x0 + cc;
@@ -285,42 +278,45 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
     if (npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
 }
 
-struct TileCfg { int TH, TW, P, NT, NPIX_T, NPIX_L, tiles_x, tiles_y; };
+struct TileCfg { int R, TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
-// choose the tile that minimises MFMA work: tiles * ceil(TH*P/32) under the LDS / register-staging limits
-TileCfg pick_tile(int H, int W, int R) {
-    const int max_px = 32 * NW * R;
+// Choose (R, TH, TW): minimise MFMA work = workgroups * R (every wave always runs R column tiles) under the LDS budget that
+// keeps `occ` workgroups resident per CU.
+TileCfg pick_tile(int H, int W, int npl, int mt, int occ) {
     TileCfg best{};
-    long long best_cost = -1;
-    for (int ntx = 1; ntx <= W; ++ntx) {
-        const int TW = (W + ntx - 1) / ntx;
-        const int P = TW + 2;
-        if (P > max_px) continue;
-        if (ntx > 1 && TW < 6) break;
-        int THmax = max_px / P;
-        if (THmax > H) THmax = H;
-        for (int TH = THmax; TH >= 1 && TH >= THmax - 8; --TH) {
-            if ((TH + 2) * P > NIT * NTHREADS) continue;
-            if (((TH * P + 31) / 32 * 32 + 2 * P + 2) * 16 * 8 > 78 * 1024) continue;   // keep two workgroups per CU (160 KiB LDS)
-            const int nty = (H + TH - 1) / TH;
-            const int NT = (TH * P + 31) / 32;
-            const long long cost = (long long)ntx * nty * (NT * 100 + 12);   // +12: per-workgroup fixed overhead (in 1/100 N-tiles)
-            if (best_cost < 0 || cost < best_cost) {
-                best_cost = cost;
-                best = TileCfg{TH, TW, P, NT, (TH + 2) * P, 0, ntx, nty};
+    double best_cost = -1;
+    const size_t budget = (size_t)(160 * 1024) / occ;
+    for (int R = 2; R <= 4; ++R) {
+        const int max_px = 32 * NW * R;
+        for (int ntx = 1; ntx <= W; ++ntx) {
+            const int TW = (W + ntx - 1) / ntx;
+            const int P = TW + 2;
+            if (P > max_px) continue;
+            if (ntx > 1 && TW < 6) break;
+            int THmax = max_px / P;
+            if (THmax > H) THmax = H;
+            for (int TH = THmax; TH >= 1 && TH >= THmax - 6; --TH) {
+                const int npix_t = (TH + 2) * P;
+                int npix_l = max_px + 2 * P + 2;
+                if (npix_l < npix_t) npix_l = npix_t;
+                if (npix_l > MAXS * NW * 64) continue;
+                const size_t lds = (size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024;
+                if (lds > budget) continue;
+                const int nty = (H + TH - 1) / TH;
+                const double cost = (double)ntx * nty * (R + 0.35);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    best = TileCfg{R, TH, TW, P, npix_t, npix_l, ntx, nty, lds};
+                }
             }
         }
     }
-    best.NPIX_L = best.NT * 32 + 2 * best.P + 2;
-    if (best.NPIX_L < best.NPIX_T) best.NPIX_L = best.NPIX_T;
     return best;
 }
 
-template <int NTERMS, int MT, int R>
-int launch(const ConvArgs& a, int B, hipStream_t s) {
-    const int npl = NTERMS == 3 ? 2 : 1;
-    const size_t lds = (size_t)2 * 2 * npl * a.NPIX_L * 16;
-    auto k = conv3x3_kernel<NTERMS, MT, R>;
+template <int NPL, int MT, int R>
+int launch(const ConvArgs& a, int B, size_t lds, hipStream_t s) {
+    auto k = conv3x3_kernel<NPL, MT, R>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -330,6 +326,15 @@ int launch(const ConvArgs& a, int B, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y * B), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
+}
+
+template <int NPL, int MT>
+int launch_r(const ConvArgs& a, int B, const TileCfg& t, hipStream_t s) {
+    switch (t.R) {
+        case 2: return launch<NPL, MT, 2>(a, B, t.lds, s);
+        case 3: return launch<NPL, MT, 3>(a, B, t.lds, s);
+        default: return launch<NPL, MT, 4>(a, B, t.lds, s);
+    }
 }
 
 }  // namespace
@@ -374,9 +379,11 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.cout = d->cout;
     a.H = d->H;
     a.W = d->W;
-    const int R = 4;
-    const TileCfg t = pick_tile(d->H, d->W, R);
-    a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NT = t.NT; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
+    const int npl = split ? 2 : 1;
+    TileCfg t = pick_tile(d->H, d->W, npl, mt, mt == 1 ? 3 : 2);
+    if (t.R == 0) t = pick_tile(d->H, d->W, npl, mt, 1);
+    if (t.R == 0) return ESR_E_UNSUPPORTED;
+    a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     a.ncp = (a.in0.ncg + a.in1.ncg + 1) / 2;
     a.act_slope = d->act_slope;
@@ -393,6 +400,6 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
     hipStream_t s = (hipStream_t)stream;
-    if (split) return mt == 1 ? launch<3, 1, 4>(a, d->B, s) : launch<3, 2, 4>(a, d->B, s);
-    return mt == 1 ? launch<1, 1, 4>(a, d->B, s) : launch<1, 2, 4>(a, d->B, s);
+    if (split) return mt == 1 ? launch_r<2, 1>(a, d->B, t, s) : launch_r<2, 2>(a, d->B, t, s);
+    return mt == 1 ? launch_r<1, 1>(a, d->B, t, s) : launch_r<1, 2>(a, d->B, t, s);
 }
