@@ -77,13 +77,20 @@ def cpu_baseline(G, cem):
 
 
 def main():
+    global BATCH, LR_PX_THROUGH_G, ALGO_BYTES_PER_FWD, FLOP_PER_FWD
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='split', choices=['split', 'bf16'])
+    ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
     args = ap.parse_args()
+    if args.batch != BATCH:
+        BATCH = args.batch
+        LR_PX_THROUGH_G = BATCH * (LR_SIZE + 2 * MARGIN_LR) ** 2
+        ALGO_BYTES_PER_FWD = LR_PX_THROUGH_G * ALGO_BYTES_PER_LR_PX
+        FLOP_PER_FWD = LR_PX_THROUGH_G * FLOP_PER_LR_PX
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

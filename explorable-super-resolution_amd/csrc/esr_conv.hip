@@ -9,29 +9,39 @@
 //                  K = 16 = two 8-channel groups at one tap  ->  v_mfma_f32_32x32x16_bf16
 //   activations    [B][CG][H+2][W+2][8] bf16 hi (+lo) planes with a zero border in memory: one B fragment is one
 //                  aligned ds_read_b128 of an LDS pixel vector, a tap shift is +-16 B, padding needs no branches
-//   tile           TH x TW output pixels per 256-thread workgroup, flattened with pitch P = TW+2 so that the
-//                  32-pixel MFMA columns are 32 CONSECUTIVE LDS vectors for every tap (conflict-free b128 reads);
-//                  the 2 pitch-padding columns compute garbage that is masked at the store
-//   K loop         chunk = 2 channel groups x 9 taps; input tile double-buffered in LDS, next chunk prefetched into
-//                  registers during the MFMAs (issue-early / write-late); weight fragments stream from L2 in
-//                  fragment order (one coalesced 1 KiB load per wave per fragment)
+//   tile           TH x TW output pixels per workgroup, flattened with pitch P = TW+2 so that the 32-pixel MFMA
+//                  columns are 32 CONSECUTIVE LDS vectors for every tap (conflict-free b128 reads); the 2
+//                  pitch-padding columns compute garbage that is masked at the store
+//   execution      two interchangeable schedules over the same tile geometry, DMA list, tap schedule and epilogue:
+//                  (T, default) one tile per 4-wave workgroup, K loop over chunks of 2 channel groups x 9 taps: LDS-DMA
+//                  (global_load_lds) of the chunk's input tile AND weight fragments -> barrier -> MFMAs out of LDS ->
+//                  barrier; 2-3 workgroups per CU hide each other's DMA waits and epilogues.
+//                  (P) persistent: one workgroup per CU walks its tiles with the DMA running 1-2 steps ahead of the
+//                  MFMAs (counted s_waitcnt keeps younger DMA / stores in flight); kept for the one-wave-per-SIMD
+//                  experiments documented in DESIGN.md
 //   split-bf16     x = hi + lo (both bf16).  acc += Wlo*Xhi + Whi*Xlo + Whi*Xhi  (3 MFMAs, lo*lo dropped: 2^-16)
-//   epilogue       bias, LeakyReLU, alpha*y + beta1*r1 + beta2*r2, optional act' mask (data-gradient use), re-split to
-//                  hi/lo and 8-byte stores that tile 512 contiguous bytes per wave instruction
+//   epilogue       compile-time specialised (EPI bits): bias, LeakyReLU, alpha*y + beta1*r1 + beta2*r2, act' mask
+//                  (data-gradient use), re-split to hi/lo via v_cvt_pk_bf16_f32, pairs of channel groups exchanged with
+//                  v_permlane32_swap so that every lane stores one full 16-byte pixel vector
 #include "esr_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int NW = 4;          // waves per workgroup
 constexpr int NTHREADS = 256;
-constexpr int MAXS = 3;        // activation DMA slots per wave per plane: NPIX_L <= MAXS*NW*64
+constexpr int MAXS = 3;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+constexpr int R = 3;           // 32-pixel column tiles per wave: a workgroup tile holds up to NW*R*32 = 384 flattened pixels
+
+// epilogue feature bits (template parameter EPI)
+constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
 
 struct ConvArgs {
     DView in0, in1;
     int ups, Win_p;                 // input upsample factor; padded input row pitch (W_in + 2)
     const uint4* wpack;
     const float* bias;
-    int cout, H, W;                 // output interior
+    int cout, B, H, W;              // output channels, batch, output interior
     int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y, ncp;
     float act_slope, alpha, beta1, beta2;
     DView res1, res2, out, out2, mask;
@@ -44,9 +54,31 @@ __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// async global -> LDS copy of 16 bytes per lane; LDS destination = (wave-uniform) dst + lane*16
-__device__ __forceinline__ void glds16(const uint4* src, unsigned char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+// two floats -> packed bf16x2 (round to nearest even); low half = first argument
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// Asynchronous global -> LDS copy, 16 bytes per lane: LDS destination = (wave-uniform) lds_dst + lane*16.
+// Issued through inline asm on purpose: hipcc treats the builtin form as a pending LDS write and drains vmcnt(0) in front of
+// every later ds_read, which would serialise the copy of step s+1 with the MFMAs of step s.  Hidden from the compiler, the
+// copy is ordered by hand: wait_vm_upto() + barrier before the first read of a stage (see the step loop).
+// M0 (the DMA's LDS base) is not preserved by hipcc across statements and no other instruction of this kernel reads it.
+__device__ __forceinline__ void glds16(const uint4* src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
+}
+
+// wait until at most n (rounded down to a multiple of 4) vector-memory operations of this wave are still outstanding
+__device__ __forceinline__ void wait_vm_upto(int n) {
+#define ESR_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k) : "memory"); break;
+    switch (n >> 2) {
+        ESR_W(0) ESR_W(1) ESR_W(2) ESR_W(3) ESR_W(4) ESR_W(5) ESR_W(6) ESR_W(7) ESR_W(8) ESR_W(9) ESR_W(10) ESR_W(11) ESR_W(12)
+        ESR_W(13) ESR_W(14)
+        default: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    }
+#undef ESR_W
 }
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
@@ -58,43 +90,133 @@ __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b
     return (lo ? a.in1.lo : a.in1.hi) + b * a.in1.bs + g1 * a.in1.cs;
 }
 
-// One workgroup = one TH x TW output tile, all output channels.  K loop over chunks of 2 channel groups x 9 taps:
-//   DMA (global_load_lds) the chunk's input tile and its 9*MT weight fragments into LDS -> barrier -> 9*MT*R*(3|1) MFMAs
-//   per wave straight out of LDS -> barrier.  The LDS stage is single-buffered on purpose: 2-3 workgroups share a CU
-//   (launch bounds + LDS budget), so one workgroup's DMA wait is covered by its neighbours' MFMAs, no staging
-//   registers or ds_writes exist, and every global access of the loop is an asynchronous 1 KiB-per-wave DMA.
-template <int NPL, int MT, int R>
-__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_kernel(const ConvArgs a) {
+struct FetchState {
+    int soff0, soff1, soff2;   // MAXS == 3 activation slots: source vector offset inside a plane, or -1 (lane past the tile)
+    int slot1, slot2;          // LDS slot (64 pixel vectors) each of them fills; slot 0 is `wave`
+    int b;                     // image index
+};
+
+__device__ __forceinline__ int slot_offset(const ConvArgs& a, int x0, int y0, int p) {
+    const int rr = p / a.P, cc = p - rr * a.P;
+    const int Yp = y0 + rr, Xp = x0 + cc;
+    const bool inb = (p < a.NPIX_T) && (Yp < a.H + 2) && (Xp < a.W + 2);
+    int sy = Yp, sx = Xp;
+    if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
+    else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
+    // out-of-image pixels read the plane's (0,0) border vector, which is zero
+    return (p < a.NPIX_L) ? (inb ? sy * a.Win_p + sx : 0) : -1;
+}
+
+__device__ __forceinline__ FetchState setup_tile(const ConvArgs& a, int t, int wave, int lane) {
+    const int tx = t % a.tiles_x;
+    const int r1 = t / a.tiles_x;
+    const int ty = r1 % a.tiles_y;
+    FetchState f;
+    f.b = r1 / a.tiles_y;
+    const int x0 = tx * a.TW, y0 = ty * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
+    // every wave issues exactly MAXS activation slots per plane (a constant instruction count keeps the s_waitcnt
+    // bookkeeping static): a slot index past the tile re-fetches this wave's first slot (same data, same destination)
+    const int nslots = (a.NPIX_L + 63) >> 6;
+    f.slot1 = (wave + 1 * NW) < nslots ? wave + 1 * NW : wave;
+    f.slot2 = (wave + 2 * NW) < nslots ? wave + 2 * NW : wave;
+    f.soff0 = slot_offset(a, x0, y0, wave * 64 + lane);
+    f.soff1 = slot_offset(a, x0, y0, f.slot1 * 64 + lane);
+    f.soff2 = slot_offset(a, x0, y0, f.slot2 * 64 + lane);
+    return f;
+}
+
+// source bases of one step: the 2*NPL input planes (group-major, hi|lo) of chunk cp in image b, and the chunk's weight fragments
+template <int NPL>
+struct Bases {
+    const uint4* p[2 * NPL];
+    const uint4* w;
+};
+template <int NPL, int MT>
+__device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b, int lane) {
+    Bases<NPL> r;
+#pragma unroll
+    for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
+    r.w = a.wpack + (size_t)cp * (9 * MT * NPL) * 64 + lane;
+    return r;
+}
+
+// the DMA of one step is a list of independent 1 KiB instructions so that it can be issued in slices between MFMAs:
+// ops [0, 2*NPL*MAXS) = activation slot s, plane (group, hi|lo);  then ceil(9*MT*NPL / NW) weight-fragment ops
+template <int NPL, int MT>
+__device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave) {
+    constexpr int NWI = 9 * MT * NPL, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
+    if (op < NACT) {
+        const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
+        const int so = s == 0 ? f.soff0 : (s == 1 ? f.soff1 : f.soff2);
+        const int slot = s == 0 ? wave : (s == 1 ? f.slot1 : f.slot2);
+        if (so >= 0) glds16(bs.p[cgpl] + so, stage + cgpl * plane_bytes + slot * 1024);
+    } else if (op < NOPS) {
+        int j = (op - NACT) * NW + wave;
+        if (j >= NWI) j = wave;            // constant instruction count per wave: re-fetch the first fragment
+        glds16(bs.w + j * 64, stage + 2 * NPL * plane_bytes + j * 1024);
+    }
+}
+
+// residual operand: this lane's 4 channels (8 bytes) of one pixel of one group plane
+__device__ __forceinline__ void load_res(const DView& v, long long plane_off, int pix2, float (&rv)[4]) {
+    const uint2 h = ((const uint2*)(v.hi + plane_off))[pix2];
+    rv[0] = bf2f(h.x & 0xFFFF); rv[1] = bf2f(h.x >> 16); rv[2] = bf2f(h.y & 0xFFFF); rv[3] = bf2f(h.y >> 16);
+    if (v.lo) {
+        const uint2 l = ((const uint2*)(v.lo + plane_off))[pix2];
+        rv[0] += bf2f(l.x & 0xFFFF); rv[1] += bf2f(l.x >> 16); rv[2] += bf2f(l.y & 0xFFFF); rv[3] += bf2f(l.y >> 16);
+    }
+}
+
+template <int NPL, int MT, int EPI>
+__global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NST = MT == 1 ? 3 : 2;                            // LDS stages: prefetch distance D = NST-1 steps
+    constexpr int D = NST - 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int b = bid / a.tiles_y;
-    const int x0 = tx * a.TW, y0 = ty * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
-    unsigned char* const s_act = smem;                              // [2 groups][NPL][NPIX_L] pixel vectors
-    unsigned char* const s_w = smem + 2 * NPL * plane_bytes;        // [9 taps][MT][NPL] fragments of 1 KiB
-    constexpr int NWI = 9 * MT * NPL;                               // weight DMA instructions per chunk
+    constexpr int NWI = 9 * MT * NPL;                               // weight fragments (1 KiB each) per chunk
+    const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;     // [2 groups][NPL][NPIX_L] pixel vectors | [9][MT][NPL] fragments
+    float* const s_bias = (float*)(smem + NST * stage_bytes);       // [MT*32]
 
-    // ---- per-lane source offsets of the activation DMA slots this wave issues (chunk independent).
-    // slot s covers LDS pixels [(wave + s*NW)*64, +64); out-of-image pixels read the plane's (0,0) border vector (zero).
-    int soff[MAXS];
+    // ---- this workgroup's tiles.  Workgroup g sits on XCD g%8 (dispatch order); each XCD owns a contiguous range of the
+    // tile space and its workgroups sweep it 32 neighbours at a time, so halo rows are shared through that XCD's L2.
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd, wg_per_xcd = gridDim.x / nxcd;
+    const int xcd = blockIdx.x % nxcd, jx = blockIdx.x / nxcd;
+    const int t_begin = xcd * per_xcd + jx;
+    int t_end = (xcd + 1) * per_xcd;
+    if (t_end > ntiles) t_end = ntiles;
+    const int nmy = t_begin < t_end ? (t_end - t_begin + wg_per_xcd - 1) / wg_per_xcd : 0;
+    if (nmy == 0) return;
+    const int nsteps = nmy * a.ncp;
+
+    if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+
+    constexpr int NACT = 2 * NPL * MAXS;
+    constexpr int NWOP = (NWI + NW - 1) / NW;
+    constexpr int NOPS = NACT + NWOP;                               // DMA instructions per wave per step (constant)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- fetch cursor (runs D steps ahead of the MFMAs)
+    int f_tile = t_begin, f_cp = 0, f_step = 0;
+    FetchState fs = setup_tile(a, f_tile, wave, lane);
+    Bases<NPL> bs = make_bases<NPL, MT>(a, 0, fs.b, lane);
+#define ESR_ADVANCE_FETCH()                                                                                                   \
+    do {                                                                                                                      \
+        ++f_step;                                                                                                             \
+        if (++f_cp == a.ncp) { f_cp = 0; f_tile += wg_per_xcd; if (f_tile < t_end) fs = setup_tile(a, f_tile, wave, lane); }  \
+        if (f_step < nsteps) bs = make_bases<NPL, MT>(a, f_cp, fs.b, lane);                                                  \
+    } while (0)
+    for (int d = 0; d < D; ++d) {
+        if (f_step < nsteps) {
+            const unsigned st = lds0 + (f_step % NST) * stage_bytes;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-        const int p = (wave + s * NW) * 64 + lane;
-        const int rr = p / P, cc = p - rr * P;
-        const int Yp = y0 + rr, Xp = x0 + cc;
-        const bool inb = (p < a.NPIX_T) && (Yp < a.H + 2) && (Xp < a.W + 2);
-        int sy = Yp, sx = Xp;
-        if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
-        else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-        soff[s] = (p < a.NPIX_L) ? (inb ? sy * a.Win_p + sx : 0) : -1;
+            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, st, plane_bytes, wave);
+            ESR_ADVANCE_FETCH();
+        }
     }
 
     f32x16 acc[MT][R];
@@ -104,150 +226,388 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_kernel(cons
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
+    // lane's fragment bases inside a stage: B = activations (group lane>>5, pixel column lane&31, N-tile wave + r*NW), A = weights
+    const int sb_off = (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
+    const int sa_off = 2 * NPL * plane_bytes + lane * 16;
 
-    // lane's B-fragment base: channel group = lane>>5, pixel column = lane&31, N-tile = wave + r*NW
-    const unsigned char* const sb = s_act + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
-    const unsigned char* const sa = s_w + lane * 16;
+    constexpr int NTERM = NPL == 2 ? 3 : 1;
+    constexpr int NM = MT * R * NTERM;       // MFMAs per tap
+    constexpr int NL = (MT + R) * NPL;       // fragment reads per tap
+    constexpr int NSLOT = NM > NL ? NM : NL;
+    constexpr int DMA_EVERY = 2;             // one DMA instruction every DMA_EVERY issue slots, from the start of the step
 
-    for (int cp = 0; cp < a.ncp; ++cp) {
-        // ---- stage chunk cp
+    int c_tile = t_begin, c_cp = 0;          // step being computed
+    int pending_stores = 0;                  // epilogue stores issued by this wave in the previous step (younger than all DMA)
+    int cs = 0;                              // its stage index
+    for (int step = 0; step < nsteps; ++step) {
+        unsigned char* const cur = smem + cs * stage_bytes;
+        // VMEM operations retire in issue order: everything older than the DMA groups of later steps (NOPS each) and than the
+        // previous step's epilogue stores must have completed — in particular this step's DMA
+        wait_vm_upto(NOPS * (f_step - (step + 1)) + pending_stores);
+        pending_stores = 0;
+        __syncthreads();     // everyone's share of this step has landed, and every wave has left the stage refilled next
+        const bool last_chunk = c_cp + 1 == a.ncp;
+        const bool fetch = f_step < nsteps;
+        const bool interleave = fetch && !last_chunk;
+        int fst = cs + D; if (fst >= NST) fst -= NST;
+        const unsigned nxt = lds0 + fst * stage_bytes;
+        const unsigned char* const sb = cur + sb_off;
+        const unsigned char* const sa = cur + sa_off;
+        uint4 fa[2][MT][NPL], fb[2][R][NPL];
+        // fragment read k of tap t (in the order the MFMAs consume them: A_lo, B_hi, A_hi, B_lo)
+        auto load_frag = [&](int t, int k, int buf) {
+            const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+            const int grp = k / (MT + R), idx = k % (MT + R);
+            const int pl_a = NPL == 2 ? 1 - grp : 0, pl_b = grp;
+            if (idx < MT) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPL + pl_a) * 1024);
+            else fb[buf][idx - MT][pl_b] = *(const uint4*)(sb + (idx - MT) * NW * 512 + tapoff + pl_b * plane_bytes);
+        };
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                const uint4* src = in_plane(a, 2 * cp + cg, b, pl == 1);
-                unsigned char* dst = s_act + (cg * NPL + pl) * plane_bytes + wave * 1024;
-#pragma unroll
-                for (int s = 0; s < MAXS; ++s)
-                    if (soff[s] >= 0) glds16(src + soff[s], dst + s * NW * 1024);
-            }
-        }
-        {
-            const uint4* wsrc = a.wpack + (size_t)cp * NWI * 64 + lane;
-#pragma unroll
-            for (int j0 = 0; j0 < NWI; j0 += NW) {
-                const int j = j0 + wave;
-                if (j < NWI) glds16(wsrc + j * 64, s_w + j * 1024);
-            }
-        }
-        __syncthreads();   // (drains this wave's DMA first: the compiler puts s_waitcnt vmcnt(0) in front of the barrier)
-
+        for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int tapoff = ((t / 3) * P + (t % 3)) * 16;
-            uint4 ah[MT], al[MT];
+            const int cb = t & 1;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *(const uint4*)(sa + ((t * MT + m) * NPL) * 1024);
-                if (NPL == 2) al[m] = *(const uint4*)(sa + ((t * MT + m) * NPL + 1) * 1024);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const unsigned char* pb = sb + r * NW * 512 + tapoff;
-                const uint4 bh = *(const uint4*)pb;
-                if (NPL == 2) {
-                    const uint4 bl = *(const uint4*)(pb + plane_bytes);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][r] = mfma(al[m], bh, acc[m][r]);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bl, acc[m][r]);
+            for (int i = 0; i < NSLOT; ++i) {
+                if (i < NM) {
+                    // split-bf16: term 0 = W_lo*X_hi, 1 = W_hi*X_lo, 2 = W_hi*X_hi; consecutive MFMAs hit different accumulators
+                    const int term = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
+                    const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
+                    acc[m][r] = mfma(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
                 }
+                if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+                const int gslot = t * NSLOT + i;
+                if (gslot % DMA_EVERY == 0 && gslot / DMA_EVERY < NOPS) {
+                    if (interleave) dma_op<NPL, MT>(fs, bs, gslot / DMA_EVERY, nxt, plane_bytes, wave);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // the issue order above is the schedule
+            }
+        }
+        if (++cs == NST) cs = 0;
+        if (interleave) ESR_ADVANCE_FETCH();
+        if (!last_chunk) { ++c_cp; continue; }
+
+        // ---- a tile's last chunk: burst-issue the DMA of the step D ahead BEFORE the epilogue's stores, so that the next
+        // step's counted s_waitcnt can leave those (younger) stores in flight
+        c_cp = 0;
+        const int tile = c_tile;
+        c_tile += wg_per_xcd;
+        if (fetch) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][r] = mfma(ah[m], bh, acc[m][r]);
+            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, nxt, plane_bytes, wave);
+            ESR_ADVANCE_FETCH();
+        }
+        // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
+        // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
+        // (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes of bf16.  Two groups are
+        // paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector.
+        const int tx = tile % a.tiles_x;
+        const int r1 = tile / a.tiles_x;
+        const int ty = r1 % a.tiles_y;
+        const int b = r1 / a.tiles_y;
+        const int x0 = tx * a.TW, y0 = ty * a.TH;
+        const int half = lane >> 5;
+        const int Wp = a.W + 2;
+        const int ncg_out = (a.cout + 7) >> 3;
+        int n_store = 0;                       // 16-byte store instructions this wave issues below (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = (wave + r * NW) * 32 + (lane & 31);
+            const int rr = q / P, cc = q - rr * P;
+            const int Y = y0 + rr, X = x0 + cc;
+            const bool valid = (rr < a.TH) && (cc < a.TW) && (Y < a.H) && (X < a.W);
+            const int pix = (Y + 1) * Wp + (X + 1);
+            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
+            if (any_valid && valid) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
+                        if (cg0 >= ncg_out) continue;                    // uniform
+                        float v[2][4];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int cg = cg0 + k, ch0 = cg * 8 + half * 4;
+                            const float4 bz = *(const float4*)(s_bias + ch0);
+                            v[k][0] = acc[m][r][(gp * 2 + k) * 4 + 0] + bz.x; v[k][1] = acc[m][r][(gp * 2 + k) * 4 + 1] + bz.y;
+                            v[k][2] = acc[m][r][(gp * 2 + k) * 4 + 2] + bz.z; v[k][3] = acc[m][r][(gp * 2 + k) * 4 + 3] + bz.w;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[k][i] = a.alpha * fmaxf(v[k][i], v[k][i] * a.act_slope);   // 0 < slope <= 1
+                            if ((EPI & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && cg < ncg_out) {
+                                float rv[4];
+                                if (EPI & EPI_RES1) {
+                                    load_res(a.res1, b * a.res1.bs + cg * a.res1.cs, pix * 2 + half, rv);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[i], v[k][i]);
+                                }
+                                if (EPI & EPI_RES2) {
+                                    load_res(a.res2, b * a.res2.bs + cg * a.res2.cs, pix * 2 + half, rv);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[i], v[k][i]);
+                                }
+                                if ((EPI & EPI_MASK) && cg >= a.mask_cg0 && cg < a.mask_cg1) {
+                                    const uint2 h = ((const uint2*)(a.mask.hi + b * a.mask.bs + (cg - a.mask_cg0) * a.mask.cs))[pix * 2 + half];
+                                    // sign of the stored (post-activation) value == sign of the pre-activation (slope > 0)
+                                    const uint32_t sg[4] = {h.x & 0x8000u, h.x & 0x80000000u, h.y & 0x8000u, h.y & 0x80000000u};
+                                    const uint32_t nz[4] = {h.x & 0x7FFFu, h.x & 0x7FFF0000u, h.y & 0x7FFFu, h.y & 0x7FFF0000u};
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;   // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
+                                }
+                                if (EPI & EPI_NCHW) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (ch0 + i < a.cout)
+                                            a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
+                                }
+                            }
+                        }
+                        if (EPI & EPI_NCHW) continue;                    // the fp32 NCHW destination replaces the act-layout one
+                        // split to hi + lo bf16 (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword
+                        uint32_t hi[2][2], lo[2][2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int ch0 = (cg0 + k) * 8 + half * 4;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (ch0 + i >= a.cout) v[k][i] = 0.f;     // channels past cout stay zero in the buffer
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const uint32_t h = cvt_pk_bf16(v[k][2 * j], v[k][2 * j + 1]);
+                                hi[k][j] = h;
+                                lo[k][j] = 0;
+                                if (NPL == 2)
+                                    lo[k][j] = cvt_pk_bf16(v[k][2 * j] - __uint_as_float(h << 16), v[k][2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
+                            }
+                        }
+                        // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
+                        const int cgs = cg0 + half;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
+                        const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        uint4 lv = hv;
+                        if (NPL == 2) {
+                            const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
+                            const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
+                            lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                        }
+                        if (cgs < ncg_out) {
+                            const long long o = b * a.out.bs + cgs * a.out.cs + pix;
+                            ((uint4*)a.out.hi)[o] = hv;
+                            if (NPL == 2) ((uint4*)a.out.lo)[o] = lv;
+                            if (EPI & EPI_OUT2) {
+                                const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
+                                ((uint4*)a.out2.hi)[o2] = hv;
+                                if (NPL == 2) ((uint4*)a.out2.lo)[o2] = lv;
+                            }
+                        }
+                    }
+                }
+            }
+            if (any_valid && !(EPI & EPI_NCHW)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+                        if (m * 4 + gp * 2 < ncg_out) n_store += NPL * ((EPI & EPI_OUT2) ? 2 : 1);
+            }
+        }
+        pending_stores = n_store;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
+    }
+#undef ESR_ADVANCE_FETCH
+}
+
+// Variant B: one output tile per workgroup, single LDS stage, 2-3 workgroups resident per CU (latency hiding comes from the
+// co-resident workgroups instead of an in-workgroup pipeline).  Same tile geometry, DMA list, tap schedule and epilogue.
+template <int NPL, int MT, int EPI>
+__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P;
+    const int plane_bytes = a.NPIX_L * 16;
+    constexpr int NWI = 9 * MT * NPL;
+    const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
+    float* const s_bias = (float*)(smem + stage_bytes);
+    // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
+    const int tile = (blockIdx.x % nxcd) * per_xcd + blockIdx.x / nxcd;
+    if (blockIdx.x / nxcd >= per_xcd || tile >= ntiles) return;
+    if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+    constexpr int NACT = 2 * NPL * MAXS;
+    constexpr int NWOP = (NWI + NW - 1) / NW;
+    constexpr int NOPS = NACT + NWOP;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const FetchState fs = setup_tile(a, tile, wave, lane);
+    f32x16 acc[MT][R];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
+    const unsigned char* const sb = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
+    const unsigned char* const sa = smem + 2 * NPL * plane_bytes + lane * 16;
+    constexpr int NTERM = NPL == 2 ? 3 : 1;
+    constexpr int NM = MT * R * NTERM;
+    constexpr int NL = (MT + R) * NPL;
+    constexpr int NSLOT = NM > NL ? NM : NL;
+    for (int cp = 0; cp < a.ncp; ++cp) {
+        const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
+#pragma unroll
+        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint4 fa[2][MT][NPL], fb[2][R][NPL];
+        auto load_frag = [&](int t, int k, int buf) {
+            const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+            const int grp = k / (MT + R), idx = k % (MT + R);
+            const int pl_a = NPL == 2 ? 1 - grp : 0, pl_b = grp;
+            if (idx < MT) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPL + pl_a) * 1024);
+            else fb[buf][idx - MT][pl_b] = *(const uint4*)(sb + (idx - MT) * NW * 512 + tapoff + pl_b * plane_bytes);
+        };
+#pragma unroll
+        for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int cb = t & 1;
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                if (i < NM) {
+                    const int term = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
+                    const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
+                    acc[m][r] = mfma(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+                }
+                if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
     }
-
-    // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
-    // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
-    // (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes of bf16.
-    const int half = lane >> 5;
-    const long long Wp = a.W + 2;
+    {
+        // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
+        // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
+        // (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes of bf16.  Two groups are
+        // paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector.
+        const int tx = tile % a.tiles_x;
+        const int r1 = tile / a.tiles_x;
+        const int ty = r1 % a.tiles_y;
+        const int b = r1 / a.tiles_y;
+        const int x0 = tx * a.TW, y0 = ty * a.TH;
+        const int half = lane >> 5;
+        const int Wp = a.W + 2;
+        const int ncg_out = (a.cout + 7) >> 3;
+        int n_store = 0;                       // 16-byte store instructions this wave issues below (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int nt = wave + r * NW;
-        const int q = nt * 32 + (lane & 31);
-        const int rr = q / P, cc = q - rr * P;
-        const int Y = y0 + rr, X = x0 + cc;
-        const bool valid = (rr < a.TH) && (cc < a.TW) && (Y < a.H) && (X < a.W);
-        if (!valid) continue;
-        const long long pix = (long long)(Y + 1) * Wp + (X + 1);
+        for (int r = 0; r < R; ++r) {
+            const int q = (wave + r * NW) * 32 + (lane & 31);
+            const int rr = q / P, cc = q - rr * P;
+            const int Y = y0 + rr, X = x0 + cc;
+            const bool valid = (rr < a.TH) && (cc < a.TW) && (Y < a.H) && (X < a.W);
+            const int pix = (Y + 1) * Wp + (X + 1);
+            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
+            if (any_valid && valid) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int cg = m * 4 + g4;             // output channel group
-                const int ch0 = cg * 8 + half * 4;     // first of this lane's 4 channels
-                if (cg * 8 >= a.cout) continue;
-                float v[4];
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
+                        if (cg0 >= ncg_out) continue;                    // uniform
+                        float v[2][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[m][r][g4 * 4 + i];
-                if (a.bias) {
-                    const float4 bz = *(const float4*)(a.bias + ch0);
-                    v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
-                }
+                        for (int k = 0; k < 2; ++k) {
+                            const int cg = cg0 + k, ch0 = cg * 8 + half * 4;
+                            const float4 bz = *(const float4*)(s_bias + ch0);
+                            v[k][0] = acc[m][r][(gp * 2 + k) * 4 + 0] + bz.x; v[k][1] = acc[m][r][(gp * 2 + k) * 4 + 1] + bz.y;
+                            v[k][2] = acc[m][r][(gp * 2 + k) * 4 + 2] + bz.z; v[k][3] = acc[m][r][(gp * 2 + k) * 4 + 3] + bz.w;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = v[i] > 0.f ? v[i] : v[i] * a.act_slope;
-                    v[i] *= a.alpha;
-                }
-                if (a.res1.hi) {
-                    const long long o = b * a.res1.bs + cg * a.res1.cs + pix;
-                    const uint2 h = ((const uint2*)(a.res1.hi + o))[half];
-                    float rv[4] = {bf2f(h.x & 0xFFFF), bf2f(h.x >> 16), bf2f(h.y & 0xFFFF), bf2f(h.y >> 16)};
-                    if (a.res1.lo) {
-                        const uint2 l = ((const uint2*)(a.res1.lo + o))[half];
-                        rv[0] += bf2f(l.x & 0xFFFF); rv[1] += bf2f(l.x >> 16); rv[2] += bf2f(l.y & 0xFFFF); rv[3] += bf2f(l.y >> 16);
+                            for (int i = 0; i < 4; ++i) v[k][i] = a.alpha * fmaxf(v[k][i], v[k][i] * a.act_slope);   // 0 < slope <= 1
+                            if ((EPI & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && cg < ncg_out) {
+                                float rv[4];
+                                if (EPI & EPI_RES1) {
+                                    load_res(a.res1, b * a.res1.bs + cg * a.res1.cs, pix * 2 + half, rv);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[i], v[k][i]);
+                                }
+                                if (EPI & EPI_RES2) {
+                                    load_res(a.res2, b * a.res2.bs + cg * a.res2.cs, pix * 2 + half, rv);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[i], v[k][i]);
+                                }
+                                if ((EPI & EPI_MASK) && cg >= a.mask_cg0 && cg < a.mask_cg1) {
+                                    const uint2 h = ((const uint2*)(a.mask.hi + b * a.mask.bs + (cg - a.mask_cg0) * a.mask.cs))[pix * 2 + half];
+                                    // sign of the stored (post-activation) value == sign of the pre-activation (slope > 0)
+                                    const uint32_t sg[4] = {h.x & 0x8000u, h.x & 0x80000000u, h.y & 0x8000u, h.y & 0x80000000u};
+                                    const uint32_t nz[4] = {h.x & 0x7FFFu, h.x & 0x7FFF0000u, h.y & 0x7FFFu, h.y & 0x7FFF0000u};
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;   // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
+                                }
+                                if (EPI & EPI_NCHW) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (ch0 + i < a.cout)
+                                            a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
+                                }
+                            }
+                        }
+                        if (EPI & EPI_NCHW) continue;                    // the fp32 NCHW destination replaces the act-layout one
+                        // split to hi + lo bf16 (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword
+                        uint32_t hi[2][2], lo[2][2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int ch0 = (cg0 + k) * 8 + half * 4;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (ch0 + i >= a.cout) v[k][i] = 0.f;     // channels past cout stay zero in the buffer
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const uint32_t h = cvt_pk_bf16(v[k][2 * j], v[k][2 * j + 1]);
+                                hi[k][j] = h;
+                                lo[k][j] = 0;
+                                if (NPL == 2)
+                                    lo[k][j] = cvt_pk_bf16(v[k][2 * j] - __uint_as_float(h << 16), v[k][2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
+                            }
+                        }
+                        // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
+                        const int cgs = cg0 + half;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
+                        const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        uint4 lv = hv;
+                        if (NPL == 2) {
+                            const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
+                            const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
+                            lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                        }
+                        if (cgs < ncg_out) {
+                            const long long o = b * a.out.bs + cgs * a.out.cs + pix;
+                            ((uint4*)a.out.hi)[o] = hv;
+                            if (NPL == 2) ((uint4*)a.out.lo)[o] = lv;
+                            if (EPI & EPI_OUT2) {
+                                const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
+                                ((uint4*)a.out2.hi)[o2] = hv;
+                                if (NPL == 2) ((uint4*)a.out2.lo)[o2] = lv;
+                            }
+                        }
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaf(a.beta1, rv[i], v[i]);
                 }
-                if (a.res2.hi) {
-                    const long long o = b * a.res2.bs + cg * a.res2.cs + pix;
-                    const uint2 h = ((const uint2*)(a.res2.hi + o))[half];
-                    float rv[4] = {bf2f(h.x & 0xFFFF), bf2f(h.x >> 16), bf2f(h.y & 0xFFFF), bf2f(h.y >> 16)};
-                    if (a.res2.lo) {
-                        const uint2 l = ((const uint2*)(a.res2.lo + o))[half];
-                        rv[0] += bf2f(l.x & 0xFFFF); rv[1] += bf2f(l.x >> 16); rv[2] += bf2f(l.y & 0xFFFF); rv[3] += bf2f(l.y >> 16);
-                    }
+            }
+            if (any_valid && !(EPI & EPI_NCHW)) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaf(a.beta2, rv[i], v[i]);
-                }
-                if (a.mask.hi && cg >= a.mask_cg0 && cg < a.mask_cg1) {
-                    const long long o = b * a.mask.bs + (cg - a.mask_cg0) * a.mask.cs + pix;
-                    const uint2 h = ((const uint2*)(a.mask.hi + o))[half];
-                    // sign of the stored (post-activation) value == sign of the pre-activation (slope > 0)
-                    const uint32_t s[4] = {h.x & 0x8000u, h.x & 0x80000000u, h.y & 0x8000u, h.y & 0x80000000u};
-                    const uint32_t nz[4] = {h.x & 0x7FFFu, h.x & 0x7FFF0000u, h.y & 0x7FFFu, h.y & 0x7FFF0000u};
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (s[i] || !nz[i]) v[i] *= a.mask_slope;   // x <= 0 -> slope (torch: grad of leaky_relu at 0 is slope)
-                }
-                if (a.out_nchw) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (ch0 + i < a.cout)
-                            a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[i];
-                }
-                if (a.out.hi) {
-                    uint32_t hh[4], ll[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (ch0 + i >= a.cout) v[i] = 0.f;
-                        split_bf16(v[i], hh[i], ll[i]);
-                    }
-                    const uint2 hv = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
-                    const uint2 lv = make_uint2(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16));
-                    const long long o = b * a.out.bs + cg * a.out.cs + pix;
-                    ((uint2*)(a.out.hi + o))[half] = hv;
-                    if (a.out.lo) ((uint2*)(a.out.lo + o))[half] = lv;
-                    if (a.out2.hi) {
-                        const long long o2 = b * a.out2.bs + cg * a.out2.cs + pix;
-                        ((uint2*)(a.out2.hi + o2))[half] = hv;
-                        if (a.out2.lo) ((uint2*)(a.out2.lo + o2))[half] = lv;
-                    }
-                }
+                    for (int gp = 0; gp < 2; ++gp)
+                        if (m * 4 + gp * 2 < ncg_out) n_store += NPL * ((EPI & EPI_OUT2) ? 2 : 1);
             }
         }
     }
@@ -278,62 +638,91 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
     if (npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
 }
 
-struct TileCfg { int R, TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
+struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
-// Choose (R, TH, TW): minimise MFMA work = workgroups * R (every wave always runs R column tiles) under the LDS budget that
-// keeps `occ` workgroups resident per CU.
-TileCfg pick_tile(int H, int W, int npl, int mt, int occ) {
+// Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
+// halo-traffic term, under the LDS budget of one resident workgroup per CU with `nst` stages.
+TileCfg pick_tile(int H, int W, int npl, int mt, int nst) {
     TileCfg best{};
     double best_cost = -1;
-    const size_t budget = (size_t)(160 * 1024) / occ;
-    for (int R = 2; R <= 4; ++R) {
-        const int max_px = 32 * NW * R;
-        for (int ntx = 1; ntx <= W; ++ntx) {
-            const int TW = (W + ntx - 1) / ntx;
-            const int P = TW + 2;
-            if (P > max_px) continue;
-            if (ntx > 1 && TW < 6) break;
-            int THmax = max_px / P;
-            if (THmax > H) THmax = H;
-            for (int TH = THmax; TH >= 1 && TH >= THmax - 6; --TH) {
-                const int npix_t = (TH + 2) * P;
-                int npix_l = max_px + 2 * P + 2;
-                if (npix_l < npix_t) npix_l = npix_t;
-                if (npix_l > MAXS * NW * 64) continue;
-                const size_t lds = (size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024;
-                if (lds > budget) continue;
-                const int nty = (H + TH - 1) / TH;
-                const double cost = (double)ntx * nty * (R + 0.35);
-                if (best_cost < 0 || cost < best_cost) {
-                    best_cost = cost;
-                    best = TileCfg{R, TH, TW, P, npix_t, npix_l, ntx, nty, lds};
-                }
+    const size_t budget = 160 * 1024;
+    const int max_px = 32 * NW * R;
+    for (int ntx = 1; ntx <= W; ++ntx) {
+        const int TW = (W + ntx - 1) / ntx;
+        const int P = TW + 2;
+        if (P > max_px) continue;
+        if (ntx > 1 && TW < 6) break;
+        int THmax = max_px / P;
+        if (THmax > H) THmax = H;
+        for (int TH = THmax; TH >= 1 && TH >= THmax - 6; --TH) {
+            const int npix_t = (TH + 2) * P;
+            int npix_l = max_px + 2 * P + 2;
+            if (npix_l < npix_t) npix_l = npix_t;
+            if (npix_l > MAXS * NW * 64) continue;
+            const size_t lds = nst * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024) + (size_t)mt * 32 * 4;
+            if (lds > budget) continue;
+            const int nty = (H + TH - 1) / TH;
+            const double halo = (double)(TH + 2) * P / ((double)TH * TW);
+            const double cost = (double)ntx * nty * (1.0 + 0.05 * halo);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = TileCfg{TH, TW, P, npix_t, npix_l, ntx, nty, lds};
             }
         }
     }
     return best;
 }
 
-template <int NPL, int MT, int R>
-int launch(const ConvArgs& a, int B, size_t lds, hipStream_t s) {
-    auto k = conv3x3_kernel<NPL, MT, R>;
+int conv_variant() {
+    static int v = -1;
+    // default: tile-per-workgroup (measured faster on MI355X, profiles/r01_*); ESR_CONV_VARIANT=P selects the persistent pipeline
+    if (v < 0) { const char* e = getenv("ESR_CONV_VARIANT"); v = (e && e[0] == 'P') ? 0 : 1; }
+    return v;
+}
+
+template <int NPL, int MT, int EPI>
+int launch_tile(const ConvArgs& a, hipStream_t s) {
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPL * 1024 + (size_t)MT * 32 * 4;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NTHREADS), lds, s, a);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+template <int NPL, int MT, int EPI>
+int launch(const ConvArgs& a, size_t lds, hipStream_t s) {
+    if (conv_variant() == 1) return launch_tile<NPL, MT, EPI>(a, s);
+    void (*k)(const ConvArgs) = conv3x3_kernel<NPL, MT, EPI>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y * B), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(256), dim3(NTHREADS), lds, s, a);   // persistent: one workgroup per CU
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
 
+// the epilogue combinations the RRDB forward / backward plans use
 template <int NPL, int MT>
-int launch_r(const ConvArgs& a, int B, const TileCfg& t, hipStream_t s) {
-    switch (t.R) {
-        case 2: return launch<NPL, MT, 2>(a, B, t.lds, s);
-        case 3: return launch<NPL, MT, 3>(a, B, t.lds, s);
-        default: return launch<NPL, MT, 4>(a, B, t.lds, s);
+int launch_epi(const ConvArgs& a, int epi, size_t lds, hipStream_t s) {
+    switch (epi) {
+        case 0: return launch<NPL, MT, 0>(a, lds, s);
+        case EPI_RES1: return launch<NPL, MT, EPI_RES1>(a, lds, s);
+        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2>(a, lds, s);
+        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW>(a, lds, s);
+        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2>(a, lds, s);
+        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK>(a, lds, s);
+        case EPI_MASK: return launch<NPL, MT, EPI_MASK>(a, lds, s);
+        default: return ESR_E_UNSUPPORTED;
     }
 }
 
@@ -368,6 +757,9 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     const int mt = (d->cout + 31) / 32;
     if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches
     if (d->out.hi && d->out.ncg * 8 < d->cout) return ESR_E_ARG;
+    if (d->out.hi && ((d->out.lo != nullptr) != split)) return ESR_E_ARG;
+    if (d->out2.hi && (!d->out.hi || (d->out2.lo != nullptr) != split)) return ESR_E_ARG;
+    if (d->act_slope <= 0.f || d->act_slope > 1.f) return ESR_E_ARG;
 
     ConvArgs a{};
     a.in0 = to_dview(d->in0);
@@ -377,12 +769,13 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.wpack = (const uint4*)d->wpack;
     a.bias = d->bias;
     a.cout = d->cout;
+    a.B = d->B;
     a.H = d->H;
     a.W = d->W;
     const int npl = split ? 2 : 1;
-    TileCfg t = pick_tile(d->H, d->W, npl, mt, mt == 1 ? 3 : 2);
-    if (t.R == 0) t = pick_tile(d->H, d->W, npl, mt, 1);
-    if (t.R == 0) return ESR_E_UNSUPPORTED;
+    const int nst = mt == 1 ? 3 : 2;   // must match the kernel's NST
+    const TileCfg t = pick_tile(d->H, d->W, npl, mt, nst);
+    if (t.TH == 0) return ESR_E_UNSUPPORTED;
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     a.ncp = (a.in0.ncg + a.in1.ncg + 1) / 2;
@@ -399,7 +792,14 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg0 = d->mask_cg0;
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
+    int epi = 0;
+    if (d->res1.hi) epi |= EPI_RES1;
+    if (d->res2.hi) epi |= EPI_RES2;
+    if (d->mask_src.hi) epi |= EPI_MASK;
+    if (d->out_nchw) epi |= EPI_NCHW;
+    if (d->out2.hi) epi |= EPI_OUT2;
+    if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
-    if (split) return mt == 1 ? launch_r<2, 1>(a, d->B, t, s) : launch_r<2, 2>(a, d->B, t, s);
-    return mt == 1 ? launch_r<1, 1>(a, d->B, t, s) : launch_r<1, 2>(a, d->B, t, s);
+    if (split) return mt == 1 ? launch_epi<2, 1>(a, epi, t.lds, s) : launch_epi<2, 2>(a, epi, t.lds, s);
+    return mt == 1 ? launch_epi<1, 1>(a, epi, t.lds, s) : launch_epi<1, 2>(a, epi, t.lds, s);
 }
