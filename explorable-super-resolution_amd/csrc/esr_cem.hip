@@ -164,3 +164,72 @@ extern "C" int esr_cem_upscale(const float* f, const float* f2, int B, int C, in
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Adjoint (transpose) of the CEM filters.  All three forward ops have the form
+//     y[q] = sum_{a,b} taps[a][b] * x_frame[ clamp(m(q_y) + a - p) ][ clamp(m(q_x) + b - p) ],   m(q) = q*sq + oq
+// on a "frame" of N_y x N_x pixels (replicate padding = index clamping), of which only positions n*sn + on are real unknowns
+// (DownscaleOP: frame = HR, sq = sf, oq = pre;  Conv_LR_with_Inv_hTh_OP: frame = LR, sq = 1;  Upscale_OP: frame = HR, sq = 1,
+// unknowns at sn = sf, on = pre).  The adjoint is the gather
+//     dx[n] = sum_q dy[q] * T[ry][rx][ iy(q_y) ][ ix(q_x) ],      n' = n*sn + on
+// where for an interior frame position the tap index is n' - m(q) + p, and for the first / last frame row (column) every tap
+// that the clamp folded onto it counts: T holds prefix / suffix sums of the taps along that axis (9 tables [3][3][k][k],
+// built on the host: 0 = prefix (first row), 1 = plain (interior), 2 = suffix (last row)).
+__global__ void cem_adjoint_kernel(const float* __restrict__ dy, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* __restrict__ tabs, int k,
+                                   int hn, int wn, int sn, int on, float* __restrict__ dx, int accumulate, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int nx = (int)(idx % wn);
+    long long t = idx / wn;
+    const int ny = (int)(t % hn);
+    const long long bc = t / hn;
+    const int p = k / 2;
+    const int fy = ny * sn + on, fx = nx * sn + on;           // frame position of this unknown
+    const int ry = fy == 0 ? 0 : (fy == Ny - 1 ? 2 : 1), rx = fx == 0 ? 0 : (fx == Nx - 1 ? 2 : 1);
+    const float* T = tabs + (size_t)(ry * 3 + rx) * k * k;
+    const float* src = dy + bc * hq * (long long)wq;
+    // q ranges whose window touches this frame position (interior), or everything that can be clamped onto it (edges)
+    auto range = [&](int f, int r, int N, int nq, int& q0, int& q1) {
+        int lo = f + p - (k - 1) - oq, hi = f + p - oq;     // m(q) in [f+p-(k-1), f+p]
+        if (r == 0) lo = -(1 << 28);                         // first row: also every q with m(q) - p < 0 ... m(q) <= p
+        if (r == 2) hi = (1 << 28);
+        q0 = lo <= 0 ? 0 : (lo + sq - 1) / sq;
+        q1 = hi < 0 ? -1 : hi / sq;
+        if (q1 > nq - 1) q1 = nq - 1;
+        (void)N;
+    };
+    auto tap_index = [&](int f, int r, int N, int q) -> int {
+        const int m = q * sq + oq;
+        if (r == 1) return f - m + p;
+        if (r == 0) { const int a = p - m; return a > k - 1 ? k - 1 : a; }        // prefix table: all taps a' <= p - m
+        const int a = N - 1 - m + p; return a < 0 ? 0 : a;                         // suffix table: all taps a' >= N-1-m+p
+    };
+    int qy0, qy1, qx0, qx1;
+    range(fy, ry, Ny, hq, qy0, qy1);
+    range(fx, rx, Nx, wq, qx0, qx1);
+    float acc = 0.f;
+    for (int qy = qy0; qy <= qy1; ++qy) {
+        const int a = tap_index(fy, ry, Ny, qy);
+        if (a < 0 || a >= k) continue;
+        const float* row = src + (long long)qy * wq;
+        const float* tr = T + a * k;
+        for (int qx = qx0; qx <= qx1; ++qx) {
+            const int b = tap_index(fx, rx, Nx, qx);
+            if (b < 0 || b >= k) continue;
+            acc = fmaf(tr[b], row[qx], acc);
+        }
+    }
+    dx[idx] = accumulate ? dx[idx] + acc : acc;
+}
+
+extern "C" int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
+                               int hn, int wn, int sn, int on, float* dx, int accumulate, esr_stream_t stream) {
+    if (!dy || !tabs || !dx || B <= 0 || C <= 0 || hq <= 0 || wq <= 0 || hn <= 0 || wn <= 0 || sq < 1 || sn < 1 || k < 1 || !(k & 1)) return ESR_E_ARG;
+    if ((hn - 1) * sn + on >= Ny || (wn - 1) * sn + on >= Nx || (hq - 1) * sq + oq >= Ny || (wq - 1) * sq + oq >= Nx) return ESR_E_ARG;
+    const long long total = (long long)B * C * hn * wn;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(cem_adjoint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, hq, wq, sq, oq, Ny, Nx, tabs, k,
+                       hn, wn, sn, on, dx, accumulate, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}

@@ -64,8 +64,9 @@ class PackedConv:
     """MFMA-fragment-ordered copy of one nn.Conv2d(k=3) weight (+ zero-padded bias), re-packed on demand when the
     parameter changes (torch bumps `_version` on every in-place update, e.g. an optimizer step or load_state_dict)."""
 
-    def __init__(self, weight, bias, lat, split=True, transposed=False):
+    def __init__(self, weight, bias, lat, split=True, transposed=False, m_slice=None):
         self.weight, self.bias_p, self.lat, self.split, self.transposed = weight, bias, lat, split, transposed
+        self.m_slice = m_slice        # data-gradient packs: (lo, hi) slice of the main input channels, or 'latent' 
         self._key = None
         self.wpack = None
         self.bias = None
@@ -90,11 +91,13 @@ class PackedConv:
             # [main groups | latent group]
             ncg_k = (cout_w + 7) // 8
             kmap = [c if c < cout_w else -1 for c in range(ncg_k * 8)]
-            mlist = [lat + c for c in range(main)]
-            mlist += [-1] * ((-len(mlist)) % 8)
-            if lat:
-                mlist += [e if e < lat else -1 for e in range(8)]
+            if self.m_slice == 'latent':
+                mlist = list(range(lat))
+            else:
+                lo, hi = self.m_slice if self.m_slice is not None else (0, main)
+                mlist = [lat + c for c in range(lo, hi)]
             mt = (len(mlist) + 31) // 32
+            assert 1 <= mt <= 2, 'a data-gradient pack covers at most 64 output channels'
             mmap = mlist + [-1] * (mt * 32 - len(mlist))
         self.ncg_in = len(kmap) // 8
         self.mtiles = mt
@@ -149,6 +152,21 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
 
 
+def act_combine(out, B, A_=None, alpha=1.0, Bv=None, beta=1.0, s=1, mask=None, mask_slope=0.2):
+    """out = alpha*A_ + beta*sumpool_s(Bv), optionally * LeakyReLU'(mask)  (esr_act_combine)."""
+    ref = lambda v: C.byref(v) if v is not None else None
+    check(_lib.lib.esr_act_combine(ref(A_), alpha, ref(Bv), beta, s, ref(mask), mask_slope, C.byref(out), B, stream_ptr()), 'esr_act_combine')
+
+
+def unpack_grad_nchw(G, dst, C_, h, w, c0, nc, pad=0, down=1, accumulate=False, batch_stride=0):
+    """Adjoint of pack_nchw: act-layout gradient G -> channels [c0, c0+nc) of the fp32 gradient `dst` of an un-padded source
+    laid out [B][C_][h][w] (image b at dst + b*batch_stride floats; 0 = C_*h*w)."""
+    require_gpu(dst, 'gradient')
+    assert dst.dtype == torch.float32 and dst.is_contiguous()
+    check(_lib.lib.esr_unpack_grad_nchw(C.byref(G), dst.data_ptr(), batch_stride, dst.shape[0], C_, h, w, c0, nc, pad, down,
+                                        1 if accumulate else 0, stream_ptr()), 'esr_unpack_grad_nchw')
+
+
 def conv3x3_nchw(x, weight, bias, act_slope=1.0, split=True):
     """Stand-alone conv3x3 on fp32 NCHW tensors (pack -> MFMA conv -> fp32 NCHW).  Used by block-level calls and tests; the
     whole-generator path keeps activations in the kernels' layout instead (engine.py)."""
@@ -173,3 +191,61 @@ def conv3x3_nchw(x, weight, bias, act_slope=1.0, split=True):
         conv3x3(sub, src.view(), B, H, W, mc, act_slope=act_slope, out_nchw=tmp)
         out[:, m0:m0 + mc] = tmp
     return out
+
+
+def conv3x3_dgrad_nchw(dy, weight, split=True):
+    """Data gradient of a stand-alone conv3x3 on fp32 NCHW tensors: dx = conv_T(dy) (weights transposed + flipped)."""
+    require_gpu(dy, 'gradient')
+    dy = dy.detach()
+    dy = (dy if dy.dtype == torch.float32 else dy.float()).contiguous()
+    B, Cout, H, W = dy.shape
+    cin = weight.shape[1]
+    assert weight.shape[0] == Cout
+    src = ActBuf(B, (Cout + 7) // 8, H, W, dy.device, split)
+    pack_nchw(dy, src.view(), 0, Cout)
+    dx = torch.empty(B, cin, H, W, dtype=torch.float32, device=dy.device)
+    for lo in range(0, cin, 64):
+        hi = min(cin, lo + 64)
+        pc = PackedConv(weight, None, 0, split=split, transposed=True, m_slice=(lo, hi)).get()
+        tmp = dx if (lo == 0 and hi == cin) else torch.empty(B, hi - lo, H, W, dtype=torch.float32, device=dy.device)
+        conv3x3(pc, src.view(), B, H, W, hi - lo, out_nchw=tmp, use_bias=False)
+        if tmp is not dx:
+            dx[:, lo:hi] = tmp
+    return dx
+
+
+def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, H, W, alpha, upsample, split, device):
+    """Weight + bias gradient of one conv layer from act-layout operands (esr_conv3x3_wgrad): returns (dW [cout][cin][3][3], db [cout])."""
+    cout, cin = wshape[0], wshape[1]
+    dw = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=device)
+    db = torch.zeros(cout, dtype=torch.float32, device=device)
+    d = _lib.WgradDesc()
+    d.dy = dy
+    d.x = x_main
+    d.xlat = x_lat if x_lat is not None else NO_VIEW
+    d.lat = lat if x_lat is not None else 0
+    d.upsample = upsample
+    d.cout, d.cin_main = cout, cin - (lat if x_lat is not None else 0)
+    d.B, d.H, d.W = dy_batch(dy), H, W
+    d.alpha = alpha
+    d.dw, d.db = dw.data_ptr(), db.data_ptr()
+    check(_lib.lib.esr_conv3x3_wgrad(C.byref(d), stream_ptr()), 'esr_conv3x3_wgrad')
+    return dw, db
+
+
+def dy_batch(view):
+    return int(view._batch) if hasattr(view, '_batch') else view.B_hint
+
+
+def conv3x3_wgrad_nchw(dy, x, wshape, split=True):
+    """Weight / bias gradient of a stand-alone conv3x3 from fp32 NCHW tensors."""
+    require_gpu(dy, 'gradient')
+    dy = (dy.detach().float()).contiguous()
+    x = (x.detach().float()).contiguous()
+    B, Cout, H, W = dy.shape
+    Cin = x.shape[1]
+    gy = ActBuf(B, (Cout + 7) // 8, H, W, dy.device, split)
+    gx = ActBuf(B, (Cin + 7) // 8, H, W, dy.device, split)
+    pack_nchw(dy, gy.view(), 0, Cout)
+    pack_nchw(x, gx.view(), 0, Cin)
+    return conv3x3_wgrad(gy.view(), gx.view(), None, 0, wshape, H, W, 1.0, 1, split, dy.device)

@@ -69,6 +69,26 @@ def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0):
     return (out, out2) if mode == 3 else out
 
 
+def adjoint_raw(dy, tabs, kind, sf, pre, in_shape):
+    """Transpose of one CEM filter: dy (the op's output gradient) -> gradient w.r.t. the op's input of shape `in_shape`."""
+    dy = _prep(dy, 'gradient')
+    B, Cc = in_shape[0], in_shape[1]
+    k = tabs.shape[-1]
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    hq, wq = dy.shape[2], dy.shape[3]
+    hn, wn = in_shape[2], in_shape[3]
+    if kind == 'downscale':      # frame = HR (the input); outputs q at sf*q+pre; unknowns = every HR pixel
+        args = (sf, pre, hn, wn, 1, 0)
+    elif kind == 'lr_filter':    # frame = LR
+        args = (1, 0, hn, wn, 1, 0)
+    else:                        # upscale: frame = HR (the output); unknowns = LR samples at sf*n+pre
+        args = (1, 0, hq, wq, sf, pre)
+    sq, oq, Ny, Nx, sn, on = args
+    check(_lib.lib.esr_cem_adjoint(dy.data_ptr(), B, Cc, hq, wq, sq, oq, Ny, Nx, tabs.data_ptr(), k, hn, wn, sn, on, dx.data_ptr(), 0,
+                                   stream_ptr()), 'esr_cem_adjoint')
+    return dx
+
+
 # ---- public, differentiable entry points -------------------------------------------------------------------------
 def downscale(y, taps, sf, pre):
     if _needs_grad(y):

@@ -1,5 +1,6 @@
 """Launch planner for the whole RRDB generator (reference: RRDBNet.forward, codes/models/modules/architecture.py:278-302
-over block.py's RRDB / ResidualDenseBlock_5C / ShortcutBlock / upconv blocks).
+over block.py's RRDB / ResidualDenseBlock_5C / ShortcutBlock / upconv blocks) and for its backward pass (autograd in the
+reference).
 
 What the reference does with ~10 torch ops per conv layer (cat, conv, leaky_relu_, mul, add, interpolate) is planned here
 as ONE esr_conv3x3 launch per conv layer:
@@ -9,7 +10,9 @@ as ONE esr_conv3x3 launch per conv layer:
     epilogue terms of the producing conv; conv5 writes straight into the next RDB's buffer
   * nearest-neighbour upsampling is folded into the input read of the following conv
   * the CEM eval-mode replicate padding and the latent's bilinear /sf are folded into the input packing kernel
-Buffers are allocated once per (batch, height, width) and reused; for inference three RDB buffers rotate.
+Inference rotates three RDB buffers; a forward that must be differentiated keeps every RDB buffer (they ARE the saved
+activations) and the backward re-uses the same conv kernel with transposed/flipped weight packs (data gradient), a
+pixel-contraction MFMA kernel (weight gradient) and the gradient buffers laid out exactly like the activations.
 """
 import torch
 
@@ -22,14 +25,17 @@ class RRDBEngine:
         self.net = net
         self.split = True
         self._packed = None
+        self._packed_t = None
         self._bufs = {}
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
+        self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
         split = precision == 'split'
         if split != self.split:
             self.split = split
             self._packed = None
+            self._packed_t = None
             self._bufs = {}
 
     # ------------------------------------------------------------------ weights
@@ -46,14 +52,11 @@ class RRDBEngine:
                     out.append(('rrdb%d.rdb%d.conv%d' % (r, k, i), rdb.convs[i][0], lat))
         out.append(('lr_conv', sub[net.nb], lat))
         idx = 2
-        n_up = 1 if net.upscale == 3 else len([1 for mod in m if isinstance(mod, torch.nn.Sequential)])
-        for j in range(n_up):
+        for j in range(self.n_up):
             out.append(('up%d' % j, m[idx][1] if net.upsample_mode == 'upconv' else m[idx][0], 0))
             idx += 1
-        lat_hr = lat
-        out.append(('hr0', m[idx], lat_hr))
-        out.append(('hr1', m[idx + 2], lat_hr))
-        self.n_up = n_up
+        out.append(('hr0', m[idx], lat))
+        out.append(('hr1', m[idx + 2], lat))
         return out
 
     def packed(self):
@@ -63,9 +66,25 @@ class RRDBEngine:
             p.get()
         return self._packed
 
+    def packed_t(self):
+        """Data-gradient packs: weights transposed + flipped, one pack per 64-channel slice of the conv's input channels
+        ('m0', 'm1', 'm2') and one for the latent group ('z')."""
+        if self._packed_t is None:
+            d = {}
+            for name, c, lat in self._convs():
+                main = c.weight.shape[1] - lat
+                for j in range((main + 63) // 64):
+                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
+                if lat:
+                    d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice='latent')
+            self._packed_t = d
+        for p in self._packed_t.values():
+            p.get()
+        return self._packed_t
+
     # ------------------------------------------------------------------ buffers
-    def _buffers(self, B, h, w, dev):
-        key = (B, h, w, str(dev))
+    def _buffers(self, B, h, w, dev, keep):
+        key = (B, h, w, str(dev), keep)
         if key in self._bufs:
             return self._bufs[key]
         if len(self._bufs) > 2:
@@ -80,7 +99,9 @@ class RRDBEngine:
                 d['zhr'] = A.ActBuf(B, 1, sf * h, sf * w, dev, sp)
         d['xin'] = A.ActBuf(B, 1, h, w, dev, sp)
         d['fea'] = A.ActBuf(B, 8, h, w, dev, sp)
-        d['rdb'] = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3)]
+        # inference: three rotating RDB buffers; differentiable forward: one per RDB (saved activations)
+        d['rdb'] = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3 * net.nb if keep else 3)]
+        d['last'] = A.ActBuf(B, 8, h, w, dev, sp)
         d['trunk'] = A.ActBuf(B, 8, h, w, dev, sp)
         ups = []
         s = 1
@@ -98,26 +119,32 @@ class RRDBEngine:
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.net.parameters())):
             from . import autograd as AG
             return AG.rrdb_forward_with_grad(self, x, pad)
-        return self.forward_nograd(x, pad)
+        return self.run_forward(x, pad, keep=False)[0]
 
-    def forward_nograd(self, x, pad=0):
+    def _check(self, x):
         net = self.net
         if net.upsample_mode != 'upconv':
             raise NotImplementedError("upsample_mode='pixelshuffle' is constructible (state_dict parity) but only 'upconv' — the mode the "
                                       "reference hard-wires for RRDB_net (networks.py:99) — is executed by the HIP engine")
-        x = x.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
         sf = net.upscale
         has_lat = net.latent_input is not None and net.num_latent_channels > 0
         lat1 = net.num_latent_channels if has_lat else 0
+        if x.shape[1] != lat1 * sf * sf + 3:
+            raise EsrError('expected %d input channels (latent %d x sf^2 + 3), got %d' % (lat1 * sf * sf + 3, lat1, x.shape[1]))
+        return sf, has_lat, lat1
+
+    def run_forward(self, x, pad=0, keep=False):
+        """Returns (g, bufs).  keep=True keeps one buffer per RDB so that `bufs` holds every activation the backward needs."""
+        net = self.net
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        sf, has_lat, lat1 = self._check(x)
         B, Ct, h0, w0 = x.shape
-        if Ct != lat1 * sf * sf + 3:
-            raise EsrError('expected %d input channels (latent %d x sf^2 + 3), got %d' % (lat1 * sf * sf + 3, lat1, Ct))
         pk = self.packed()
         h, w = h0 + 2 * pad, w0 + 2 * pad
         H, W = sf * h, sf * w
-        bufs = self._buffers(B, h, w, x.device)
+        bufs = self._buffers(B, h, w, x.device, keep)
         conv = A.conv3x3
 
         # ---- input packing (+ replicate pad, + latent bilinear /sf)
@@ -135,15 +162,20 @@ class RRDBEngine:
 
         if self._ev:
             self._ev[0].record()
-        # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
         rdb = bufs['rdb']
-        conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=rdb[0].view(0, 8) if net.nb else None)
-        cur = 0
+        nrdb = 3 * net.nb
+
+        def buf_of(j):       # buffer that holds RDB j's dense block (j = 3*r + k); j == nrdb: the trunk's last feature map
+            if j == nrdb:
+                return bufs['last']
+            return rdb[j] if keep else rdb[j % 3]
+
+        # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
+        conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, 8) if net.nb else None)
         for r in range(net.nb):
-            rrdb_in = rdb[cur]
+            rrdb_in = buf_of(3 * r)
             for k in range(3):
-                buf = rdb[(cur + k) % 3]
-                nxt = rdb[(cur + k + 1) % 3]
+                buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
                 for i in range(4):
                     conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
                          out=buf.view(8 + 4 * i, 4))
@@ -151,10 +183,10 @@ class RRDBEngine:
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8))
                 else:         # RRDB output: 0.2*(0.2*conv5 + x) + x_rrdb   (block.py:270); lands in the next RRDB's first buffer
+                    # (inference: that is rrdb_in's own buffer when the three buffers rotate; the kernel's in-place residual is safe)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.04, res1=buf.view(0, 8), beta1=0.2,
                          res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8))
-            cur = (cur + 3) % 3
-        last = rdb[cur].view(0, 8) if net.nb else bufs['fea'].view()
+        last = buf_of(nrdb).view(0, 8) if net.nb else bufs['fea'].view()
         # LR_conv + trunk shortcut (block.py:96)
         conv(pk['lr_conv'], last, B, h, w, 64, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view())
         # upsamplers: nearest xs folded into the conv's input read
@@ -169,4 +201,170 @@ class RRDBEngine:
         conv(pk['hr1'], bufs['hr0'].view(), B, H, W, net.out_nc, in0=zhr, out_nchw=g)
         if self._ev:
             self._ev[1].record()
-        return g
+        return g, bufs
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False, debug=None):
+        """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
+        net, sp = self.net, self.split
+        sf = net.upscale
+        has_lat = net.latent_input is not None and net.num_latent_channels > 0
+        lat1 = net.num_latent_channels if has_lat else 0
+        lat = net._lat_all_layers
+        B, Ct, h0, w0 = x_shape
+        h, w = h0 + 2 * pad, w0 + 2 * pad
+        H, W = sf * h, sf * w
+        dev = dg.device
+        pt = self.packed_t()
+        conv = A.conv3x3
+        dg = dg.detach()
+        dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
+        wg = WGrad(self, need_dw)
+
+        def zview(bufname):
+            return bufs[bufname].view() if bufname in bufs else None
+
+        def dgrad(name, dy, out, cg_lo, cg_hi, Hh, Ww, alpha=1.0, accumulate=False, extra=None, extra_beta=1.0, mask=None, upsample=1):
+            """out[cg_lo:cg_hi] (+)= alpha * conv_T(dy) [+ extra_beta*extra], then * act'(mask[cg_lo:cg_hi]) where mask is given as
+            (buffer, first masked group, end masked group) in `out` group numbering."""
+            for j in range(cg_lo // 8, (cg_hi + 7) // 8):
+                lo, hi = max(cg_lo, 8 * j), min(cg_hi, 8 * j + 8)
+                if lo >= hi:
+                    continue
+                kw = {}
+                ov = out.view(lo, hi - lo)
+                if accumulate:
+                    kw.update(res1=ov, beta1=1.0)
+                    if extra is not None and lo < 8:
+                        kw.update(res2=extra, beta2=extra_beta)
+                elif extra is not None and lo < 8:
+                    kw.update(res1=extra, beta1=extra_beta)
+                if mask is not None:
+                    mb, m0, m1 = mask
+                    a0, a1 = max(m0, lo), min(m1, hi)
+                    if a0 < a1:
+                        kw.update(mask_src=mb.view(a0, a1 - a0), mask_cg=(a0 - lo, a1 - lo), mask_slope=0.2)
+                conv(pt[name, 'm%d' % j], dy, B, Hh, Ww, (hi - lo) * 8, alpha=alpha, out=ov, use_bias=False, **kw)
+
+        def dgrad_z(name, dy, gz, Hh, Ww, alpha, first):
+            kw = {} if first else dict(res1=gz.view(), beta1=1.0)
+            conv(pt[name, 'z'], dy, B, Hh, Ww, lat1, alpha=alpha, out=gz.view(), use_bias=False, **kw)
+
+        # ---- HR part
+        G_g = A.ActBuf(B, 1, H, W, dev, sp)
+        A.pack_nchw(dg, G_g.view(), 0, net.out_nc)
+        G_hr0 = A.ActBuf(B, 8, H, W, dev, sp)
+        GZ_hr = A.ActBuf(B, 1, H, W, dev, sp) if (has_lat and lat) else None
+        GZ_lr = A.ActBuf(B, 1, h, w, dev, sp) if has_lat else None
+        wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W)
+        dgrad('hr1', G_g.view(), G_hr0, 0, 8, H, W, mask=(bufs['hr0'], 0, 8))
+        if GZ_hr is not None:
+            dgrad_z('hr1', G_g.view(), GZ_hr, H, W, 1.0, first=True)
+        G_up = A.ActBuf(B, 8, H, W, dev, sp)
+        src_act = bufs['ups'][-1] if self.n_up else bufs['trunk']
+        wg.conv('hr0', G_hr0.view(), src_act.view(), zview('zhr') if lat else None, H, W)
+        dgrad('hr0', G_hr0.view(), G_up, 0, 8, H, W, mask=(src_act, 0, 8) if self.n_up else None)
+        if GZ_hr is not None:
+            dgrad_z('hr0', G_hr0.view(), GZ_hr, H, W, 1.0, first=False)
+        if debug is not None:
+            debug['hr0'] = G_hr0.to_nchw(64)
+            debug['up_last'] = G_up.to_nchw(64)
+        del G_hr0, G_g
+        # ---- upsamplers (reverse): conv data-gradient at the upsampled size, then sum-pool = adjoint of nearest upsample
+        cur_g, s = G_up, sf if sf != 3 else 3
+        for j in reversed(range(self.n_up)):
+            f = 3 if sf == 3 else 2
+            Hj, Wj = s * h, s * w
+            below = bufs['ups'][j - 1] if j > 0 else bufs['trunk']
+            wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f)
+            tmp = A.ActBuf(B, 8, Hj, Wj, dev, sp)
+            dgrad('up%d' % j, cur_g.view(), tmp, 0, 8, Hj, Wj)
+            s //= f
+            nxt_g = A.ActBuf(B, 8, s * h, s * w, dev, sp)
+            A.act_combine(nxt_g.view(), B, Bv=tmp.view(), beta=1.0, s=f, mask=below.view() if j > 0 else None)
+            cur_g = nxt_g
+            del tmp
+        G_trunk = cur_g
+        if debug is not None:
+            debug['trunk'] = G_trunk.to_nchw(64)
+        # ---- trunk: trunk = fea + LR_conv(last)
+        nrdb = 3 * net.nb
+        G_last = A.ActBuf(B, 8, h, w, dev, sp)
+        last_act = bufs['last'] if net.nb else bufs['fea']
+        wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w)
+        dgrad('lr_conv', G_trunk.view(), G_last, 0, 8, h, w)
+        zfirst = True
+        if lat:
+            dgrad_z('lr_conv', G_trunk.view(), GZ_lr, h, w, 1.0, first=True)
+            zfirst = False
+        dout = G_last                         # gradient w.r.t. the output of RRDB r (8 groups)
+        GX = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3)] if net.nb else []
+        for r in reversed(range(net.nb)):
+            dout_rrdb = dout
+            for k in reversed(range(3)):
+                X = bufs['rdb'][3 * r + k]
+                G = GX[k]
+                name = 'rrdb%d.rdb%d' % (r, k)
+                scale = 0.2 if k == 2 else 1.0          # d(RDB_k out): RDB3's output enters the RRDB sum scaled by 0.2
+                dy_out = dout_rrdb.view(0, 8) if k == 2 else GX[k + 1].view(0, 8)
+                # conv4: y = 0.2*conv(X[0:24]) + x  ->  G[0:24] = 0.2*scale*conv_T(dy_out);  G[0:8] += scale*dy_out;  G[20:24] *= act'
+                wg.conv(name + '.conv4', dy_out, X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * scale)
+                dgrad(name + '.conv4', dy_out, G, 0, 24, h, w, alpha=0.2 * scale, extra=dy_out, extra_beta=scale, mask=(X, 20, 24))
+                if lat:
+                    dgrad_z(name + '.conv4', dy_out, GZ_lr, h, w, 0.2 * scale, first=zfirst)
+                    zfirst = False
+                for i in (3, 2, 1, 0):
+                    dy = G.view(8 + 4 * i, 4)            # complete and already multiplied by act'
+                    wg.conv('%s.conv%d' % (name, i), dy, X.view(0, 8 + 4 * i), zview('zlr') if lat else None, h, w)
+                    last_rdb_conv = (k == 0 and i == 0)
+                    dgrad('%s.conv%d' % (name, i), dy, G, 0, 8 + 4 * i, h, w, accumulate=True,
+                          extra=dout_rrdb.view(0, 8) if last_rdb_conv else None,      # RRDB skip: d x_rrdb += d out_rrdb
+                          mask=(X, 4 + 4 * i, 8 + 4 * i) if i > 0 else None)
+                    if lat:
+                        dgrad_z('%s.conv%d' % (name, i), dy, GZ_lr, h, w, 1.0, first=False)
+            # GX[0][0:8] now holds d(input of RRDB r) = d(output of RRDB r-1); copy it out of the rotating set
+            nd = A.ActBuf(B, 8, h, w, dev, sp)
+            A.act_combine(nd.view(), B, A_=GX[0].view(0, 8), alpha=1.0)
+            dout = nd
+        # d fea = d trunk (shortcut) + d(first RRDB input)
+        G_fea = A.ActBuf(B, 8, h, w, dev, sp)
+        A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)
+        if debug is not None:
+            debug['fea'] = G_fea.to_nchw(64)
+        wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w)
+        dx = None
+        if need_dx:
+            dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dev)
+            G_x = A.ActBuf(B, 1, h, w, dev, sp)
+            conv(pt['fea', 'm0'], G_fea.view(), B, h, w, 3, out=G_x.view(), use_bias=False)
+            A.unpack_grad_nchw(G_x.view(), dx, Ct, h0, w0, c0=Ct - 3, nc=3, pad=pad)
+            if has_lat:
+                dgrad_z('fea', G_fea.view(), GZ_lr, h, w, 1.0, first=zfirst)
+                # the latent's gradient goes back through the raw [lat][sf*h0][sf*w0] view of the first lat*sf^2 channels
+                kw = dict(batch_stride=Ct * h0 * w0)
+                A.unpack_grad_nchw(GZ_lr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, down=sf, **kw)
+                if GZ_hr is not None:
+                    A.unpack_grad_nchw(GZ_hr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, accumulate=True, **kw)
+        return dx, wg.result()
+
+
+class WGrad:
+    """Weight / bias gradient collection (filled by the weight-gradient kernel)."""
+
+    def __init__(self, engine, enabled):
+        self.engine, self.enabled = engine, enabled
+        self.grads = {} if enabled else None
+        self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
+        self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
+
+    def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1):
+        if not self.enabled:
+            return
+        c = self.mods[name]
+        dw, db = A.conv3x3_wgrad(dy, x_main, x_lat, self.lats[name], c.weight.shape, H, W, alpha, upsample, self.engine.split, c.weight.device)
+        self.grads[c.weight] = dw
+        if c.bias is not None:
+            self.grads[c.bias] = db
+
+    def result(self):
+        return self.grads

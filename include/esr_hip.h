@@ -138,6 +138,20 @@ int esr_cem_upscale(const float* f, const float* f2, int B, int C, int h, int w,
                     const float* taps, int k, const float* g, int crop, int mode, float range,
                     float* out, float* out2, esr_stream_t stream);
 
+/* ---- backward-pass helpers (autograd of the reference's torch ops) ----
+ * out = alpha*A + beta*sumpool_s(Bv), optionally * LeakyReLU'(mask) — gradient of the nearest upsample
+ * (block.py:293-300), of residual sums, and of LeakyReLU (block.py:18).  A / Bv / mask may be NULL. */
+int esr_act_combine(const esr_act_view* A, float alpha, const esr_act_view* Bv, float beta, int s, const esr_act_view* mask,
+                    float mask_slope, const esr_act_view* out, int B, esr_stream_t stream);
+/* Adjoint of esr_pack_nchw (replicate padding folded back onto the edge pixels, bilinear /down taps transposed):
+ * act-layout gradient -> fp32 NCHW gradient of channels [c0, c0+nc) of the un-padded source. */
+int esr_unpack_grad_nchw(const esr_act_view* G, float* dst, int64_t dst_batch_stride, int B, int C, int h, int w, int c0, int nc,
+                         int pad, int down, int accumulate, esr_stream_t stream);
+/* Adjoint of a CEM filter (see csrc/esr_cem.hip): y[q] = sum taps * frame[clamp(q*sq+oq + a - p)], unknowns at n*sn+on.
+ * tabs: device fp32 [3][3][k][k] prefix/plain/suffix tap tables (esr_hip/cem_ops.py builds them). */
+int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
+                    int hn, int wn, int sn, int on, float* dx, int accumulate, esr_stream_t stream);
+
 int esr_version(void);
 
 #ifdef __cplusplus
