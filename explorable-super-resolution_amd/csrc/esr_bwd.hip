@@ -178,3 +178,220 @@ extern "C" int esr_unpack_grad_nchw(const esr_act_view* G, float* dst, int64_t d
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight (and bias) gradient of conv3x3:   dW[co][ci][dy][dx] = alpha * sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy-1,x+dx-1]
+// (autograd of nn.Conv2d in the reference, codes/models/modules/block.py:141-142).
+//
+// The contraction runs over PIXELS, while both operands store 8 CHANNELS contiguously per pixel.  v_mfma_f32_32x32x2_f32 takes
+// one fp32 scalar per lane for A (row = lane&31, k = lane>>5) and for B (col = lane&31, k = lane>>5), so with k = two adjacent
+// pixels every lane reads exactly "its channel of its pixel" — no transposition anywhere — and hi+lo recombine to the exact value
+// (fp32 MFMA == an fmaf chain, so this kernel has fp32 accuracy).
+//   workgroup  = (32 input channels = 4 groups, one kernel row dy) x a slice of the image tiles; 4 waves
+//   per tile   : LDS-DMA of dY[TH x TW] (all output groups) and X[TH x (TW+2)] (row offset dy), barrier, then per pixel pair
+//                MT x 3 MFMAs (3 = dx taps) per wave; waves split the tile's rows
+//   end        : the 4 waves' accumulators are summed through LDS and added to dW with fp32 atomics (split-K over slices)
+namespace {
+
+constexpr int WG_TH = 8, WG_TW = 32;       // tile: 256 pixels
+
+struct WgradArgs {
+    DView dy, x, xlat;
+    int lat, ups, cout, cin_main, cin_total, B, H, W;
+    int Wx_p;                  // padded row pitch of the x source (W/ups + 2)
+    int tiles_x, tiles_y, nslices, ncit_main;
+    float alpha;
+    float* dw;
+    float* db;
+};
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ void glds16w(const uint4* src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float ld_split(const unsigned char* hi, int lo_off) {
+    const uint32_t h = *(const uint16_t*)hi;
+    float v = __uint_as_float(h << 16);
+    if (lo_off) {
+        const uint32_t l = *(const uint16_t*)(hi + lo_off);
+        v += __uint_as_float(l << 16);
+    }
+    return v;
+}
+
+template <int MT, int NPL>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.x / a.nslices, slice = blockIdx.x % a.nslices;
+    const int cit = group / 3, dyk = group % 3;                  // input-channel tile, kernel row
+    const bool lat_tile = cit >= a.ncit_main;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    constexpr int XP = WG_TH * (WG_TW + 2);                      // x pixels per plane in LDS
+    constexpr int YP = WG_TH * WG_TW;                            // dy pixels per plane
+    constexpr int X_BYTES = 4 * NPL * XP * 16;                   // [4 groups][NPL][XP]
+    constexpr int XSLOTS = (XP + 63) / 64, YSLOTS = YP / 64;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+
+    f32x16_t acc[MT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][d][i] = 0.f;
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+    const bool do_bias = (group == 0) && a.db;
+
+    const int chan = lane & 31, kk = lane >> 5;                   // this lane's channel inside the 32-tile, pixel of the pair
+    const int cgl = chan >> 3, ce = (chan & 7) * 2;               // group inside the tile, byte offset of the channel in a vector
+
+    for (int tile = slice; tile < ntiles; tile += a.nslices) {
+        const int tx = tile % a.tiles_x;
+        const int r1 = tile / a.tiles_x;
+        const int ty = r1 % a.tiles_y;
+        const int b = r1 / a.tiles_y;
+        const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+        // ---- stage X: rows y0+dyk .. (padded coords), cols x0 .. x0+TW+1 ; 4 groups x NPL planes
+        for (int s = wave; s < 4 * NPL * XSLOTS; s += 4) {
+            const int pl = s / XSLOTS, sl = s % XSLOTS;           // plane = group*NPL + (hi|lo)
+            const int g = pl / NPL, islo = pl % NPL;
+            const int p = sl * 64 + lane;
+            if (p < XP) {
+                const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
+                const int Yp = y0 + rr + dyk, Xp = x0 + cc;       // padded output-resolution coords of the tap source
+                const bool inb = (Yp < a.H + 2) && (Xp < a.W + 2);
+                int sy = Yp, sx = Xp;
+                if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
+                else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
+                const DView& v = lat_tile ? a.xlat : a.x;
+                const int cg = lat_tile ? g : cit * 4 + g;
+                const bool have = cg < v.ncg;
+                const uint4* base = (islo ? v.lo : v.hi) + b * v.bs + (have ? cg : 0) * v.cs;
+                glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), lds0 + pl * XP * 16 + sl * 1024);
+            }
+        }
+        // ---- stage dY: rows y0.., cols x0.. ; MT*4 groups x NPL planes
+        for (int s = wave; s < MT * 4 * NPL * YSLOTS; s += 4) {
+            const int pl = s / YSLOTS, sl = s % YSLOTS;
+            const int g = pl / NPL, islo = pl % NPL;
+            const int p = sl * 64 + lane;
+            const int rr = p / WG_TW, cc = p - rr * WG_TW;
+            const int Y = y0 + rr, X = x0 + cc;
+            const bool inb = (Y < a.H) && (X < a.W) && (g < a.dy.ncg);
+            const uint4* base = (islo ? a.dy.lo : a.dy.hi) + b * a.dy.bs + (g < a.dy.ncg ? g : 0) * a.dy.cs;
+            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), lds0 + X_BYTES + pl * YP * 16 + sl * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- MFMAs: wave handles rows wave, wave+4
+        const unsigned char* xs = smem + (cgl * NPL) * XP * 16 + ce;
+        const unsigned char* ys = smem + X_BYTES + ce;
+        constexpr int XLO = NPL == 2 ? XP * 16 : 0, YLO = NPL == 2 ? YP * 16 : 0;
+        for (int rr = wave; rr < WG_TH; rr += 4) {
+#pragma unroll 4
+            for (int pp = 0; pp < WG_TW / 2; ++pp) {
+                const int xx = 2 * pp + kk;
+                float av[MT], bv[3];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    av[m] = ld_split(ys + ((m * 4 + cgl) * NPL) * YP * 16 + (rr * WG_TW + xx) * 16, YLO);
+                    bsum[m] += av[m];
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) bv[d] = ld_split(xs + (rr * (WG_TW + 2) + xx + d) * 16, XLO);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[m][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[d], acc[m][d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- reduce the 4 waves through LDS, then one atomic per output element
+    float* red = (float*)smem;                                   // [wave][MT*3*16][64]
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[((wave * MT * 3 + m * 3 + d) * 16 + i) * 64 + lane] = acc[m][d][i];
+    float* bred = red + 4 * MT * 3 * 16 * 64;                    // [wave][MT][64]
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bred[(wave * MT + m) * 64 + lane] = bsum[m];
+    __syncthreads();
+    for (int e = tid; e < MT * 3 * 16 * 64; e += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * MT * 3 * 16 * 64 + e];
+        const int ln = e & 63, i = (e >> 6) & 15, md = e >> 10;
+        const int m = md / 3, d = md % 3;
+        const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);       // D row
+        const int c = ln & 31;                                                  // D col = channel inside the tile
+        int ci = -1;
+        if (lat_tile) { if (c < a.lat) ci = c; }
+        else if (cit * 32 + c < a.cin_main) ci = a.lat + cit * 32 + c;
+        if (co < a.cout && ci >= 0) atomicAdd(a.dw + ((long long)co * a.cin_total + ci) * 9 + dyk * 3 + d, a.alpha * v);
+    }
+    if (do_bias) {
+        for (int e = tid; e < MT * 32; e += 256) {
+            const int m = e >> 5, c = e & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += bred[(w4 * MT + m) * 64 + c] + bred[(w4 * MT + m) * 64 + c + 32];
+            if (m * 32 + c < a.cout) atomicAdd(a.db + m * 32 + c, a.alpha * v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
+    if (!d || !d->dy.hi || !d->x.hi || !d->dw || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
+    const int ups = d->upsample <= 0 ? 1 : d->upsample;
+    if (d->x.H * ups != d->H || d->x.W * ups != d->W || d->dy.H != d->H || d->dy.W != d->W) return ESR_E_ARG;
+    if (d->xlat.hi && (ups != 1 || d->xlat.H != d->H || d->xlat.W != d->W || d->lat <= 0 || d->lat > 8)) return ESR_E_ARG;
+    const int mt = (d->cout + 31) / 32;
+    if (mt > 2) return ESR_E_UNSUPPORTED;
+    const bool split = d->dy.lo != nullptr;
+    if ((d->x.lo != nullptr) != split) return ESR_E_ARG;
+    WgradArgs a{};
+    a.dy = to_dview(d->dy);
+    a.x = to_dview(d->x);
+    a.xlat = to_dview(d->xlat);
+    a.lat = d->xlat.hi ? d->lat : 0;
+    a.ups = ups;
+    a.cout = d->cout;
+    a.cin_main = d->cin_main;
+    a.cin_total = d->cin_main + a.lat;
+    a.B = d->B; a.H = d->H; a.W = d->W;
+    a.Wx_p = d->x.W + 2;
+    a.tiles_x = (d->W + WG_TW - 1) / WG_TW;
+    a.tiles_y = (d->H + WG_TH - 1) / WG_TH;
+    a.ncit_main = (d->cin_main + 31) / 32;
+    const int ngroups = (a.ncit_main + (a.lat ? 1 : 0)) * 3;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    int ns = (768 + ngroups - 1) / ngroups;          // ~3 workgroups per CU in total
+    if (ns > ntiles) ns = ntiles;
+    if (ns < 1) ns = 1;
+    a.nslices = ns;
+    a.alpha = d->alpha;
+    a.dw = d->dw;
+    a.db = d->db;
+    const int npl = split ? 2 : 1;
+    const size_t stage = (size_t)4 * npl * WG_TH * (WG_TW + 2) * 16 + (size_t)mt * 4 * npl * WG_TH * WG_TW * 16;
+    const size_t red = (size_t)4 * mt * 3 * 16 * 64 * 4 + (size_t)4 * mt * 64 * 4;
+    const size_t lds = stage > red ? stage : red;
+    void (*k)(const WgradArgs) = split ? (mt == 1 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<2, 2>)
+                                       : (mt == 1 ? conv3x3_wgrad_kernel<1, 1> : conv3x3_wgrad_kernel<2, 1>);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(k, dim3(ngroups * ns), dim3(256), lds, (hipStream_t)stream, a);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}

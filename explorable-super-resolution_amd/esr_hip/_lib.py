@@ -26,6 +26,13 @@ class Conv3x3Desc(C.Structure):
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float)]
 
 
+class WgradDesc(C.Structure):
+    """esr_wgrad_desc (include/esr_hip.h)."""
+    _fields_ = [('dy', ActView), ('x', ActView), ('xlat', ActView), ('lat', C.c_int32), ('upsample', C.c_int32), ('cout', C.c_int32),
+                ('cin_main', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('alpha', C.c_float), ('dw', C.c_void_p),
+                ('db', C.c_void_p)]
+
+
 _SIGS = {
     'esr_version': (C.c_int, []),
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
@@ -42,6 +49,7 @@ _SIGS = {
                                        C.c_int, C.c_int, C.c_void_p]),
     'esr_cem_adjoint': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'esr_conv3x3_wgrad': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

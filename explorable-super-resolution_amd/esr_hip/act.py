@@ -214,27 +214,22 @@ def conv3x3_dgrad_nchw(dy, weight, split=True):
     return dx
 
 
-def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, H, W, alpha, upsample, split, device):
+def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
     """Weight + bias gradient of one conv layer from act-layout operands (esr_conv3x3_wgrad): returns (dW [cout][cin][3][3], db [cout])."""
     cout, cin = wshape[0], wshape[1]
     dw = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=device)
     db = torch.zeros(cout, dtype=torch.float32, device=device)
+    nlat = lat if x_lat is not None else 0
     d = _lib.WgradDesc()
-    d.dy = dy
-    d.x = x_main
+    d.dy, d.x = dy, x_main
     d.xlat = x_lat if x_lat is not None else NO_VIEW
-    d.lat = lat if x_lat is not None else 0
-    d.upsample = upsample
-    d.cout, d.cin_main = cout, cin - (lat if x_lat is not None else 0)
-    d.B, d.H, d.W = dy_batch(dy), H, W
+    d.lat, d.upsample = nlat, upsample
+    d.cout, d.cin_main = cout, cin - nlat
+    d.B, d.H, d.W = B, H, W
     d.alpha = alpha
     d.dw, d.db = dw.data_ptr(), db.data_ptr()
     check(_lib.lib.esr_conv3x3_wgrad(C.byref(d), stream_ptr()), 'esr_conv3x3_wgrad')
     return dw, db
-
-
-def dy_batch(view):
-    return int(view._batch) if hasattr(view, '_batch') else view.B_hint
 
 
 def conv3x3_wgrad_nchw(dy, x, wshape, split=True):
@@ -248,4 +243,4 @@ def conv3x3_wgrad_nchw(dy, x, wshape, split=True):
     gx = ActBuf(B, (Cin + 7) // 8, H, W, dy.device, split)
     pack_nchw(dy, gy.view(), 0, Cout)
     pack_nchw(x, gx.view(), 0, Cin)
-    return conv3x3_wgrad(gy.view(), gx.view(), None, 0, wshape, H, W, 1.0, 1, split, dy.device)
+    return conv3x3_wgrad(gy.view(), gx.view(), None, 0, wshape, B, H, W, 1.0, 1, dy.device)

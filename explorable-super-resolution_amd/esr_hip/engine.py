@@ -219,7 +219,7 @@ class RRDBEngine:
         conv = A.conv3x3
         dg = dg.detach()
         dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
-        wg = WGrad(self, need_dw)
+        wg = WGrad(self, need_dw, B)
 
         def zview(bufname):
             return bufs[bufname].view() if bufname in bufs else None
@@ -351,8 +351,8 @@ class RRDBEngine:
 class WGrad:
     """Weight / bias gradient collection (filled by the weight-gradient kernel)."""
 
-    def __init__(self, engine, enabled):
-        self.engine, self.enabled = engine, enabled
+    def __init__(self, engine, enabled, B):
+        self.engine, self.enabled, self.B = engine, enabled, B
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
@@ -361,7 +361,7 @@ class WGrad:
         if not self.enabled:
             return
         c = self.mods[name]
-        dw, db = A.conv3x3_wgrad(dy, x_main, x_lat, self.lats[name], c.weight.shape, H, W, alpha, upsample, self.engine.split, c.weight.device)
+        dw, db = A.conv3x3_wgrad(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device)
         self.grads[c.weight] = dw
         if c.bias is not None:
             self.grads[c.bias] = db

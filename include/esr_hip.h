@@ -152,6 +152,24 @@ int esr_unpack_grad_nchw(const esr_act_view* G, float* dst, int64_t dst_batch_st
 int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
                     int hn, int wn, int sn, int on, float* dx, int accumulate, esr_stream_t stream);
 
+/* ---- conv3x3 weight / bias gradient (autograd of nn.Conv2d, block.py:141-142) ----
+ *   dw[co][lat+ci][dy][dx] += alpha * sum_{b,y,x} dy[b,co,y,x] * x[b,ci,(y+dy-1)/up,(x+dx-1)/up]     (zero padded)
+ *   dw[co][e][dy][dx]      += ... with xlat for the latent channels e < lat;   db[co] += alpha * sum dy
+ * dw ([cout][lat+cin_main][3][3]) and db ([cout], may be NULL) are fp32 and ACCUMULATED into (zero them first). */
+typedef struct {
+    esr_act_view dy;         /* gradient w.r.t. the conv's (pre-activation) output, cout channels */
+    esr_act_view x;          /* the conv's main input (before the nearest upsample when upsample > 1) */
+    esr_act_view xlat;       /* optional latent segment (hi == NULL: absent) */
+    int32_t lat;             /* real latent channels (<= 8) */
+    int32_t upsample;
+    int32_t cout, cin_main;
+    int32_t B, H, W;         /* output-resolution size */
+    float alpha;
+    float* dw;
+    float* db;
+} esr_wgrad_desc;
+int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream);
+
 int esr_version(void);
 
 #ifdef __cplusplus

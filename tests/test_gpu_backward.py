@@ -144,3 +144,44 @@ def test_cem_wrapped_generator_z_gradient_eval_mode():
     (yg * cot.to(DEV)).sum().backward()
     assert rel_l2(yg.detach().cpu().numpy(), yc.detach().numpy()) < 1e-4
     assert_grad_close(zg.grad.cpu().numpy(), zc.grad.numpy(), 'dZ')
+
+
+@pytest.mark.parametrize('cin,cout,H,W', [(64, 32, 17, 23), (96, 32, 9, 40), (192, 64, 33, 21), (3, 64, 12, 16), (64, 3, 40, 37), (67, 64, 10, 12)])
+def test_conv3x3_weight_gradient_matches_torch_cpu(cin, cout, H, W):
+    """Stand-alone wgrad kernel (fp32 MFMA over pixel pairs) vs torch's conv2d weight/bias gradient in float64."""
+    from esr_hip import act as A
+    x = seeded_uniform((2, cin, H, W), cin + cout, -1.0, 1.0)
+    dy = seeded_uniform((2, cout, H, W), cin * 3 + cout, -1.0, 1.0)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w, b, padding=1) * dy.double()).sum().backward()
+    dw, db = A.conv3x3_wgrad_nchw(dy.to(DEV), x.to(DEV), (cout, cin, 3, 3))
+    assert rel_l2(dw.cpu().numpy(), w.grad.numpy()) < 2e-5      # operands are hi+lo (2^-17), accumulation fp32
+    assert rel_l2(db.cpu().numpy(), b.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('name,nb,sf,lat', [c for c in F4_CASES if c[0] in ('nb1_x4', 'nb1_x2', 'nb1_x4_lat3', 'nb2_x4_lat3')],
+                         ids=['nb1_x4', 'nb1_x2', 'nb1_x4_lat3', 'nb2_x4_lat3'])
+def test_rrdb_parameter_gradients_match_reference_golden(name, nb, sf, lat):
+    """dL/dW, dL/db of every conv (training path) against the digests (sum, norm, 24 samples) captured from the reference."""
+    g = load('rrdb_fwd_bwd.npz')
+    net = _rrdb(nb, sf, lat).to(DEV)
+    x = _f4_input(nb, sf, lat).to(DEV)
+    y = net(x)
+    cot = seeded_uniform(tuple(y.shape), 41 + nb + sf + lat, -1.0, 1.0).to(DEV)
+    (y * cot).sum().backward()
+    dig = g[name + '/dparams']
+    bad = []
+    for j, (k, p) in enumerate(net.named_parameters()):
+        assert p.grad is not None, k
+        f = p.grad.detach().cpu().reshape(-1).double()
+        norm_ref = dig[j][1]
+        idx = torch.linspace(0, f.numel() - 1, steps=24).long()
+        # same reasoning as assert_grad_close: a flipped LeakyReLU branch perturbs gradients by O(1e-3); norms must agree to 2 %
+        # and the sampled entries to 20 % of the tensor's rms scale (a flip is local: a few entries move, the bulk does not)
+        if abs(float(f.norm()) - norm_ref) > 2e-2 * max(norm_ref, 1e-6):
+            bad.append((k, 'norm', float(f.norm()), norm_ref))
+        scale = max(norm_ref / np.sqrt(f.numel()), 1e-6)
+        if np.abs(f[idx].numpy() - dig[j][2:]).max() > 0.2 * scale + 1e-6:
+            bad.append((k, 'samples', float(np.abs(f[idx].numpy() - dig[j][2:]).max() / scale)))
+    assert not bad, bad[:5]
