@@ -35,6 +35,9 @@ constexpr int R = 3;           // 32-pixel column tiles per wave: a workgroup ti
 
 // epilogue feature bits (template parameter EPI)
 constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
+// residual 1 is a channel-group slice of the conv's own input (RDB conv5: out = 0.2*conv + x, block.py:235): it is added to the
+// accumulators from the LDS copy the K loop stages anyway, so the epilogue has no residual loads at all
+constexpr int EPI_RESIN = 32;
 
 struct ConvArgs {
     DView in0, in1;
@@ -48,6 +51,11 @@ struct ConvArgs {
     float* out_nchw;
     int mask_cg0, mask_cg1;
     float mask_slope;
+    int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
+    float resin_scale;              // beta1 / alpha
+#ifdef ESR_TRACE
+    unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
+#endif
 };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
@@ -68,17 +76,6 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // M0 (the DMA's LDS base) is not preserved by hipcc across statements and no other instruction of this kernel reads it.
 __device__ __forceinline__ void glds16(const uint4* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
-}
-
-// wait until at most n (rounded down to a multiple of 4) vector-memory operations of this wave are still outstanding
-__device__ __forceinline__ void wait_vm_upto(int n) {
-#define ESR_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k) : "memory"); break;
-    switch (n >> 2) {
-        ESR_W(0) ESR_W(1) ESR_W(2) ESR_W(3) ESR_W(4) ESR_W(5) ESR_W(6) ESR_W(7) ESR_W(8) ESR_W(9) ESR_W(10) ESR_W(11) ESR_W(12)
-        ESR_W(13) ESR_W(14)
-        default: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
-    }
-#undef ESR_W
 }
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
@@ -157,275 +154,47 @@ __device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs
     }
 }
 
-// residual operand: this lane's 4 channels (8 bytes) of one pixel of one group plane
-__device__ __forceinline__ void load_res(const DView& v, long long plane_off, int pix2, float (&rv)[4]) {
-    const uint2 h = ((const uint2*)(v.hi + plane_off))[pix2];
-    rv[0] = bf2f(h.x & 0xFFFF); rv[1] = bf2f(h.x >> 16); rv[2] = bf2f(h.y & 0xFFFF); rv[3] = bf2f(h.y >> 16);
-    if (v.lo) {
-        const uint2 l = ((const uint2*)(v.lo + plane_off))[pix2];
-        rv[0] += bf2f(l.x & 0xFFFF); rv[1] += bf2f(l.x >> 16); rv[2] += bf2f(l.y & 0xFFFF); rv[3] += bf2f(l.y >> 16);
+// Residual / mask operand of one PAIR of channel groups (cg0, cg0+1) at this lane's pixel, read the way the output is stored:
+// lanes 0-31 load the full 16-byte pixel vector of group cg0, lanes 32-63 that of group cg0+1 (one coalesced b128 load per
+// plane); res_unpack() then exchanges halves (v_permlane32_swap) into the accumulator arrangement: this lane's 4 channels
+// (4*half .. 4*half+3) of both groups.
+struct ResRaw { uint4 h, l; };
+__device__ __forceinline__ ResRaw res_issue(const DView& v, int b, int cgs, int pix, bool want_lo) {
+    ResRaw r;
+    r.h = make_uint4(0, 0, 0, 0);
+    r.l = make_uint4(0, 0, 0, 0);
+    if (cgs >= 0 && cgs < v.ncg) {
+        const long long o = b * v.bs + cgs * v.cs + pix;
+        r.h = v.hi[o];
+        if (want_lo && v.lo) r.l = v.lo[o];
+    }
+    return r;
+}
+__device__ __forceinline__ void swap_halves(const uint4& x, uint32_t (&d)[2][2]) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(x.x, x.z, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(x.y, x.w, false, false);
+    d[0][0] = s0[0]; d[0][1] = s1[0]; d[1][0] = s0[1]; d[1][1] = s1[1];
+}
+__device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (&rv)[2][4]) {
+    uint32_t d[2][2];
+    swap_halves(q.h, d);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        rv[k][0] = bf2f(d[k][0] & 0xFFFF); rv[k][1] = __uint_as_float(d[k][0] & 0xFFFF0000u);
+        rv[k][2] = bf2f(d[k][1] & 0xFFFF); rv[k][3] = __uint_as_float(d[k][1] & 0xFFFF0000u);
+    }
+    if (has_lo) {
+        swap_halves(q.l, d);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            rv[k][0] += bf2f(d[k][0] & 0xFFFF); rv[k][1] += __uint_as_float(d[k][0] & 0xFFFF0000u);
+            rv[k][2] += bf2f(d[k][1] & 0xFFFF); rv[k][3] += __uint_as_float(d[k][1] & 0xFFFF0000u);
+        }
     }
 }
 
-template <int NPL, int MT, int EPI>
-__global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NST = MT == 1 ? 3 : 2;                            // LDS stages: prefetch distance D = NST-1 steps
-    constexpr int D = NST - 1;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.P;
-    const int plane_bytes = a.NPIX_L * 16;
-    constexpr int NWI = 9 * MT * NPL;                               // weight fragments (1 KiB each) per chunk
-    const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;     // [2 groups][NPL][NPIX_L] pixel vectors | [9][MT][NPL] fragments
-    float* const s_bias = (float*)(smem + NST * stage_bytes);       // [MT*32]
-
-    // ---- this workgroup's tiles.  Workgroup g sits on XCD g%8 (dispatch order); each XCD owns a contiguous range of the
-    // tile space and its workgroups sweep it 32 neighbours at a time, so halo rows are shared through that XCD's L2.
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd, wg_per_xcd = gridDim.x / nxcd;
-    const int xcd = blockIdx.x % nxcd, jx = blockIdx.x / nxcd;
-    const int t_begin = xcd * per_xcd + jx;
-    int t_end = (xcd + 1) * per_xcd;
-    if (t_end > ntiles) t_end = ntiles;
-    const int nmy = t_begin < t_end ? (t_end - t_begin + wg_per_xcd - 1) / wg_per_xcd : 0;
-    if (nmy == 0) return;
-    const int nsteps = nmy * a.ncp;
-
-    if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
-
-    constexpr int NACT = 2 * NPL * MAXS;
-    constexpr int NWOP = (NWI + NW - 1) / NW;
-    constexpr int NOPS = NACT + NWOP;                               // DMA instructions per wave per step (constant)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-    // ---- fetch cursor (runs D steps ahead of the MFMAs)
-    int f_tile = t_begin, f_cp = 0, f_step = 0;
-    FetchState fs = setup_tile(a, f_tile, wave, lane);
-    Bases<NPL> bs = make_bases<NPL, MT>(a, 0, fs.b, lane);
-#define ESR_ADVANCE_FETCH()                                                                                                   \
-    do {                                                                                                                      \
-        ++f_step;                                                                                                             \
-        if (++f_cp == a.ncp) { f_cp = 0; f_tile += wg_per_xcd; if (f_tile < t_end) fs = setup_tile(a, f_tile, wave, lane); }  \
-        if (f_step < nsteps) bs = make_bases<NPL, MT>(a, f_cp, fs.b, lane);                                                  \
-    } while (0)
-    for (int d = 0; d < D; ++d) {
-        if (f_step < nsteps) {
-            const unsigned st = lds0 + (f_step % NST) * stage_bytes;
-#pragma unroll
-            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, st, plane_bytes, wave);
-            ESR_ADVANCE_FETCH();
-        }
-    }
-
-    f32x16 acc[MT][R];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
-    // lane's fragment bases inside a stage: B = activations (group lane>>5, pixel column lane&31, N-tile wave + r*NW), A = weights
-    const int sb_off = (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
-    const int sa_off = 2 * NPL * plane_bytes + lane * 16;
-
-    constexpr int NTERM = NPL == 2 ? 3 : 1;
-    constexpr int NM = MT * R * NTERM;       // MFMAs per tap
-    constexpr int NL = (MT + R) * NPL;       // fragment reads per tap
-    constexpr int NSLOT = NM > NL ? NM : NL;
-    constexpr int DMA_EVERY = 2;             // one DMA instruction every DMA_EVERY issue slots, from the start of the step
-
-    int c_tile = t_begin, c_cp = 0;          // step being computed
-    int pending_stores = 0;                  // epilogue stores issued by this wave in the previous step (younger than all DMA)
-    int cs = 0;                              // its stage index
-    for (int step = 0; step < nsteps; ++step) {
-        unsigned char* const cur = smem + cs * stage_bytes;
-        // VMEM operations retire in issue order: everything older than the DMA groups of later steps (NOPS each) and than the
-        // previous step's epilogue stores must have completed — in particular this step's DMA
-        wait_vm_upto(NOPS * (f_step - (step + 1)) + pending_stores);
-        pending_stores = 0;
-        __syncthreads();     // everyone's share of this step has landed, and every wave has left the stage refilled next
-        const bool last_chunk = c_cp + 1 == a.ncp;
-        const bool fetch = f_step < nsteps;
-        const bool interleave = fetch && !last_chunk;
-        int fst = cs + D; if (fst >= NST) fst -= NST;
-        const unsigned nxt = lds0 + fst * stage_bytes;
-        const unsigned char* const sb = cur + sb_off;
-        const unsigned char* const sa = cur + sa_off;
-        uint4 fa[2][MT][NPL], fb[2][R][NPL];
-        // fragment read k of tap t (in the order the MFMAs consume them: A_lo, B_hi, A_hi, B_lo)
-        auto load_frag = [&](int t, int k, int buf) {
-            const int tapoff = ((t / 3) * P + (t % 3)) * 16;
-            const int grp = k / (MT + R), idx = k % (MT + R);
-            const int pl_a = NPL == 2 ? 1 - grp : 0, pl_b = grp;
-            if (idx < MT) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPL + pl_a) * 1024);
-            else fb[buf][idx - MT][pl_b] = *(const uint4*)(sb + (idx - MT) * NW * 512 + tapoff + pl_b * plane_bytes);
-        };
-#pragma unroll
-        for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int cb = t & 1;
-#pragma unroll
-            for (int i = 0; i < NSLOT; ++i) {
-                if (i < NM) {
-                    // split-bf16: term 0 = W_lo*X_hi, 1 = W_hi*X_lo, 2 = W_hi*X_hi; consecutive MFMAs hit different accumulators
-                    const int term = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
-                    const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
-                    acc[m][r] = mfma(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
-                }
-                if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
-                const int gslot = t * NSLOT + i;
-                if (gslot % DMA_EVERY == 0 && gslot / DMA_EVERY < NOPS) {
-                    if (interleave) dma_op<NPL, MT>(fs, bs, gslot / DMA_EVERY, nxt, plane_bytes, wave);
-                }
-                __builtin_amdgcn_sched_barrier(0);     // the issue order above is the schedule
-            }
-        }
-        if (++cs == NST) cs = 0;
-        if (interleave) ESR_ADVANCE_FETCH();
-        if (!last_chunk) { ++c_cp; continue; }
-
-        // ---- a tile's last chunk: burst-issue the DMA of the step D ahead BEFORE the epilogue's stores, so that the next
-        // step's counted s_waitcnt can leave those (younger) stores in flight
-        c_cp = 0;
-        const int tile = c_tile;
-        c_tile += wg_per_xcd;
-        if (fetch) {
-#pragma unroll
-            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, nxt, plane_bytes, wave);
-            ESR_ADVANCE_FETCH();
-        }
-        // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
-        // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
-        // (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes of bf16.  Two groups are
-        // paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector.
-        const int tx = tile % a.tiles_x;
-        const int r1 = tile / a.tiles_x;
-        const int ty = r1 % a.tiles_y;
-        const int b = r1 / a.tiles_y;
-        const int x0 = tx * a.TW, y0 = ty * a.TH;
-        const int half = lane >> 5;
-        const int Wp = a.W + 2;
-        const int ncg_out = (a.cout + 7) >> 3;
-        int n_store = 0;                       // 16-byte store instructions this wave issues below (wave-uniform)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int q = (wave + r * NW) * 32 + (lane & 31);
-            const int rr = q / P, cc = q - rr * P;
-            const int Y = y0 + rr, X = x0 + cc;
-            const bool valid = (rr < a.TH) && (cc < a.TW) && (Y < a.H) && (X < a.W);
-            const int pix = (Y + 1) * Wp + (X + 1);
-            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
-            if (any_valid && valid) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
-                        if (cg0 >= ncg_out) continue;                    // uniform
-                        float v[2][4];
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int cg = cg0 + k, ch0 = cg * 8 + half * 4;
-                            const float4 bz = *(const float4*)(s_bias + ch0);
-                            v[k][0] = acc[m][r][(gp * 2 + k) * 4 + 0] + bz.x; v[k][1] = acc[m][r][(gp * 2 + k) * 4 + 1] + bz.y;
-                            v[k][2] = acc[m][r][(gp * 2 + k) * 4 + 2] + bz.z; v[k][3] = acc[m][r][(gp * 2 + k) * 4 + 3] + bz.w;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[k][i] = a.alpha * fmaxf(v[k][i], v[k][i] * a.act_slope);   // 0 < slope <= 1
-                            if ((EPI & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && cg < ncg_out) {
-                                float rv[4];
-                                if (EPI & EPI_RES1) {
-                                    load_res(a.res1, b * a.res1.bs + cg * a.res1.cs, pix * 2 + half, rv);
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[i], v[k][i]);
-                                }
-                                if (EPI & EPI_RES2) {
-                                    load_res(a.res2, b * a.res2.bs + cg * a.res2.cs, pix * 2 + half, rv);
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[i], v[k][i]);
-                                }
-                                if ((EPI & EPI_MASK) && cg >= a.mask_cg0 && cg < a.mask_cg1) {
-                                    const uint2 h = ((const uint2*)(a.mask.hi + b * a.mask.bs + (cg - a.mask_cg0) * a.mask.cs))[pix * 2 + half];
-                                    // sign of the stored (post-activation) value == sign of the pre-activation (slope > 0)
-                                    const uint32_t sg[4] = {h.x & 0x8000u, h.x & 0x80000000u, h.y & 0x8000u, h.y & 0x80000000u};
-                                    const uint32_t nz[4] = {h.x & 0x7FFFu, h.x & 0x7FFF0000u, h.y & 0x7FFFu, h.y & 0x7FFF0000u};
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;   // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
-                                }
-                                if (EPI & EPI_NCHW) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (ch0 + i < a.cout)
-                                            a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
-                                }
-                            }
-                        }
-                        if (EPI & EPI_NCHW) continue;                    // the fp32 NCHW destination replaces the act-layout one
-                        // split to hi + lo bf16 (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword
-                        uint32_t hi[2][2], lo[2][2];
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int ch0 = (cg0 + k) * 8 + half * 4;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (ch0 + i >= a.cout) v[k][i] = 0.f;     // channels past cout stay zero in the buffer
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const uint32_t h = cvt_pk_bf16(v[k][2 * j], v[k][2 * j + 1]);
-                                hi[k][j] = h;
-                                lo[k][j] = 0;
-                                if (NPL == 2)
-                                    lo[k][j] = cvt_pk_bf16(v[k][2 * j] - __uint_as_float(h << 16), v[k][2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
-                            }
-                        }
-                        // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
-                        const int cgs = cg0 + half;
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
-                        const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        uint4 lv = hv;
-                        if (NPL == 2) {
-                            const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
-                            const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
-                            lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
-                        }
-                        if (cgs < ncg_out) {
-                            const long long o = b * a.out.bs + cgs * a.out.cs + pix;
-                            ((uint4*)a.out.hi)[o] = hv;
-                            if (NPL == 2) ((uint4*)a.out.lo)[o] = lv;
-                            if (EPI & EPI_OUT2) {
-                                const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
-                                ((uint4*)a.out2.hi)[o2] = hv;
-                                if (NPL == 2) ((uint4*)a.out2.lo)[o2] = lv;
-                            }
-                        }
-                    }
-                }
-            }
-            if (any_valid && !(EPI & EPI_NCHW)) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp)
-                        if (m * 4 + gp * 2 < ncg_out) n_store += NPL * ((EPI & EPI_OUT2) ? 2 : 1);
-            }
-        }
-        pending_stores = n_store;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
-    }
-#undef ESR_ADVANCE_FETCH
-}
-
-// Variant B: one output tile per workgroup, single LDS stage, 2-3 workgroups resident per CU (latency hiding comes from the
-// co-resident workgroups instead of an in-workgroup pipeline).  Same tile geometry, DMA list, tap schedule and epilogue.
+// One output tile per workgroup, single LDS stage, 2-3 workgroups resident per CU: latency hiding comes from the co-resident
+// workgroups instead of an in-workgroup pipeline (the persistent multi-stage variant measured slower).
 template <int NPL, int MT, int EPI>
 __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -447,6 +216,14 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
     constexpr int NWOP = (NWI + NW - 1) / NW;
     constexpr int NOPS = NACT + NWOP;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#ifdef ESR_TRACE
+    unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
+    int tslot = 2;
+    if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); tr[126] = wall_clock64(); }
+#define ESR_TR() do { if (tr && tid == 0 && tslot < 126) tr[tslot++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESR_TR() do { } while (0)
+#endif
     const FetchState fs = setup_tile(a, tile, wave, lane);
     f32x16 acc[MT][R];
 #pragma unroll
@@ -463,10 +240,14 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
     constexpr int NSLOT = NM > NL ? NM : NL;
     for (int cp = 0; cp < a.ncp; ++cp) {
         const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
+        ESR_TR();
 #pragma unroll
         for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+        ESR_TR();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ESR_TR();
         __syncthreads();
+        ESR_TR();
         uint4 fa[2][MT][NPL], fb[2][R][NPL];
         auto load_frag = [&](int t, int k, int buf) {
             const int tapoff = ((t / 3) * P + (t % 3)) * 16;
@@ -491,8 +272,37 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr ((EPI & EPI_RESIN) != 0) {
+            // groups 2cp, 2cp+1 of the input are in LDS right now: if they belong to the residual slice, add this lane's 4
+            // channels of the centre-tap pixel (exactly hi + lo, in fp32) to the matching accumulator rows
+#pragma unroll
+            for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                const int og = 2 * cp + sgrp - a.resin_g0;              // output group fed by this input group (uniform)
+                if (og < 0 || og * 8 >= a.cout) continue;
+#pragma unroll
+                for (int mg = 0; mg < MT * 4; ++mg) {
+                    if (og != mg) continue;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const unsigned char* const pr = smem + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
+                        const uint2 h = *(const uint2*)pr;
+                        float x0 = bf2f(h.x & 0xFFFF), x1 = __uint_as_float(h.x & 0xFFFF0000u), x2 = bf2f(h.y & 0xFFFF), x3 = __uint_as_float(h.y & 0xFFFF0000u);
+                        if (NPL == 2) {
+                            const uint2 l = *(const uint2*)(pr + plane_bytes);
+                            x0 += bf2f(l.x & 0xFFFF); x1 += __uint_as_float(l.x & 0xFFFF0000u); x2 += bf2f(l.y & 0xFFFF); x3 += __uint_as_float(l.y & 0xFFFF0000u);
+                        }
+                        acc[mg / 4][r][(mg % 4) * 4 + 0] = fmaf(a.resin_scale, x0, acc[mg / 4][r][(mg % 4) * 4 + 0]);
+                        acc[mg / 4][r][(mg % 4) * 4 + 1] = fmaf(a.resin_scale, x1, acc[mg / 4][r][(mg % 4) * 4 + 1]);
+                        acc[mg / 4][r][(mg % 4) * 4 + 2] = fmaf(a.resin_scale, x2, acc[mg / 4][r][(mg % 4) * 4 + 2]);
+                        acc[mg / 4][r][(mg % 4) * 4 + 3] = fmaf(a.resin_scale, x3, acc[mg / 4][r][(mg % 4) * 4 + 3]);
+                    }
+                }
+            }
+        }
+        ESR_TR();
         __syncthreads();
     }
+    ESR_TR();
     {
         // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
         // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
@@ -506,7 +316,6 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
         const int half = lane >> 5;
         const int Wp = a.W + 2;
         const int ncg_out = (a.cout + 7) >> 3;
-        int n_store = 0;                       // 16-byte store instructions this wave issues below (wave-uniform)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int q = (wave + r * NW) * 32 + (lane & 31);
@@ -516,6 +325,16 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
             const int pix = (Y + 1) * Wp + (X + 1);
             const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
             if (any_valid && valid) {
+                // all residual / mask loads of this column tile first (independent 16-byte loads in flight together), then the math
+                constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
+                ResRaw q1[HAS_R1 ? MT * 2 : 1], q2[HAS_R2 ? MT * 2 : 1], qm[HAS_MK ? MT * 2 : 1];
+#pragma unroll
+                for (int mp = 0; mp < MT * 2; ++mp) {
+                    const int cgs = (mp * 2 + half) < ncg_out ? mp * 2 + half : -1;      // -1: no such output group, operand = 0
+                    if constexpr (HAS_R1) q1[mp] = res_issue(a.res1, b, cgs, pix, NPL == 2);
+                    if constexpr (HAS_R2) q2[mp] = res_issue(a.res2, b, cgs, pix, NPL == 2);
+                    if constexpr (HAS_MK) qm[mp] = res_issue(a.mask, b, (cgs >= a.mask_cg0 && cgs < a.mask_cg1) ? cgs - a.mask_cg0 : -1, pix, false);
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -525,42 +344,56 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
                         float v[2][4];
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            const int cg = cg0 + k, ch0 = cg * 8 + half * 4;
+                            const int ch0 = (cg0 + k) * 8 + half * 4;
                             const float4 bz = *(const float4*)(s_bias + ch0);
                             v[k][0] = acc[m][r][(gp * 2 + k) * 4 + 0] + bz.x; v[k][1] = acc[m][r][(gp * 2 + k) * 4 + 1] + bz.y;
                             v[k][2] = acc[m][r][(gp * 2 + k) * 4 + 2] + bz.z; v[k][3] = acc[m][r][(gp * 2 + k) * 4 + 3] + bz.w;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[k][i] = a.alpha * fmaxf(v[k][i], v[k][i] * a.act_slope);   // 0 < slope <= 1
-                            if ((EPI & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && cg < ncg_out) {
-                                float rv[4];
-                                if (EPI & EPI_RES1) {
-                                    load_res(a.res1, b * a.res1.bs + cg * a.res1.cs, pix * 2 + half, rv);
+                        }
+                        if constexpr (HAS_R1) {
+                            float rv[2][4];
+                            res_unpack(q1[m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[i], v[k][i]);
-                                }
-                                if (EPI & EPI_RES2) {
-                                    load_res(a.res2, b * a.res2.bs + cg * a.res2.cs, pix * 2 + half, rv);
+                            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[i], v[k][i]);
-                                }
-                                if ((EPI & EPI_MASK) && cg >= a.mask_cg0 && cg < a.mask_cg1) {
-                                    const uint2 h = ((const uint2*)(a.mask.hi + b * a.mask.bs + (cg - a.mask_cg0) * a.mask.cs))[pix * 2 + half];
-                                    // sign of the stored (post-activation) value == sign of the pre-activation (slope > 0)
-                                    const uint32_t sg[4] = {h.x & 0x8000u, h.x & 0x80000000u, h.y & 0x8000u, h.y & 0x80000000u};
-                                    const uint32_t nz[4] = {h.x & 0x7FFFu, h.x & 0x7FFF0000u, h.y & 0x7FFFu, h.y & 0x7FFF0000u};
+                                for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[k][i], v[k][i]);
+                        }
+                        if constexpr (HAS_R2) {
+                            float rv[2][4];
+                            res_unpack(q2[m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;   // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
-                                }
-                                if (EPI & EPI_NCHW) {
+                            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (ch0 + i < a.cout)
-                                            a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
-                                }
+                                for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[k][i], v[k][i]);
+                        }
+                        if constexpr (HAS_MK) {
+                            // LeakyReLU' from the stored post-activation value: its sign is the pre-activation's (slope > 0);
+                            // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
+                            uint32_t d[2][2];
+                            swap_halves(qm[m * 2 + gp].h, d);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int cg = cg0 + k;
+                                if (cg < a.mask_cg0 || cg >= a.mask_cg1) continue;
+                                const uint32_t sg[4] = {d[k][0] & 0x8000u, d[k][0] & 0x80000000u, d[k][1] & 0x8000u, d[k][1] & 0x80000000u};
+                                const uint32_t nz[4] = {d[k][0] & 0x7FFFu, d[k][0] & 0x7FFF0000u, d[k][1] & 0x7FFFu, d[k][1] & 0x7FFF0000u};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;
                             }
                         }
-                        if (EPI & EPI_NCHW) continue;                    // the fp32 NCHW destination replaces the act-layout one
+                        if constexpr ((EPI & EPI_NCHW) != 0) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int ch0 = (cg0 + k) * 8 + half * 4;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (ch0 + i < a.cout)
+                                        a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
+                            }
+                            continue;                                    // the fp32 NCHW destination replaces the act-layout one
+                        }
                         // split to hi + lo bf16 (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword
                         uint32_t hi[2][2], lo[2][2];
 #pragma unroll
@@ -602,15 +435,12 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel
                     }
                 }
             }
-            if (any_valid && !(EPI & EPI_NCHW)) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp)
-                        if (m * 4 + gp * 2 < ncg_out) n_store += NPL * ((EPI & EPI_OUT2) ? 2 : 1);
-            }
         }
     }
+    ESR_TR();
+#ifdef ESR_TRACE
+    if (tr && tid == 0) tr[127] = wall_clock64();
+#endif
 }
 
 // ---- weight packing: [M][K][3][3] fp32 -> [kstep = cp*9+tap][mtile][hi|lo][lane][8] bf16
@@ -641,8 +471,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
 struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
 // Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
-// halo-traffic term, under the LDS budget of one resident workgroup per CU with `nst` stages.
-TileCfg pick_tile(int H, int W, int npl, int mt, int nst) {
+// halo-traffic term, under the LDS budget that keeps `nwg` workgroups resident per CU.
+TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
     TileCfg best{};
     double best_cost = -1;
     const size_t budget = 160 * 1024;
@@ -659,7 +489,7 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nst) {
             int npix_l = max_px + 2 * P + 2;
             if (npix_l < npix_t) npix_l = npix_t;
             if (npix_l > MAXS * NW * 64) continue;
-            const size_t lds = nst * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024) + (size_t)mt * 32 * 4;
+            const size_t lds = nwg * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024) + (size_t)mt * 32 * 4;
             if (lds > budget) continue;
             const int nty = (H + TH - 1) / TH;
             const double halo = (double)(TH + 2) * P / ((double)TH * TW);
@@ -673,17 +503,14 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nst) {
     return best;
 }
 
-int conv_variant() {
-    static int v = -1;
-    // default: tile-per-workgroup (measured faster on MI355X, profiles/r01_*); ESR_CONV_VARIANT=P selects the persistent pipeline
-    if (v < 0) { const char* e = getenv("ESR_CONV_VARIANT"); v = (e && e[0] == 'P') ? 0 : 1; }
-    return v;
-}
+#ifdef ESR_TRACE
+unsigned long long* g_trace = nullptr;
+#endif
 
 template <int NPL, int MT, int EPI>
-int launch_tile(const ConvArgs& a, hipStream_t s) {
+int launch(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI>;
-    static bool attr_set = false;
+    static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
@@ -696,37 +523,28 @@ int launch_tile(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI>
-int launch(const ConvArgs& a, size_t lds, hipStream_t s) {
-    if (conv_variant() == 1) return launch_tile<NPL, MT, EPI>(a, s);
-    void (*k)(const ConvArgs) = conv3x3_kernel<NPL, MT, EPI>;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(256), dim3(NTHREADS), lds, s, a);   // persistent: one workgroup per CU
-    ESR_CHECK_LAUNCH();
-    return ESR_OK;
-}
-
 // the epilogue combinations the RRDB forward / backward plans use
 template <int NPL, int MT>
-int launch_epi(const ConvArgs& a, int epi, size_t lds, hipStream_t s) {
+int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case 0: return launch<NPL, MT, 0>(a, lds, s);
-        case EPI_RES1: return launch<NPL, MT, EPI_RES1>(a, lds, s);
-        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2>(a, lds, s);
-        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW>(a, lds, s);
-        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2>(a, lds, s);
-        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK>(a, lds, s);
-        case EPI_MASK: return launch<NPL, MT, EPI_MASK>(a, lds, s);
+        case 0: return launch<NPL, MT, 0>(a, s);
+        case EPI_RES1: return launch<NPL, MT, EPI_RES1>(a, s);
+        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2>(a, s);
+        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN>(a, s);
+        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2>(a, s);
+        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW>(a, s);
+        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2>(a, s);
+        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK>(a, s);
+        case EPI_MASK: return launch<NPL, MT, EPI_MASK>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
 }
 
 }  // namespace
+
+#ifdef ESR_TRACE
+extern "C" void esr_debug_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+#endif
 
 extern "C" size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split) {
     const int ncp = (ncg_in + 1) / 2, mt = (cout + 31) / 32;
@@ -773,8 +591,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.H = d->H;
     a.W = d->W;
     const int npl = split ? 2 : 1;
-    const int nst = mt == 1 ? 3 : 2;   // must match the kernel's NST
-    const TileCfg t = pick_tile(d->H, d->W, npl, mt, nst);
+    const int wgs_per_cu = mt == 1 ? 3 : 2;   // must match the kernel's __launch_bounds__
+    const TileCfg t = pick_tile(d->H, d->W, npl, mt, wgs_per_cu);
     if (t.TH == 0) return ESR_E_UNSUPPORTED;
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
@@ -792,14 +610,29 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg0 = d->mask_cg0;
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
+#ifdef ESR_TRACE
+    a.trace = g_trace;
+#endif
     int epi = 0;
     if (d->res1.hi) epi |= EPI_RES1;
+    // residual 1 == a channel-group slice of this conv's own main input, linear epilogue: take it from the staged LDS tile
+    if (d->res1.hi && d->act_slope == 1.f && d->alpha != 0.f && ups == 1 && !d->mask_src.hi && !d->out_nchw &&
+        d->res1.batch_stride == d->in1.batch_stride && d->res1.cg_stride == d->in1.cg_stride && ((d->res1.lo != nullptr) == split)) {
+        const long long unit = (long long)d->in1.cg_stride * 16;
+        const long long off = (const char*)d->res1.hi - (const char*)d->in1.hi;
+        const bool lo_ok = !split || ((const char*)d->res1.lo - (const char*)d->in1.lo) == off;
+        if (lo_ok && off >= 0 && off % unit == 0 && off / unit + (d->cout + 7) / 8 <= d->in1.ncg) {
+            a.resin_g0 = a.in0.ncg + (int)(off / unit);
+            a.resin_scale = d->beta1 / d->alpha;
+            epi = (epi & ~EPI_RES1) | EPI_RESIN;
+        }
+    }
     if (d->res2.hi) epi |= EPI_RES2;
     if (d->mask_src.hi) epi |= EPI_MASK;
     if (d->out_nchw) epi |= EPI_NCHW;
     if (d->out2.hi) epi |= EPI_OUT2;
     if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
-    if (split) return mt == 1 ? launch_epi<2, 1>(a, epi, t.lds, s) : launch_epi<2, 2>(a, epi, t.lds, s);
-    return mt == 1 ? launch_epi<1, 1>(a, epi, t.lds, s) : launch_epi<1, 2>(a, epi, t.lds, s);
+    if (split) return mt == 1 ? launch_epi<2, 1>(a, epi, s) : launch_epi<2, 2>(a, epi, s);
+    return mt == 1 ? launch_epi<1, 1>(a, epi, s) : launch_epi<1, 2>(a, epi, s);
 }

@@ -62,7 +62,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # ESR_HIP_LIBRARY: an alternative build of the same C-ABI (e.g. an instrumented one); still no fallback if it is missing
+    return os.environ.get('ESR_HIP_LIBRARY') or os.path.join(_HERE, _LIB_NAME)
 
 
 def load_library():
