@@ -31,6 +31,15 @@ namespace {
 constexpr int NW = 4;          // waves per workgroup
 constexpr int NTHREADS = 256;
 constexpr int MAXS = 3;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+// Measured on MI355X (RRDB-23 forward, ms): MT1/MT2 resident workgroups 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is
+// power-limited under this kernel: beyond the overlap that reaches the power cap, more resident waves cost clock.
+#ifndef ESR_WGS_MT1
+#define ESR_WGS_MT1 2
+#endif
+#ifndef ESR_WGS_MT2
+#define ESR_WGS_MT2 2
+#endif
+constexpr int WGS_MT1 = ESR_WGS_MT1, WGS_MT2 = ESR_WGS_MT2;   // resident workgroups per CU the kernels are built (registers) and tiled (LDS) for
 constexpr int R = 3;           // 32-pixel column tiles per wave: a workgroup tile holds up to NW*R*32 = 384 flattened pixels
 
 // epilogue feature bits (template parameter EPI)
@@ -196,7 +205,7 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
 // One output tile per workgroup, single LDS stage, 2-3 workgroups resident per CU: latency hiding comes from the co-resident
 // workgroups instead of an in-workgroup pipeline (the persistent multi-stage variant measured slower).
 template <int NPL, int MT, int EPI>
-__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void conv3x3_tile_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3_tile_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -591,7 +600,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.H = d->H;
     a.W = d->W;
     const int npl = split ? 2 : 1;
-    const int wgs_per_cu = mt == 1 ? 3 : 2;   // must match the kernel's __launch_bounds__
+    const int wgs_per_cu = mt == 1 ? WGS_MT1 : WGS_MT2;
     const TileCfg t = pick_tile(d->H, d->W, npl, mt, wgs_per_cu);
     if (t.TH == 0) return ESR_E_UNSUPPORTED;
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
