@@ -150,6 +150,13 @@ def main():
     value = world * hr_px * args.steps / dt
 
     if rank == 0:
+        # HBM bytes per conv launch from the PMC passes of this same command (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
+        # FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/
+        import glob
+        traffic = None
+        pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+        if pmc and BATCH == 32:
+            traffic = json.load(open(pmc[-1]))['hbm_bytes_per_launch']
         conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
         t_launch = conv_ms * 1e-3 / N_CONV_LAUNCHES
         achieved = (ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES) / t_launch
@@ -165,12 +172,15 @@ def main():
             'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
                        'arithmetic': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate' if args.precision == 'split' else 'bf16 MFMA operands, fp32 accumulate',
                        'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_kernel (351 launches per forward)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': None,
+            'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
+                         'traffic_source': os.path.basename(pmc[-1]) if traffic else None,
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
                          'generator_ms_per_step': conv_ms,
                          'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15},
+                         'mfma_bf16_issue_frac': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                         # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
+                         'mfma_bf16_issue_frac_of_measured_1.79PF': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
         if not args.no_cpu_baseline:

@@ -243,7 +243,11 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
     const unsigned char* const sb = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa = smem + 2 * NPL * plane_bytes + lane * 16;
+#ifdef ESR_ABL_TERMS
+    constexpr int NTERM = NPL == 2 ? ESR_ABL_TERMS : 1;   // ablation build: wrong results, timing only
+#else
     constexpr int NTERM = NPL == 2 ? 3 : 1;
+#endif
     constexpr int NM = MT * R * NTERM;
     constexpr int NL = (MT + R) * NPL;
     constexpr int NSLOT = NM > NL ? NM : NL;
@@ -251,7 +255,15 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
         const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
         ESR_TR();
 #pragma unroll
-        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+        for (int op = 0; op < NOPS; ++op) {
+#ifdef ESR_ABL_NOWDMA
+            if (op >= NACT && cp > 0) continue;
+#endif
+#ifdef ESR_ABL_NOADMA
+            if (op < NACT && cp > 0) continue;
+#endif
+            dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+        }
         ESR_TR();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ESR_TR();
@@ -277,7 +289,11 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
                     const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
                     acc[m][r] = mfma(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
                 }
+#ifdef ESR_ABL_NOLDS
+                if (t < 8 && i < NL && cp == 0) load_frag(t + 1, i, cb ^ 1);
+#else
                 if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
