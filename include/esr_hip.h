@@ -59,6 +59,10 @@ typedef struct {
  * Also used as the data-gradient of the same conv (weights packed transposed+flipped).
  *
  *   out = alpha * act(conv(in0 ++ in1) + bias) + beta1*res1 + beta2*res2
+ *
+ * When res1 is a channel-group slice of in1 itself (same strides; the RDB's  conv5*0.2 + x, block.py:235) and act_slope == 1,
+ * the library notices it from the pointers and takes the residual from the input tile it stages on chip anyway (no extra reads);
+ * the result is the same expression evaluated in fp32.
  */
 typedef struct {
     esr_act_view in0;        /* optional leading segment (latent Z group); ncg = 0 when absent */
