@@ -206,21 +206,37 @@ struct WgradArgs {
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ void glds16w(const uint4* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
 }
 
-__device__ __forceinline__ float ld_split(const unsigned char* hi, int lo_off) {
-    const uint32_t h = *(const uint16_t*)hi;
-    float v = __uint_as_float(h << 16);
-    if (lo_off) {
-        const uint32_t l = *(const uint16_t*)(hi + lo_off);
-        v += __uint_as_float(l << 16);
-    }
-    return v;
+// LDS planes are padded so that consecutive channel groups start 64 bytes apart modulo 256: the four 64-byte runs a half-wave
+// touches in one ds_read_b64_tr_b16 (2 groups x 4 pixels, twice) then fall into four different 16-bank windows
+constexpr int XP = WG_TH * (WG_TW + 2), XPP = 276;   // x pixels per plane in LDS (8 rows x 34 = 272, padded: 276 % 16 == 4)
+constexpr int YP = WG_TH * WG_TW, YPP = 260;         // dy pixels per plane (256, padded: 260 % 16 == 4)
+
+// One MFMA operand fragment whose K axis runs over PIXELS, out of the pixel-major [pixel][8 channels] LDS image: gfx950's
+// transposing LDS read.  Inside a 16-lane group, lane i points at 4 consecutive channels (8 bytes) of pixel (i >> 2) in channel
+// quad (i & 3) of the group's 16 channels; the hardware hands lane l the 4 pixels of channel l (profiles/microbench/tr_b16_probe.hip).
+// Two reads (pixels +0..3, +4..7) make the 8 K-values of one lane.
+__device__ __forceinline__ uint4 frag_tr(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(size_t)(p));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(size_t)(p + 64));
+    const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
+    return make_uint4(u0.x, u0.y, u1.x, u1.y);
 }
 
+__device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// dW[co][ci][dy][dx] = sum over pixels of dY[co][p] * X[ci][p + tap]: a GEMM with M = output channels, N = 32 input channels,
+// K = pixels, on the bf16 MFMA pipe with the same split operands as the forward (dYlo*Xhi + dYhi*Xlo + dYhi*Xhi, fp32 accumulate).
+// Workgroup = (32-input-channel tile, kernel row dy) x a slice of the 8x32-pixel tiles; its 4 waves split a tile's rows (split K),
+// each keeping MT x 3 (dx) accumulator tiles; waves are reduced through LDS and slices with one atomicAdd per weight.
 template <int MT, int NPL>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -230,26 +246,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
     const int cit = group / 3, dyk = group % 3;                  // input-channel tile, kernel row
     const bool lat_tile = cit >= a.ncit_main;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    constexpr int XP = WG_TH * (WG_TW + 2);                      // x pixels per plane in LDS
-    constexpr int YP = WG_TH * WG_TW;                            // dy pixels per plane
-    constexpr int X_BYTES = 4 * NPL * XP * 16;                   // [4 groups][NPL][XP]
+    constexpr int X_BYTES = 4 * NPL * XPP * 16;                  // [hi|lo][4 groups][XPP]
     constexpr int XSLOTS = (XP + 63) / 64, YSLOTS = YP / 64;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
 
-    f32x16_t acc[MT][3];
+    f32x16_t acc[MT][3], accb[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accb[m][i] = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][d][i] = 0.f;
-    float bsum[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
-    const bool do_bias = (group == 0) && a.db;
+    }
+    const bool do_bias = (group == 0) && a.db;                   // uniform: the first group's workgroups also reduce dY itself
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
 
-    const int chan = lane & 31, kk = lane >> 5;                   // this lane's channel inside the 32-tile, pixel of the pair
-    const int cgl = chan >> 3, ce = (chan & 7) * 2;               // group inside the tile, byte offset of the channel in a vector
+    // this lane's source address inside a fragment's 16-lane group (see frag_tr)
+    const int li = lane & 15, grp16 = lane >> 4;
+    const int rb2 = (grp16 & 1) * 2 + ((li & 3) >> 1);           // channel group (of the 32-channel tile's 4) this lane points into
+    const int kb = (grp16 >> 1) * 8 + (li >> 2);                 // pixel inside the 16-pixel K step
+    const int lane_off = (li & 1) * 8;                           // low / high 4 channels of the 16-byte vector
+    const unsigned char* const xs = smem + rb2 * XPP * 16 + kb * 16 + lane_off;
+    const unsigned char* const ys = smem + X_BYTES + rb2 * YPP * 16 + kb * 16 + lane_off;
+    constexpr int XLO = 4 * XPP * 16, YLO = MT * 4 * YPP * 16;   // hi plane set -> lo plane set
 
     for (int tile = slice; tile < ntiles; tile += a.nslices) {
         const int tx = tile % a.tiles_x;
@@ -257,10 +278,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
         const int ty = r1 % a.tiles_y;
         const int b = r1 / a.tiles_y;
         const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-        // ---- stage X: rows y0+dyk .. (padded coords), cols x0 .. x0+TW+1 ; 4 groups x NPL planes
+        // ---- stage X: rows y0+dyk .. (padded coords), cols x0 .. x0+TW+1 ; NPL x 4 group planes
         for (int s = wave; s < 4 * NPL * XSLOTS; s += 4) {
-            const int pl = s / XSLOTS, sl = s % XSLOTS;           // plane = group*NPL + (hi|lo)
-            const int g = pl / NPL, islo = pl % NPL;
+            const int pl = s / XSLOTS, sl = s % XSLOTS;           // plane = (hi|lo)*4 + group
+            const int islo = pl / 4, g = pl % 4;
             const int p = sl * 64 + lane;
             if (p < XP) {
                 const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
@@ -273,42 +294,52 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
                 const int cg = lat_tile ? g : cit * 4 + g;
                 const bool have = cg < v.ncg;
                 const uint4* base = (islo ? v.lo : v.hi) + b * v.bs + (have ? cg : 0) * v.cs;
-                glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), lds0 + pl * XP * 16 + sl * 1024);
+                glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), lds0 + pl * XPP * 16 + sl * 1024);
             }
         }
-        // ---- stage dY: rows y0.., cols x0.. ; MT*4 groups x NPL planes
+        // ---- stage dY: rows y0.., cols x0.. ; NPL x MT*4 group planes
         for (int s = wave; s < MT * 4 * NPL * YSLOTS; s += 4) {
             const int pl = s / YSLOTS, sl = s % YSLOTS;
-            const int g = pl / NPL, islo = pl % NPL;
+            const int islo = pl / (MT * 4), g = pl % (MT * 4);
             const int p = sl * 64 + lane;
             const int rr = p / WG_TW, cc = p - rr * WG_TW;
             const int Y = y0 + rr, X = x0 + cc;
             const bool inb = (Y < a.H) && (X < a.W) && (g < a.dy.ncg);
             const uint4* base = (islo ? a.dy.lo : a.dy.hi) + b * a.dy.bs + (g < a.dy.ncg ? g : 0) * a.dy.cs;
-            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), lds0 + X_BYTES + pl * YP * 16 + sl * 1024);
+            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), lds0 + X_BYTES + pl * YPP * 16 + sl * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // ---- MFMAs: wave handles rows wave, wave+4
-        const unsigned char* xs = smem + (cgl * NPL) * XP * 16 + ce;
-        const unsigned char* ys = smem + X_BYTES + ce;
-        constexpr int XLO = NPL == 2 ? XP * 16 : 0, YLO = NPL == 2 ? YP * 16 : 0;
-        for (int rr = wave; rr < WG_TH; rr += 4) {
-#pragma unroll 4
-            for (int pp = 0; pp < WG_TW / 2; ++pp) {
-                const int xx = 2 * pp + kk;
-                float av[MT], bv[3];
+        // ---- MFMAs: wave handles rows wave, wave+4; a row of 32 pixels = two K steps of 16
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    av[m] = ld_split(ys + ((m * 4 + cgl) * NPL) * YP * 16 + (rr * WG_TW + xx) * 16, YLO);
-                    bsum[m] += av[m];
-                }
+        for (int rq = 0; rq < WG_TH / 4; ++rq) {
+            const int rr = wave + rq * 4;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) bv[d] = ld_split(xs + (rr * (WG_TW + 2) + xx + d) * 16, XLO);
+            for (int ks = 0; ks < WG_TW / 16; ++ks) {
+                uint4 fa[MT][NPL], fb[3][NPL];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) acc[m][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[d], acc[m][d], 0, 0, 0);
+                    for (int pl = 0; pl < NPL; ++pl) fa[m][pl] = frag_tr(ys + pl * YLO + (m * 4 * YPP + rr * WG_TW + ks * 16) * 16);
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) fb[d][pl] = frag_tr(xs + pl * XLO + (rr * (WG_TW + 2) + ks * 16 + d) * 16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        if (NPL == 2) {
+                            acc[m][d] = mfma_bf16(fa[m][1], fb[d][0], acc[m][d]);
+                            acc[m][d] = mfma_bf16(fa[m][0], fb[d][NPL - 1], acc[m][d]);
+                        }
+                        acc[m][d] = mfma_bf16(fa[m][0], fb[d][0], acc[m][d]);
+                    }
+                    if (do_bias) {                                // dY x ones: every column of the tile holds sum_k dY[row][k]
+                        accb[m] = mfma_bf16(fa[m][0], ones, accb[m]);
+                        if (NPL == 2) accb[m] = mfma_bf16(fa[m][1], ones, accb[m]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -321,9 +352,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) red[((wave * MT * 3 + m * 3 + d) * 16 + i) * 64 + lane] = acc[m][d][i];
-    float* bred = red + 4 * MT * 3 * 16 * 64;                    // [wave][MT][64]
+    float* bred = red + 4 * MT * 3 * 16 * 64;                    // [wave][MT][16][64]
+    if (do_bias) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) bred[(wave * MT + m) * 64 + lane] = bsum[m];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bred[((wave * MT + m) * 16 + i) * 64 + lane] = accb[m][i];
+    }
     __syncthreads();
     for (int e = tid; e < MT * 3 * 16 * 64; e += 256) {
         float v = 0.f;
@@ -339,12 +374,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
         if (co < a.cout && ci >= 0) atomicAdd(a.dw + ((long long)co * a.cin_total + ci) * 9 + dyk * 3 + d, a.alpha * v);
     }
     if (do_bias) {
+        // column 0 of each D tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
         for (int e = tid; e < MT * 32; e += 256) {
-            const int m = e >> 5, c = e & 31;
+            const int m = e >> 5, row = e & 31;
+            const int i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
             float v = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += bred[(w4 * MT + m) * 64 + c] + bred[(w4 * MT + m) * 64 + c + 32];
-            if (m * 32 + c < a.cout) atomicAdd(a.db + m * 32 + c, a.alpha * v);
+            for (int w4 = 0; w4 < 4; ++w4) v += bred[((w4 * MT + m) * 16 + i) * 64 + ln];
+            if (m * 32 + row < a.cout) atomicAdd(a.db + m * 32 + row, a.alpha * v);
         }
     }
 }
@@ -384,8 +421,8 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     a.dw = d->dw;
     a.db = d->db;
     const int npl = split ? 2 : 1;
-    const size_t stage = (size_t)4 * npl * WG_TH * (WG_TW + 2) * 16 + (size_t)mt * 4 * npl * WG_TH * WG_TW * 16;
-    const size_t red = (size_t)4 * mt * 3 * 16 * 64 * 4 + (size_t)4 * mt * 64 * 4;
+    const size_t stage = (size_t)4 * npl * XPP * 16 + (size_t)mt * 4 * npl * YPP * 16;
+    const size_t red = (size_t)4 * mt * 3 * 16 * 64 * 4 + (size_t)4 * mt * 16 * 64 * 4;
     const size_t lds = stage > red ? stage : red;
     void (*k)(const WgradArgs) = split ? (mt == 1 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<2, 2>)
                                        : (mt == 1 ? conv3x3_wgrad_kernel<1, 1> : conv3x3_wgrad_kernel<2, 1>);
