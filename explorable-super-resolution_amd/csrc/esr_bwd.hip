@@ -203,6 +203,8 @@ struct WgradArgs {
     float alpha;
     float* dw;
     float* db;
+    float* ws;                 // partial sums: [group][slice][MT*3*1024] then [slice][MT*32] (bias)
+    int ngroups;
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -360,10 +362,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
             for (int i = 0; i < 16; ++i) bred[((wave * MT + m) * 16 + i) * 64 + lane] = accb[m][i];
     }
     __syncthreads();
+    // the workgroup's partial sums go to the workspace in raw accumulator order (coalesced); wgrad_reduce_kernel folds the
+    // slices and scatters into dW (float atomics from ~10^3 workgroups onto ~10^4 addresses measured 5x slower than the MFMAs)
+    float* const wsp = a.ws + ((size_t)group * a.nslices + slice) * (MT * 3 * 1024);
     for (int e = tid; e < MT * 3 * 16 * 64; e += 256) {
         float v = 0.f;
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * MT * 3 * 16 * 64 + e];
+        wsp[e] = v;
+    }
+    if (do_bias) {
+        // column 0 of each D tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
+        float* const wsb = a.ws + (size_t)a.ngroups * a.nslices * (MT * 3 * 1024) + (size_t)slice * (MT * 32);
+        for (int e = tid; e < MT * 32; e += 256) {
+            const int m = e >> 5, row = e & 31;
+            const int i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += bred[((w4 * MT + m) * 16 + i) * 64 + ln];
+            wsb[e] = v;
+        }
+    }
+}
+
+// dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus MT*32 threads for the bias
+__global__ void wgrad_reduce_kernel(const WgradArgs a, int mt) {
+    const int per = mt * 3 * 1024;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nmain = (long long)a.ngroups * per;
+    if (idx < nmain) {
+        const int group = (int)(idx / per), e = (int)(idx % per);
+        const float* p = a.ws + (size_t)group * a.nslices * per + e;
+        float v = 0.f;
+        for (int s = 0; s < a.nslices; ++s) v += p[(size_t)s * per];
+        const int cit = group / 3, dyk = group % 3;
+        const bool lat_tile = cit >= a.ncit_main;
         const int ln = e & 63, i = (e >> 6) & 15, md = e >> 10;
         const int m = md / 3, d = md % 3;
         const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);       // D row
@@ -371,22 +404,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
         int ci = -1;
         if (lat_tile) { if (c < a.lat) ci = c; }
         else if (cit * 32 + c < a.cin_main) ci = a.lat + cit * 32 + c;
-        if (co < a.cout && ci >= 0) atomicAdd(a.dw + ((long long)co * a.cin_total + ci) * 9 + dyk * 3 + d, a.alpha * v);
-    }
-    if (do_bias) {
-        // column 0 of each D tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
-        for (int e = tid; e < MT * 32; e += 256) {
-            const int m = e >> 5, row = e & 31;
-            const int i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
-            float v = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += bred[((w4 * MT + m) * 16 + i) * 64 + ln];
-            if (m * 32 + row < a.cout) atomicAdd(a.db + m * 32 + row, a.alpha * v);
-        }
+        if (co < a.cout && ci >= 0) a.dw[((long long)co * a.cin_total + ci) * 9 + dyk * 3 + d] += a.alpha * v;
+    } else if (a.db && idx < nmain + mt * 32) {
+        const int e = (int)(idx - nmain);
+        const float* p = a.ws + (size_t)nmain * a.nslices + e;
+        float v = 0.f;
+        for (int s = 0; s < a.nslices; ++s) v += p[(size_t)s * (mt * 32)];
+        if (e < a.cout) a.db[e] += a.alpha * v;
     }
 }
 
+// grid decomposition shared by the workspace query and the launch
+struct WgradPlan { int tiles_x, tiles_y, ncit_main, ngroups, nslices, mt; };
+static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
+    WgradPlan p;
+    p.mt = (d->cout + 31) / 32;
+    p.tiles_x = (d->W + WG_TW - 1) / WG_TW;
+    p.tiles_y = (d->H + WG_TH - 1) / WG_TH;
+    p.ncit_main = (d->cin_main + 31) / 32;
+    const int lat = d->xlat.hi ? d->lat : 0;
+    p.ngroups = (p.ncit_main + (lat ? 1 : 0)) * 3;
+    const int ntiles = p.tiles_x * p.tiles_y * d->B;
+    int ns = (768 + p.ngroups - 1) / p.ngroups;      // ~3 workgroups per CU in total
+    if (ns > ntiles) ns = ntiles;
+    if (ns < 1) ns = 1;
+    p.nslices = ns;
+    return p;
+}
+
 }  // namespace
+
+extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0 || d->cout > 64) return ESR_E_ARG;
+    const WgradPlan p = wgrad_plan(d);
+    return (int64_t)p.ngroups * p.nslices * (p.mt * 3 * 1024) + (int64_t)p.nslices * (p.mt * 32);
+}
 
 extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     if (!d || !d->dy.hi || !d->x.hi || !d->dw || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
@@ -397,6 +449,8 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     if (mt > 2) return ESR_E_UNSUPPORTED;
     const bool split = d->dy.lo != nullptr;
     if ((d->x.lo != nullptr) != split) return ESR_E_ARG;
+    if (!d->workspace || d->workspace_floats < esr_conv3x3_wgrad_workspace_floats(d)) return ESR_E_ARG;
+    const WgradPlan p = wgrad_plan(d);
     WgradArgs a{};
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
@@ -408,18 +462,15 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     a.cin_total = d->cin_main + a.lat;
     a.B = d->B; a.H = d->H; a.W = d->W;
     a.Wx_p = d->x.W + 2;
-    a.tiles_x = (d->W + WG_TW - 1) / WG_TW;
-    a.tiles_y = (d->H + WG_TH - 1) / WG_TH;
-    a.ncit_main = (d->cin_main + 31) / 32;
-    const int ngroups = (a.ncit_main + (a.lat ? 1 : 0)) * 3;
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    int ns = (768 + ngroups - 1) / ngroups;          // ~3 workgroups per CU in total
-    if (ns > ntiles) ns = ntiles;
-    if (ns < 1) ns = 1;
-    a.nslices = ns;
+    a.tiles_x = p.tiles_x;
+    a.tiles_y = p.tiles_y;
+    a.ncit_main = p.ncit_main;
+    a.ngroups = p.ngroups;
+    a.nslices = p.nslices;
     a.alpha = d->alpha;
     a.dw = d->dw;
     a.db = d->db;
+    a.ws = d->workspace;
     const int npl = split ? 2 : 1;
     const size_t stage = (size_t)4 * npl * XPP * 16 + (size_t)mt * 4 * npl * YPP * 16;
     const size_t red = (size_t)4 * mt * 3 * 16 * 64 * 4 + (size_t)4 * mt * 16 * 64 * 4;
@@ -428,7 +479,10 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
                                        : (mt == 1 ? conv3x3_wgrad_kernel<1, 1> : conv3x3_wgrad_kernel<2, 1>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(ngroups * ns), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), lds, (hipStream_t)stream, a);
+    ESR_CHECK_LAUNCH();
+    const long long nred = (long long)p.ngroups * mt * 3 * 1024 + mt * 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, mt);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }

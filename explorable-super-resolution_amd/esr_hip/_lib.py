@@ -30,7 +30,7 @@ class WgradDesc(C.Structure):
     """esr_wgrad_desc (include/esr_hip.h)."""
     _fields_ = [('dy', ActView), ('x', ActView), ('xlat', ActView), ('lat', C.c_int32), ('upsample', C.c_int32), ('cout', C.c_int32),
                 ('cin_main', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('alpha', C.c_float), ('dw', C.c_void_p),
-                ('db', C.c_void_p)]
+                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_floats', C.c_int64)]
 
 
 _SIGS = {
@@ -50,6 +50,7 @@ _SIGS = {
     'esr_cem_adjoint': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'esr_conv3x3_wgrad': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    'esr_conv3x3_wgrad_workspace_floats': (C.c_int64, [C.POINTER(WgradDesc)]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -228,8 +228,26 @@ def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, devi
     d.B, d.H, d.W = B, H, W
     d.alpha = alpha
     d.dw, d.db = dw.data_ptr(), db.data_ptr()
+    need = _lib.lib.esr_conv3x3_wgrad_workspace_floats(C.byref(d))
+    check(min(need, 0), 'esr_conv3x3_wgrad_workspace_floats')
+    ws = _wgrad_workspace(device, need)
+    d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(_lib.lib.esr_conv3x3_wgrad(C.byref(d), stream_ptr()), 'esr_conv3x3_wgrad')
     return dw, db
+
+
+_WS = {}
+
+
+def _wgrad_workspace(device, nfloats):
+    """One grow-only scratch tensor per device: the weight-gradient launches of a backward pass run back to back on one stream,
+    so they can share it."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
 
 
 def conv3x3_wgrad_nchw(dy, x, wshape, split=True):

@@ -159,7 +159,9 @@ int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int o
 /* ---- conv3x3 weight / bias gradient (autograd of nn.Conv2d, block.py:141-142) ----
  *   dw[co][lat+ci][dy][dx] += alpha * sum_{b,y,x} dy[b,co,y,x] * x[b,ci,(y+dy-1)/up,(x+dx-1)/up]     (zero padded)
  *   dw[co][e][dy][dx]      += ... with xlat for the latent channels e < lat;   db[co] += alpha * sum dy
- * dw ([cout][lat+cin_main][3][3]) and db ([cout], may be NULL) are fp32 and ACCUMULATED into (zero them first). */
+ * dw ([cout][lat+cin_main][3][3]) and db ([cout], may be NULL) are fp32 and ACCUMULATED into (zero them first).
+ * The pixel sum is split over ~3 workgroups per CU; their partial tiles go through `workspace` (caller-owned device memory of at
+ * least esr_conv3x3_wgrad_workspace_floats(d) floats, contents undefined afterwards) and a second small kernel folds them. */
 typedef struct {
     esr_act_view dy;         /* gradient w.r.t. the conv's (pre-activation) output, cout channels */
     esr_act_view x;          /* the conv's main input (before the nearest upsample when upsample > 1) */
@@ -171,7 +173,10 @@ typedef struct {
     float alpha;
     float* dw;
     float* db;
+    float* workspace;
+    int64_t workspace_floats;
 } esr_wgrad_desc;
+int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d);   /* depends on B, H, W, cout, cin_main, lat only; <0: bad argument */
 int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream);
 
 int esr_version(void);

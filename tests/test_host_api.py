@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_exports_every_declared_symbol():
     from esr_hip import _lib
     hdr = open(os.path.join(ROOT, 'include', 'esr_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|size_t)\s+(esr_\w+)\s*\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^(?:int|size_t|int64_t)\s+(esr_\w+)\s*\(', hdr, flags=re.M))
     assert declared, 'no entry points parsed from the header'
     h = _lib.load_library()
     for name in declared:
