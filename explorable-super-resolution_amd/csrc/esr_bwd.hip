@@ -183,14 +183,15 @@ extern "C" int esr_unpack_grad_nchw(const esr_act_view* G, float* dst, int64_t d
 // Weight (and bias) gradient of conv3x3:   dW[co][ci][dy][dx] = alpha * sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy-1,x+dx-1]
 // (autograd of nn.Conv2d in the reference, codes/models/modules/block.py:141-142).
 //
-// The contraction runs over PIXELS, while both operands store 8 CHANNELS contiguously per pixel.  v_mfma_f32_32x32x2_f32 takes
-// one fp32 scalar per lane for A (row = lane&31, k = lane>>5) and for B (col = lane&31, k = lane>>5), so with k = two adjacent
-// pixels every lane reads exactly "its channel of its pixel" — no transposition anywhere — and hi+lo recombine to the exact value
-// (fp32 MFMA == an fmaf chain, so this kernel has fp32 accuracy).
-//   workgroup  = (32 input channels = 4 groups, one kernel row dy) x a slice of the image tiles; 4 waves
-//   per tile   : LDS-DMA of dY[TH x TW] (all output groups) and X[TH x (TW+2)] (row offset dy), barrier, then per pixel pair
-//                MT x 3 MFMAs (3 = dx taps) per wave; waves split the tile's rows
-//   end        : the 4 waves' accumulators are summed through LDS and added to dW with fp32 atomics (split-K over slices)
+// A GEMM with M = 32 output channels, N = 32 input channels and K = PIXELS on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16, 16
+// pixels per instruction) with the forward's split operands: dYlo*Xhi + dYhi*Xlo + dYhi*Xhi, fp32 accumulate.  Both operands
+// store 8 CHANNELS contiguously per pixel, so "8 consecutive pixels of one channel per lane" is a transposition — done by gfx950's
+// transposing LDS read (ds_read_b64_tr_b16) straight out of the pixel-major tiles that LDS-DMA copies verbatim from HBM.
+//   workgroup  = (32-input-channel tile, 32-output-channel tile) x a slice of the 8x32-pixel image tiles; 4 waves; all 9 taps
+//   per tile   : LDS-DMA of dY[8 x 32] and the haloed X[10 x 34] (4 channel groups each, hi + lo) into one of two LDS stages,
+//                issued one tile ahead of the MFMAs; waves split the tile's rows (split K), 2 rows x 2 K-steps x 9 taps x 3 terms
+//   end        : the 4 waves' accumulators are summed through LDS, written to the caller's workspace, and wgrad_reduce_kernel folds
+//                the slices into dW / db (float atomics from ~10^3 workgroups onto ~10^4 addresses measured 5x slower than the MFMAs)
 namespace {
 
 constexpr int WG_TH = 8, WG_TW = 32;       // tile: 256 pixels
@@ -199,12 +200,11 @@ struct WgradArgs {
     DView dy, x, xlat;
     int lat, ups, cout, cin_main, cin_total, B, H, W;
     int Wx_p;                  // padded row pitch of the x source (W/ups + 2)
-    int tiles_x, tiles_y, nslices, ncit_main;
+    int tiles_x, tiles_y, nslices, ncit_main, ncit, mt, ngroups;
     float alpha;
     float* dw;
     float* db;
-    float* ws;                 // partial sums: [group][slice][MT*3*1024] then [slice][MT*32] (bias)
-    int ngroups;
+    float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -214,15 +214,17 @@ __device__ __forceinline__ void glds16w(const uint4* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
 }
 
-// LDS planes are padded so that consecutive channel groups start 64 bytes apart modulo 256: the four 64-byte runs a half-wave
-// touches in one ds_read_b64_tr_b16 (2 groups x 4 pixels, twice) then fall into four different 16-bank windows
-constexpr int XP = WG_TH * (WG_TW + 2), XPP = 276;   // x pixels per plane in LDS (8 rows x 34 = 272, padded: 276 % 16 == 4)
-constexpr int YP = WG_TH * WG_TW, YPP = 260;         // dy pixels per plane (256, padded: 260 % 16 == 4)
+// LDS planes are sized so that consecutive channel groups start 64 bytes apart modulo 256: the four 64-byte runs a half-wave
+// touches in one ds_read_b64_tr_b16 (2 groups x 4 pixels, for two 16-lane groups) then fall into four different 16-bank windows
+constexpr int XP = (WG_TH + 2) * (WG_TW + 2);        // 340 haloed x pixels per plane; 340 % 16 == 4
+constexpr int YP = WG_TH * WG_TW, YPP = 260;         // 256 dy pixels per plane, padded: 260 % 16 == 4
+constexpr int XSLOTS = (XP + 63) / 64, YSLOTS = YP / 64;            // 64-pixel DMA slots per plane: 6, 4
+constexpr int WG_X_BYTES = 4 * XP * 16, WG_Y_BYTES = 4 * YPP * 16;  // one plane set (4 groups)
+static_assert(XP % 16 == 4 && YPP % 16 == 4, "bank spreading of the transposing reads");
 
-// One MFMA operand fragment whose K axis runs over PIXELS, out of the pixel-major [pixel][8 channels] LDS image: gfx950's
-// transposing LDS read.  Inside a 16-lane group, lane i points at 4 consecutive channels (8 bytes) of pixel (i >> 2) in channel
-// quad (i & 3) of the group's 16 channels; the hardware hands lane l the 4 pixels of channel l (profiles/microbench/tr_b16_probe.hip).
-// Two reads (pixels +0..3, +4..7) make the 8 K-values of one lane.
+// One MFMA operand fragment whose K axis runs over PIXELS, out of the pixel-major [pixel][8 channels] LDS image.  Inside a 16-lane
+// group, lane i points at 4 consecutive channels (8 bytes) of pixel (i >> 2) in channel quad (i & 3) of the group's 16 channels; the
+// hardware hands lane l the 4 pixels of channel l (profiles/microbench/tr_b16_probe.hip).  Two reads make the 8 K-values of a lane.
 __device__ __forceinline__ uint4 frag_tr(const unsigned char* p) {
     typedef __attribute__((address_space(3))) s16x4* lptr;
     const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(size_t)(p));
@@ -235,159 +237,162 @@ __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// dW[co][ci][dy][dx] = sum over pixels of dY[co][p] * X[ci][p + tap]: a GEMM with M = output channels, N = 32 input channels,
-// K = pixels, on the bf16 MFMA pipe with the same split operands as the forward (dYlo*Xhi + dYhi*Xlo + dYhi*Xhi, fp32 accumulate).
-// Workgroup = (32-input-channel tile, kernel row dy) x a slice of the 8x32-pixel tiles; its 4 waves split a tile's rows (split K),
-// each keeping MT x 3 (dx) accumulator tiles; waves are reduced through LDS and slices with one atomicAdd per weight.
-template <int MT, int NPL>
+template <int NPL>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = blockIdx.x / a.nslices, slice = blockIdx.x % a.nslices;
-    const int cit = group / 3, dyk = group % 3;                  // input-channel tile, kernel row
+    const int cit = group / a.mt, cot = group % a.mt;            // input-channel tile, output-channel tile
     const bool lat_tile = cit >= a.ncit_main;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    constexpr int X_BYTES = 4 * NPL * XPP * 16;                  // [hi|lo][4 groups][XPP]
-    constexpr int XSLOTS = (XP + 63) / 64, YSLOTS = YP / 64;
+    constexpr int STAGE = NPL * (WG_X_BYTES + WG_Y_BYTES);       // [X hi | X lo | dY hi | dY lo], 4 group planes each
+    constexpr int NX = NPL * 4 * XSLOTS / 4, NY = NPL * 4 * YSLOTS / 4;   // DMA instructions per wave per tile: 12 + 8 (6 + 4)
+    static_assert((NPL * 4 * XSLOTS) % 4 == 0 && (NPL * 4 * YSLOTS) % 4 == 0, "equal DMA count per wave");
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const DView& xv = lat_tile ? a.xlat : a.x;
 
-    f32x16_t acc[MT][3], accb[MT];
+    f32x16_t acc[9], accb;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int i = 0; i < 16; ++i) accb[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) accb[m][i] = 0.f;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][d][i] = 0.f;
-    }
-    const bool do_bias = (group == 0) && a.db;                   // uniform: the first group's workgroups also reduce dY itself
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const bool do_bias = (cit == 0) && a.db;                     // uniform: the first input tile's workgroups also reduce dY itself
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
 
     // this lane's source address inside a fragment's 16-lane group (see frag_tr)
     const int li = lane & 15, grp16 = lane >> 4;
     const int rb2 = (grp16 & 1) * 2 + ((li & 3) >> 1);           // channel group (of the 32-channel tile's 4) this lane points into
     const int kb = (grp16 >> 1) * 8 + (li >> 2);                 // pixel inside the 16-pixel K step
-    const int lane_off = (li & 1) * 8;                           // low / high 4 channels of the 16-byte vector
-    const unsigned char* const xs = smem + rb2 * XPP * 16 + kb * 16 + lane_off;
-    const unsigned char* const ys = smem + X_BYTES + rb2 * YPP * 16 + kb * 16 + lane_off;
-    constexpr int XLO = 4 * XPP * 16, YLO = MT * 4 * YPP * 16;   // hi plane set -> lo plane set
+    const int frag_off = kb * 16 + (li & 1) * 8;                 // + low / high 4 channels of the 16-byte vector
+    const int xs_off = rb2 * XP * 16 + frag_off;
+    const int ys_off = NPL * WG_X_BYTES + rb2 * YPP * 16 + frag_off;
 
-    for (int tile = slice; tile < ntiles; tile += a.nslices) {
+    // All DMA of one tile: every wave issues exactly NX + NY instructions (flat slot index s = wave, wave+4, ...), so that the
+    // consumer can wait with a constant vmcnt while the next tile's copies stay in flight.
+    auto issue_tile = [&](int tile, unsigned st) {
         const int tx = tile % a.tiles_x;
         const int r1 = tile / a.tiles_x;
         const int ty = r1 % a.tiles_y;
         const int b = r1 / a.tiles_y;
         const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-        // ---- stage X: rows y0+dyk .. (padded coords), cols x0 .. x0+TW+1 ; NPL x 4 group planes
-        for (int s = wave; s < 4 * NPL * XSLOTS; s += 4) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int s = wave + 4 * j;
             const int pl = s / XSLOTS, sl = s % XSLOTS;           // plane = (hi|lo)*4 + group
             const int islo = pl / 4, g = pl % 4;
             const int p = sl * 64 + lane;
-            if (p < XP) {
-                const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
-                const int Yp = y0 + rr + dyk, Xp = x0 + cc;       // padded output-resolution coords of the tap source
-                const bool inb = (Yp < a.H + 2) && (Xp < a.W + 2);
-                int sy = Yp, sx = Xp;
-                if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
-                else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-                const DView& v = lat_tile ? a.xlat : a.x;
-                const int cg = lat_tile ? g : cit * 4 + g;
-                const bool have = cg < v.ncg;
-                const uint4* base = (islo ? v.lo : v.hi) + b * v.bs + (have ? cg : 0) * v.cs;
-                glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), lds0 + pl * XPP * 16 + sl * 1024);
-            }
+            const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
+            const int Yp = y0 + rr, Xp = x0 + cc;                 // padded output-resolution coords of the haloed tile
+            const bool inb = (p < XP) && (Yp < a.H + 2) && (Xp < a.W + 2);
+            int sy = Yp, sx = Xp;
+            if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
+            else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
+            const int cg = lat_tile ? g : cit * 4 + g;
+            const bool have = cg < xv.ncg;
+            const uint4* base = (islo ? xv.lo : xv.hi) + b * xv.bs + (have ? cg : 0) * xv.cs;
+            // lanes past the plane (last slot) re-read the zero border vector into the 4-pixel plane padding / next plane's start:
+            // keep them inside the plane by clamping the destination lane instead
+            if (p < XP) glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), st + pl * XP * 16 + sl * 1024);
+            else asm volatile("s_nop 0" ::: "memory");
         }
-        // ---- stage dY: rows y0.., cols x0.. ; NPL x MT*4 group planes
-        for (int s = wave; s < MT * 4 * NPL * YSLOTS; s += 4) {
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int s = wave + 4 * j;
             const int pl = s / YSLOTS, sl = s % YSLOTS;
-            const int islo = pl / (MT * 4), g = pl % (MT * 4);
+            const int islo = pl / 4, g = cot * 4 + pl % 4;
             const int p = sl * 64 + lane;
             const int rr = p / WG_TW, cc = p - rr * WG_TW;
             const int Y = y0 + rr, X = x0 + cc;
-            const bool inb = (Y < a.H) && (X < a.W) && (g < a.dy.ncg);
-            const uint4* base = (islo ? a.dy.lo : a.dy.hi) + b * a.dy.bs + (g < a.dy.ncg ? g : 0) * a.dy.cs;
-            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), lds0 + X_BYTES + pl * YPP * 16 + sl * 1024);
+            const bool have = g < a.dy.ncg;
+            const bool inb = (Y < a.H) && (X < a.W) && have;
+            const uint4* base = (islo ? a.dy.lo : a.dy.hi) + b * a.dy.bs + (have ? g : 0) * a.dy.cs;
+            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), st + NPL * WG_X_BYTES + pl * YPP * 16 + sl * 1024);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    int tile = slice;
+    int cur = 0;
+    if (tile < ntiles) issue_tile(tile, lds0);
+    for (; tile < ntiles; tile += a.nslices) {
+        const int nxt = tile + a.nslices;
+        if (nxt < ntiles) {
+            issue_tile(nxt, lds0 + (cur ^ 1) * STAGE);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NY) : "memory");     // everything but the copies just issued
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
+        const unsigned char* const sx = smem + cur * STAGE + xs_off;
+        const unsigned char* const sy = smem + cur * STAGE + ys_off;
         // ---- MFMAs: wave handles rows wave, wave+4; a row of 32 pixels = two K steps of 16
 #pragma unroll
         for (int rq = 0; rq < WG_TH / 4; ++rq) {
             const int rr = wave + rq * 4;
 #pragma unroll
             for (int ks = 0; ks < WG_TW / 16; ++ks) {
-                uint4 fa[MT][NPL], fb[3][NPL];
+                uint4 fa[NPL];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
+                if (do_bias) {                                    // dY x ones: every column of the tile holds sum_k dY[row][k]
+                    accb = mfma_bf16(fa[0], ones, accb);
+                    if (NPL == 2) accb = mfma_bf16(fa[NPL - 1], ones, accb);
+                }
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fa[m][pl] = frag_tr(ys + pl * YLO + (m * 4 * YPP + rr * WG_TW + ks * 16) * 16);
+                for (int t = 0; t < 9; ++t) {
+                    uint4 fb[NPL];
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fb[d][pl] = frag_tr(xs + pl * XLO + (rr * (WG_TW + 2) + ks * 16 + d) * 16);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        if (NPL == 2) {
-                            acc[m][d] = mfma_bf16(fa[m][1], fb[d][0], acc[m][d]);
-                            acc[m][d] = mfma_bf16(fa[m][0], fb[d][NPL - 1], acc[m][d]);
-                        }
-                        acc[m][d] = mfma_bf16(fa[m][0], fb[d][0], acc[m][d]);
+                    for (int pl = 0; pl < NPL; ++pl)
+                        fb[pl] = frag_tr(sx + pl * WG_X_BYTES + ((rr + t / 3) * (WG_TW + 2) + ks * 16 + t % 3) * 16);
+                    if (NPL == 2) {
+                        acc[t] = mfma_bf16(fa[1], fb[0], acc[t]);
+                        acc[t] = mfma_bf16(fa[0], fb[NPL - 1], acc[t]);
                     }
-                    if (do_bias) {                                // dY x ones: every column of the tile holds sum_k dY[row][k]
-                        accb[m] = mfma_bf16(fa[m][0], ones, accb[m]);
-                        if (NPL == 2) accb[m] = mfma_bf16(fa[m][1], ones, accb[m]);
-                    }
+                    acc[t] = mfma_bf16(fa[0], fb[0], acc[t]);
                 }
             }
         }
         __syncthreads();
+        cur ^= 1;
     }
-    // ---- reduce the 4 waves through LDS, then one atomic per output element
-    float* red = (float*)smem;                                   // [wave][MT*3*16][64]
+    // ---- reduce the 4 waves through LDS (two passes of at most 5 taps: 4 x 5 x 4 KiB = 80 KiB), partial sums to the workspace
+    float* const red = (float*)smem;                             // [wave][tap in pass][16][64]
+    float* const wsp = a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int t0 = pass * 5, nt = pass == 0 ? 5 : 4;
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+        for (int t = 0; t < 5; ++t)
+            if (t < nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[((wave * MT * 3 + m * 3 + d) * 16 + i) * 64 + lane] = acc[m][d][i];
-    float* bred = red + 4 * MT * 3 * 16 * 64;                    // [wave][MT][16][64]
-    if (do_bias) {
+                for (int i = 0; i < 16; ++i) red[((wave * 5 + t) * 16 + i) * 64 + lane] = acc[t0 + t][i];
+        if (pass == 1 && do_bias)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bred[((wave * MT + m) * 16 + i) * 64 + lane] = accb[m][i];
-    }
-    __syncthreads();
-    // the workgroup's partial sums go to the workspace in raw accumulator order (coalesced); wgrad_reduce_kernel folds the
-    // slices and scatters into dW (float atomics from ~10^3 workgroups onto ~10^4 addresses measured 5x slower than the MFMAs)
-    float* const wsp = a.ws + ((size_t)group * a.nslices + slice) * (MT * 3 * 1024);
-    for (int e = tid; e < MT * 3 * 16 * 64; e += 256) {
-        float v = 0.f;
-#pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * MT * 3 * 16 * 64 + e];
-        wsp[e] = v;
-    }
-    if (do_bias) {
-        // column 0 of each D tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
-        float* const wsb = a.ws + (size_t)a.ngroups * a.nslices * (MT * 3 * 1024) + (size_t)slice * (MT * 32);
-        for (int e = tid; e < MT * 32; e += 256) {
-            const int m = e >> 5, row = e & 31;
-            const int i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
+            for (int i = 0; i < 16; ++i) red[((wave * 5 + 4) * 16 + i) * 64 + lane] = accb[i];
+        __syncthreads();
+        for (int e = tid; e < nt * 1024; e += 256) {
             float v = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += bred[((w4 * MT + m) * 16 + i) * 64 + ln];
-            wsb[e] = v;
+            for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * 5 * 1024 + e];
+            wsp[t0 * 1024 + e] = v;
         }
+        if (pass == 1 && do_bias && tid < 32) {
+            // column 0 of the dY x ones tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
+            const int row = tid, i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += red[((w4 * 5 + 4) * 16 + i) * 64 + ln];
+            a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = v;
+        }
+        __syncthreads();
     }
 }
 
-// dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus MT*32 threads for the bias
-__global__ void wgrad_reduce_kernel(const WgradArgs a, int mt) {
-    const int per = mt * 3 * 1024;
+// dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
+__global__ void wgrad_reduce_kernel(const WgradArgs a) {
+    const int per = 9 * 1024;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nmain = (long long)a.ngroups * per;
     if (idx < nmain) {
@@ -395,27 +400,26 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a, int mt) {
         const float* p = a.ws + (size_t)group * a.nslices * per + e;
         float v = 0.f;
         for (int s = 0; s < a.nslices; ++s) v += p[(size_t)s * per];
-        const int cit = group / 3, dyk = group % 3;
+        const int cit = group / a.mt, cot = group % a.mt;
         const bool lat_tile = cit >= a.ncit_main;
-        const int ln = e & 63, i = (e >> 6) & 15, md = e >> 10;
-        const int m = md / 3, d = md % 3;
-        const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);       // D row
+        const int ln = e & 63, i = (e >> 6) & 15, t = e >> 10;
+        const int co = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);     // D row
         const int c = ln & 31;                                                  // D col = channel inside the tile
         int ci = -1;
         if (lat_tile) { if (c < a.lat) ci = c; }
         else if (cit * 32 + c < a.cin_main) ci = a.lat + cit * 32 + c;
-        if (co < a.cout && ci >= 0) a.dw[((long long)co * a.cin_total + ci) * 9 + dyk * 3 + d] += a.alpha * v;
-    } else if (a.db && idx < nmain + mt * 32) {
-        const int e = (int)(idx - nmain);
-        const float* p = a.ws + (size_t)nmain * a.nslices + e;
+        if (co < a.cout && ci >= 0) a.dw[((long long)co * a.cin_total + ci) * 9 + t] += a.alpha * v;
+    } else if (a.db && idx < nmain + a.mt * 32) {
+        const int e = (int)(idx - nmain);                                       // output channel
+        const float* p = a.ws + (size_t)nmain * a.nslices + (size_t)(e >> 5) * a.nslices * 32 + (e & 31);
         float v = 0.f;
-        for (int s = 0; s < a.nslices; ++s) v += p[(size_t)s * (mt * 32)];
+        for (int s = 0; s < a.nslices; ++s) v += p[(size_t)s * 32];
         if (e < a.cout) a.db[e] += a.alpha * v;
     }
 }
 
 // grid decomposition shared by the workspace query and the launch
-struct WgradPlan { int tiles_x, tiles_y, ncit_main, ngroups, nslices, mt; };
+struct WgradPlan { int tiles_x, tiles_y, ncit_main, ncit, ngroups, nslices, mt; };
 static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
     WgradPlan p;
     p.mt = (d->cout + 31) / 32;
@@ -423,9 +427,10 @@ static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
     p.tiles_y = (d->H + WG_TH - 1) / WG_TH;
     p.ncit_main = (d->cin_main + 31) / 32;
     const int lat = d->xlat.hi ? d->lat : 0;
-    p.ngroups = (p.ncit_main + (lat ? 1 : 0)) * 3;
+    p.ncit = p.ncit_main + (lat ? 1 : 0);
+    p.ngroups = p.ncit * p.mt;
     const int ntiles = p.tiles_x * p.tiles_y * d->B;
-    int ns = (768 + p.ngroups - 1) / p.ngroups;      // ~3 workgroups per CU in total
+    int ns = (512 + p.ngroups - 1) / p.ngroups;      // ~2 workgroups per CU in total (one resident at a time)
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     p.nslices = ns;
@@ -435,9 +440,9 @@ static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
 }  // namespace
 
 extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
-    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0 || d->cout > 64) return ESR_E_ARG;
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
     const WgradPlan p = wgrad_plan(d);
-    return (int64_t)p.ngroups * p.nslices * (p.mt * 3 * 1024) + (int64_t)p.nslices * (p.mt * 32);
+    return (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
 }
 
 extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
@@ -445,10 +450,9 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const int ups = d->upsample <= 0 ? 1 : d->upsample;
     if (d->x.H * ups != d->H || d->x.W * ups != d->W || d->dy.H != d->H || d->dy.W != d->W) return ESR_E_ARG;
     if (d->xlat.hi && (ups != 1 || d->xlat.H != d->H || d->xlat.W != d->W || d->lat <= 0 || d->lat > 8)) return ESR_E_ARG;
-    const int mt = (d->cout + 31) / 32;
-    if (mt > 2) return ESR_E_UNSUPPORTED;
     const bool split = d->dy.lo != nullptr;
     if ((d->x.lo != nullptr) != split) return ESR_E_ARG;
+    if (d->xlat.hi && ((d->xlat.lo != nullptr) != split)) return ESR_E_ARG;
     if (!d->workspace || d->workspace_floats < esr_conv3x3_wgrad_workspace_floats(d)) return ESR_E_ARG;
     const WgradPlan p = wgrad_plan(d);
     WgradArgs a{};
@@ -465,6 +469,8 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
     a.ncit_main = p.ncit_main;
+    a.ncit = p.ncit;
+    a.mt = p.mt;
     a.ngroups = p.ngroups;
     a.nslices = p.nslices;
     a.alpha = d->alpha;
@@ -472,17 +478,16 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     a.db = d->db;
     a.ws = d->workspace;
     const int npl = split ? 2 : 1;
-    const size_t stage = (size_t)4 * npl * XPP * 16 + (size_t)mt * 4 * npl * YPP * 16;
-    const size_t red = (size_t)4 * mt * 3 * 16 * 64 * 4 + (size_t)4 * mt * 16 * 64 * 4;
-    const size_t lds = stage > red ? stage : red;
-    void (*k)(const WgradArgs) = split ? (mt == 1 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<2, 2>)
-                                       : (mt == 1 ? conv3x3_wgrad_kernel<1, 1> : conv3x3_wgrad_kernel<2, 1>);
+    const size_t stage2 = (size_t)2 * npl * (WG_X_BYTES + WG_Y_BYTES);
+    const size_t red = (size_t)4 * 5 * 1024 * 4;
+    const size_t lds = stage2 > red ? stage2 : red;
+    void (*k)(const WgradArgs) = split ? conv3x3_wgrad_kernel<2> : conv3x3_wgrad_kernel<1>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), lds, (hipStream_t)stream, a);
     ESR_CHECK_LAUNCH();
-    const long long nred = (long long)p.ngroups * mt * 3 * 1024 + mt * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, mt);
+    const long long nred = (long long)p.ngroups * 9 * 1024 + p.mt * 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
