@@ -8,6 +8,7 @@
 //   ReplicationPad2d            codes/CEM/CEMnet.py:70-71,286-295                           -> fold the pad ring into the edge pixels
 //   bilinear /sf of the latent  codes/models/modules/architecture.py:284                    -> spread each LR gradient over its taps
 #include "esr_common.h"
+#include <vector>
 
 namespace {
 
@@ -238,17 +239,14 @@ __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c) {
 }
 
 template <int NPL>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = blockIdx.x / a.nslices, slice = blockIdx.x % a.nslices;
     const int cit = group / a.mt, cot = group % a.mt;            // input-channel tile, output-channel tile
     const bool lat_tile = cit >= a.ncit_main;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     constexpr int STAGE = NPL * (WG_X_BYTES + WG_Y_BYTES);       // [X hi | X lo | dY hi | dY lo], 4 group planes each
-    constexpr int NX = NPL * 4 * XSLOTS / 4, NY = NPL * 4 * YSLOTS / 4;   // DMA instructions per wave per tile: 12 + 8 (6 + 4)
-    static_assert((NPL * 4 * XSLOTS) % 4 == 0 && (NPL * 4 * YSLOTS) % 4 == 0, "equal DMA count per wave");
+    constexpr int NX = NPL * XSLOTS, NY = NPL * YSLOTS;          // DMA instructions per wave per tile: 12 + 8 (6 + 4 without lo)
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const DView& xv = lat_tile ? a.xlat : a.x;
 
@@ -270,56 +268,56 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
     const int xs_off = rb2 * XP * 16 + frag_off;
     const int ys_off = NPL * WG_X_BYTES + rb2 * YPP * 16 + frag_off;
 
-    // All DMA of one tile: every wave issues exactly NX + NY instructions (flat slot index s = wave, wave+4, ...), so that the
-    // consumer can wait with a constant vmcnt while the next tile's copies stay in flight.
-    auto issue_tile = [&](int tile, unsigned st) {
-        const int tx = tile % a.tiles_x;
-        const int r1 = tile / a.tiles_x;
-        const int ty = r1 % a.tiles_y;
-        const int b = r1 / a.tiles_y;
-        const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int s = wave + 4 * j;
-            const int pl = s / XSLOTS, sl = s % XSLOTS;           // plane = (hi|lo)*4 + group
-            const int islo = pl / 4, g = pl % 4;
-            const int p = sl * 64 + lane;
-            const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
-            const int Yp = y0 + rr, Xp = x0 + cc;                 // padded output-resolution coords of the haloed tile
-            const bool inb = (p < XP) && (Yp < a.H + 2) && (Xp < a.W + 2);
-            int sy = Yp, sx = Xp;
-            if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
-            else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-            const int cg = lat_tile ? g : cit * 4 + g;
-            const bool have = cg < xv.ncg;
-            const uint4* base = (islo ? xv.lo : xv.hi) + b * xv.bs + (have ? cg : 0) * xv.cs;
-            // lanes past the plane (last slot) re-read the zero border vector into the 4-pixel plane padding / next plane's start:
-            // keep them inside the plane by clamping the destination lane instead
-            if (p < XP) glds16w(base + ((inb && have) ? sy * a.Wx_p + sx : 0), st + pl * XP * 16 + sl * 1024);
-            else asm volatile("s_nop 0" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < NY; ++j) {
-            const int s = wave + 4 * j;
-            const int pl = s / YSLOTS, sl = s % YSLOTS;
-            const int islo = pl / 4, g = cot * 4 + pl % 4;
-            const int p = sl * 64 + lane;
-            const int rr = p / WG_TW, cc = p - rr * WG_TW;
-            const int Y = y0 + rr, X = x0 + cc;
-            const bool have = g < a.dy.ncg;
-            const bool inb = (Y < a.H) && (X < a.W) && have;
-            const uint4* base = (islo ? a.dy.lo : a.dy.hi) + b * a.dy.bs + (have ? g : 0) * a.dy.cs;
-            glds16w(base + (inb ? (Y + 1) * (a.W + 2) + (X + 1) : 0), st + NPL * WG_X_BYTES + pl * YPP * 16 + sl * 1024);
-        }
-    };
+    // All DMA of one tile.  Wave w copies channel group w of both operands (hi and lo planes): 6 + 4 slots of 64 pixel vectors per
+    // plane, i.e. exactly NX + NY instructions per wave, so that the consumer can wait with a constant vmcnt while the next tile's
+    // copies stay in flight.  The per-lane source offsets are computed once per slot and shared by the hi and lo planes.
+    static_assert(NX == NPL * XSLOTS && NY == NPL * YSLOTS, "one channel group per wave");
+    const int xcg = lat_tile ? wave : cit * 4 + wave;            // this wave's x group (may not exist: zero weights, read group 0's border)
+    const bool xhave = xcg < xv.ncg;
+    const int ycg = cot * 4 + wave;
+    const bool yhave = ycg < a.dy.ncg;
+#define ESR_WG_ISSUE(TILE, ST)                                                                                                   \
+    do {                                                                                                                         \
+        const int tx_ = (TILE) % a.tiles_x;                                                                                      \
+        const int r1_ = (TILE) / a.tiles_x;                                                                                      \
+        const int ty_ = r1_ % a.tiles_y;                                                                                         \
+        const int b_ = r1_ / a.tiles_y;                                                                                          \
+        const int x0_ = tx_ * WG_TW, y0_ = ty_ * WG_TH;                                                                          \
+        const uint4* const xh_ = xv.hi + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs;                                                 \
+        const uint4* const xl_ = NPL == 2 ? xv.lo + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs : nullptr;                            \
+        const unsigned xd_ = (ST) + wave * XP * 16;                                                                              \
+        _Pragma("unroll") for (int sl = 0; sl < XSLOTS; ++sl) {                                                                  \
+            const int p = sl * 64 + lane;                                                                                        \
+            const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);                                                           \
+            const int Yp = y0_ + rr, Xp = x0_ + cc;                 /* padded output-resolution coords of the haloed tile */     \
+            int sy = Yp, sx = Xp;                                                                                                \
+            if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }                                                          \
+            else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }                                \
+            const int off = (xhave && Yp < a.H + 2 && Xp < a.W + 2) ? sy * a.Wx_p + sx : 0;   /* 0: the zero border vector */    \
+            if (sl < XSLOTS - 1 || p < XP) {                                                                                     \
+                glds16w(xh_ + off, xd_ + sl * 1024);                                                                             \
+                if (NPL == 2) glds16w(xl_ + off, xd_ + WG_X_BYTES + sl * 1024);                                                  \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        const uint4* const yh_ = a.dy.hi + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs;                                           \
+        const uint4* const yl_ = NPL == 2 ? a.dy.lo + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs : nullptr;                      \
+        const unsigned yd_ = (ST) + NPL * WG_X_BYTES + wave * YPP * 16;                                                          \
+        _Pragma("unroll") for (int sl = 0; sl < YSLOTS; ++sl) {                                                                  \
+            const int p = sl * 64 + lane;                                                                                        \
+            const int Y = y0_ + (p >> 5), X = x0_ + (p & 31);                                                                    \
+            const int off = (yhave && Y < a.H && X < a.W) ? (Y + 1) * (a.W + 2) + (X + 1) : 0;                                   \
+            glds16w(yh_ + off, yd_ + sl * 1024);                                                                                 \
+            if (NPL == 2) glds16w(yl_ + off, yd_ + WG_Y_BYTES + sl * 1024);                                                      \
+        }                                                                                                                        \
+    } while (0)
 
     int tile = slice;
     int cur = 0;
-    if (tile < ntiles) issue_tile(tile, lds0);
+    if (tile < ntiles) ESR_WG_ISSUE(tile, lds0);
     for (; tile < ntiles; tile += a.nslices) {
         const int nxt = tile + a.nslices;
         if (nxt < ntiles) {
-            issue_tile(nxt, lds0 + (cur ^ 1) * STAGE);
+            ESR_WG_ISSUE(nxt, lds0 + (cur ^ 1) * STAGE);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NY) : "memory");     // everything but the copies just issued
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -357,9 +355,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
         __syncthreads();
         cur ^= 1;
     }
-    // ---- reduce the 4 waves through LDS (two passes of at most 5 taps: 4 x 5 x 4 KiB = 80 KiB), partial sums to the workspace
+    // ---- reduce the 4 waves through LDS (two passes of at most 5 taps: 4 x 5 x 4 KiB = 80 KiB).  A workgroup that owns its
+    // (input tile, output tile) alone (nslices == 1) adds straight into dW / db; otherwise its partial sums go to the workspace.
     float* const red = (float*)smem;                             // [wave][tap in pass][16][64]
-    float* const wsp = a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
+    const bool direct = a.nslices == 1;
+    float* const wsp = direct ? nullptr : a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int t0 = pass * 5, nt = pass == 0 ? 5 : 4;
@@ -376,7 +376,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
             float v = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * 5 * 1024 + e];
-            wsp[t0 * 1024 + e] = v;
+            if (direct) {
+                const int ln = e & 63, i = (e >> 6) & 15, t = t0 + (e >> 10);
+                const int co = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);     // D row
+                const int c = ln & 31;                                                  // D col = channel inside the tile
+                int ci = -1;
+                if (lat_tile) { if (c < a.lat) ci = c; }
+                else if (cit * 32 + c < a.cin_main) ci = a.lat + cit * 32 + c;
+                if (co < a.cout && ci >= 0) a.dw[((long long)co * a.cin_total + ci) * 9 + t] += a.alpha * v;
+            } else {
+                wsp[t0 * 1024 + e] = v;
+            }
         }
         if (pass == 1 && do_bias && tid < 32) {
             // column 0 of the dY x ones tile (lanes 0 and 32): row (i&3) + 8*(i>>2) + 4*(lane>>5)
@@ -384,16 +394,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a
             float v = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) v += red[((w4 * 5 + 4) * 16 + i) * 64 + ln];
-            a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = v;
+            if (direct) { if (cot * 32 + row < a.cout) a.db[cot * 32 + row] += a.alpha * v; }
+            else a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = v;
         }
         __syncthreads();
     }
 }
 
+#undef ESR_WG_ISSUE
+
+template <int NPL>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    wgrad_body<NPL>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
+}
+
+// Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
+// slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
+// splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
+template <int NPL>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int4 m = map[blockIdx.x];
+    const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
+    const WgradArgs a = table[e];
+    wgrad_body<NPL>(a, group, slice, smem);
+}
+
 // dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
-__global__ void wgrad_reduce_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& a, const long long idx) {
     const int per = 9 * 1024;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nmain = (long long)a.ngroups * per;
     if (idx < nmain) {
         const int group = (int)(idx / per), e = (int)(idx % per);
@@ -417,10 +447,16 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a) {
         if (e < a.cout) a.db[e] += a.alpha * v;
     }
 }
+__global__ void wgrad_reduce_kernel(const WgradArgs a) { wgrad_reduce_body(a, (long long)blockIdx.x * blockDim.x + threadIdx.x); }
+// blockIdx.y = table entry (entries that wrote straight into dW have nslices == 1 and nothing to fold)
+__global__ void wgrad_reduce_batch_kernel(const WgradArgs* __restrict__ table) {
+    const WgradArgs a = table[blockIdx.y];
+    if (a.nslices > 1) wgrad_reduce_body(a, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // grid decomposition shared by the workspace query and the launch
 struct WgradPlan { int tiles_x, tiles_y, ncit_main, ncit, ngroups, nslices, mt; };
-static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
+static WgradPlan wgrad_plan(const esr_wgrad_desc* d, int target_wgs = 512) {
     WgradPlan p;
     p.mt = (d->cout + 31) / 32;
     p.tiles_x = (d->W + WG_TW - 1) / WG_TW;
@@ -430,22 +466,14 @@ static WgradPlan wgrad_plan(const esr_wgrad_desc* d) {
     p.ncit = p.ncit_main + (lat ? 1 : 0);
     p.ngroups = p.ncit * p.mt;
     const int ntiles = p.tiles_x * p.tiles_y * d->B;
-    int ns = (512 + p.ngroups - 1) / p.ngroups;      // ~2 workgroups per CU in total (one resident at a time)
+    int ns = (target_wgs + p.ngroups - 1) / p.ngroups;   // single launch: ~2 workgroups per CU in total (one resident at a time)
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     p.nslices = ns;
     return p;
 }
 
-}  // namespace
-
-extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
-    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
-    const WgradPlan p = wgrad_plan(d);
-    return (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
-}
-
-extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
+static int wgrad_validate(const esr_wgrad_desc* d) {
     if (!d || !d->dy.hi || !d->x.hi || !d->dw || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
     const int ups = d->upsample <= 0 ? 1 : d->upsample;
     if (d->x.H * ups != d->H || d->x.W * ups != d->W || d->dy.H != d->H || d->dy.W != d->W) return ESR_E_ARG;
@@ -453,14 +481,16 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const bool split = d->dy.lo != nullptr;
     if ((d->x.lo != nullptr) != split) return ESR_E_ARG;
     if (d->xlat.hi && ((d->xlat.lo != nullptr) != split)) return ESR_E_ARG;
-    if (!d->workspace || d->workspace_floats < esr_conv3x3_wgrad_workspace_floats(d)) return ESR_E_ARG;
-    const WgradPlan p = wgrad_plan(d);
+    return ESR_OK;
+}
+
+static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* ws) {
     WgradArgs a{};
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
     a.xlat = to_dview(d->xlat);
     a.lat = d->xlat.hi ? d->lat : 0;
-    a.ups = ups;
+    a.ups = d->upsample <= 0 ? 1 : d->upsample;
     a.cout = d->cout;
     a.cin_main = d->cin_main;
     a.cin_total = d->cin_main + a.lat;
@@ -476,18 +506,116 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     a.alpha = d->alpha;
     a.dw = d->dw;
     a.db = d->db;
-    a.ws = d->workspace;
-    const int npl = split ? 2 : 1;
-    const size_t stage2 = (size_t)2 * npl * (WG_X_BYTES + WG_Y_BYTES);
-    const size_t red = (size_t)4 * 5 * 1024 * 4;
-    const size_t lds = stage2 > red ? stage2 : red;
+    a.ws = ws;
+    return a;
+}
+
+static inline int p_groups(const esr_wgrad_desc& d) { return wgrad_plan(&d, 1).ngroups; }
+
+static inline int64_t wgrad_partial_floats(const WgradPlan& p) {
+    return p.nslices == 1 ? 0 : (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
+}
+
+static size_t wgrad_lds(int npl) {
+    const size_t stage2 = (size_t)2 * npl * (WG_X_BYTES + WG_Y_BYTES), red = (size_t)4 * 5 * 1024 * 4;
+    return stage2 > red ? stage2 : red;
+}
+
+// batch layout inside the caller's workspace: [WgradArgs table][int4 workgroup map][fp32 partial sums]
+struct BatchPlan { int target; int64_t nwg, table_bytes, map_bytes, partial_floats; };
+static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
+    BatchPlan b{};
+    int64_t groups = 0;
+    for (int i = 0; i < n; ++i) groups += wgrad_plan(&descs[i], 1).ngroups;
+    // enough workgroups for two waves over the chip; beyond that the pixel sum is not split at all
+    b.target = groups >= 512 ? 1 : 512;
+    for (int i = 0; i < n; ++i) {
+        const WgradPlan p = wgrad_plan(&descs[i], b.target == 1 ? 1 : (int)((512 * (int64_t)p_groups(descs[i]) + groups - 1) / groups));
+        b.nwg += (int64_t)p.ngroups * p.nslices;
+        b.partial_floats += wgrad_partial_floats(p);
+    }
+    b.table_bytes = (((int64_t)n * sizeof(WgradArgs)) + 255) / 256 * 256;
+    b.map_bytes = ((b.nwg * (int64_t)sizeof(int4)) + 255) / 256 * 256;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
+    const int64_t n = wgrad_partial_floats(wgrad_plan(d));
+    return n > 0 ? n : 1;
+}
+
+extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
+    const int rc = wgrad_validate(d);
+    if (rc != ESR_OK) return rc;
+    if (!d->workspace || d->workspace_floats < esr_conv3x3_wgrad_workspace_floats(d)) return ESR_E_ARG;
+    const WgradPlan p = wgrad_plan(d);
+    const WgradArgs a = wgrad_args(d, p, d->workspace);
+    const bool split = d->dy.lo != nullptr;
     void (*k)(const WgradArgs) = split ? conv3x3_wgrad_kernel<2> : conv3x3_wgrad_kernel<1>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1), (hipStream_t)stream, a);
     ESR_CHECK_LAUNCH();
-    const long long nred = (long long)p.ngroups * 9 * 1024 + p.mt * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (p.nslices > 1) {
+        const long long nred = (long long)p.ngroups * 9 * 1024 + p.mt * 32;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+        ESR_CHECK_LAUNCH();
+    }
+    return ESR_OK;
+}
+
+extern "C" int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc* descs, int n) {
+    if (!descs || n <= 0) return ESR_E_ARG;
+    for (int i = 0; i < n; ++i)
+        if (descs[i].B <= 0 || descs[i].H <= 0 || descs[i].W <= 0 || descs[i].cout <= 0 || descs[i].cin_main <= 0) return ESR_E_ARG;
+    const BatchPlan b = batch_plan(descs, n);
+    return b.table_bytes + b.map_bytes + (b.partial_floats + 1) * 4;
+}
+
+extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
+    if (!descs || n <= 0 || !workspace) return ESR_E_ARG;
+    const bool split = descs[0].dy.lo != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const int rc = wgrad_validate(&descs[i]);
+        if (rc != ESR_OK) return rc;
+        if ((descs[i].dy.lo != nullptr) != split) return ESR_E_ARG;      // one operand format per batch
+    }
+    if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
+    const BatchPlan b = batch_plan(descs, n);
+    int64_t groups = 0;
+    for (int i = 0; i < n; ++i) groups += p_groups(descs[i]);
+    std::vector<WgradArgs> table(n);
+    std::vector<int4> map((size_t)b.nwg);
+    float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
+    int64_t w = 0, pf = 0;
+    int max_red = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradPlan p = wgrad_plan(&descs[i], b.target == 1 ? 1 : (int)((512 * (int64_t)p_groups(descs[i]) + groups - 1) / groups));
+        table[i] = wgrad_args(&descs[i], p, partials + pf);
+        pf += wgrad_partial_floats(p);
+        // slice-major inside a layer so that co-running workgroups of one layer read different images
+        for (int sl = 0; sl < p.nslices; ++sl)
+            for (int g = 0; g < p.ngroups; ++g) map[(size_t)w++] = make_int4(i, g, sl, 0);
+        if (p.nslices > 1 && p.ngroups * 9 * 1024 + p.mt * 32 > max_red) max_red = p.ngroups * 9 * 1024 + p.mt * 32;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // pageable host memory: the runtime stages it before returning, the vectors may go out of scope
+    if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(WgradArgs), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
+    if (hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), (size_t)b.nwg * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
+        return ESR_E_LAUNCH;
+    void (*k)(const WgradArgs*, const int4*) = split ? conv3x3_wgrad_batch_kernel<2> : conv3x3_wgrad_batch_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1), s, (const WgradArgs*)workspace,
+                       (const int4*)((char*)workspace + b.table_bytes));
     ESR_CHECK_LAUNCH();
+    if (max_red > 0) {
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((max_red + 255) / 256), (unsigned)n), dim3(256), 0, s,
+                           (const WgradArgs*)workspace);
+        ESR_CHECK_LAUNCH();
+    }
     return ESR_OK;
 }

@@ -51,6 +51,8 @@ _SIGS = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'esr_conv3x3_wgrad': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'esr_conv3x3_wgrad_workspace_floats': (C.c_int64, [C.POINTER(WgradDesc)]),
+    'esr_conv3x3_wgrad_batch_workspace_bytes': (C.c_int64, [C.POINTER(WgradDesc), C.c_int]),
+    'esr_conv3x3_wgrad_batch': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

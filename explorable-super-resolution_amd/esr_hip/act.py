@@ -214,8 +214,8 @@ def conv3x3_dgrad_nchw(dy, weight, split=True):
     return dx
 
 
-def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
-    """Weight + bias gradient of one conv layer from act-layout operands (esr_conv3x3_wgrad): returns (dW [cout][cin][3][3], db [cout])."""
+def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
+    """esr_wgrad_desc for one conv layer plus its freshly zeroed outputs: returns (desc, dW [cout][cin][3][3], db [cout])."""
     cout, cin = wshape[0], wshape[1]
     dw = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=device)
     db = torch.zeros(cout, dtype=torch.float32, device=device)
@@ -228,12 +228,30 @@ def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, devi
     d.B, d.H, d.W = B, H, W
     d.alpha = alpha
     d.dw, d.db = dw.data_ptr(), db.data_ptr()
+    return d, dw, db
+
+
+def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
+    """Weight + bias gradient of one conv layer from act-layout operands (esr_conv3x3_wgrad): returns (dW [cout][cin][3][3], db [cout])."""
+    d, dw, db = wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device)
     need = _lib.lib.esr_conv3x3_wgrad_workspace_floats(C.byref(d))
     check(min(need, 0), 'esr_conv3x3_wgrad_workspace_floats')
     ws = _wgrad_workspace(device, need)
     d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(_lib.lib.esr_conv3x3_wgrad(C.byref(d), stream_ptr()), 'esr_conv3x3_wgrad')
     return dw, db
+
+
+def conv3x3_wgrad_batch(descs, device):
+    """All recorded layers' weight gradients in one launch (esr_conv3x3_wgrad_batch).  The caller keeps every dy / x buffer alive
+    and unmodified until this returns (the launch is enqueued behind the kernels that produced them)."""
+    if not descs:
+        return
+    arr = (_lib.WgradDesc * len(descs))(*descs)
+    need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, len(descs))
+    check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+    ws = _wgrad_workspace(device, (need + 3) // 4)
+    check(_lib.lib.esr_conv3x3_wgrad_batch(arr, len(descs), ws.data_ptr(), ws.numel() * 4, stream_ptr()), 'esr_conv3x3_wgrad_batch')
 
 
 _WS = {}

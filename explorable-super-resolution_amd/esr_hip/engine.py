@@ -256,13 +256,13 @@ class RRDBEngine:
         G_hr0 = A.ActBuf(B, 8, H, W, dev, sp)
         GZ_hr = A.ActBuf(B, 1, H, W, dev, sp) if (has_lat and lat) else None
         GZ_lr = A.ActBuf(B, 1, h, w, dev, sp) if has_lat else None
-        wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W)
+        wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W, keep=(G_g,))
         dgrad('hr1', G_g.view(), G_hr0, 0, 8, H, W, mask=(bufs['hr0'], 0, 8))
         if GZ_hr is not None:
             dgrad_z('hr1', G_g.view(), GZ_hr, H, W, 1.0, first=True)
         G_up = A.ActBuf(B, 8, H, W, dev, sp)
         src_act = bufs['ups'][-1] if self.n_up else bufs['trunk']
-        wg.conv('hr0', G_hr0.view(), src_act.view(), zview('zhr') if lat else None, H, W)
+        wg.conv('hr0', G_hr0.view(), src_act.view(), zview('zhr') if lat else None, H, W, keep=(G_hr0,))
         dgrad('hr0', G_hr0.view(), G_up, 0, 8, H, W, mask=(src_act, 0, 8) if self.n_up else None)
         if GZ_hr is not None:
             dgrad_z('hr0', G_hr0.view(), GZ_hr, H, W, 1.0, first=False)
@@ -276,7 +276,7 @@ class RRDBEngine:
             f = 3 if sf == 3 else 2
             Hj, Wj = s * h, s * w
             below = bufs['ups'][j - 1] if j > 0 else bufs['trunk']
-            wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f)
+            wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f, keep=(cur_g,))
             tmp = A.ActBuf(B, 8, Hj, Wj, dev, sp)
             dgrad('up%d' % j, cur_g.view(), tmp, 0, 8, Hj, Wj)
             s //= f
@@ -291,47 +291,54 @@ class RRDBEngine:
         nrdb = 3 * net.nb
         G_last = A.ActBuf(B, 8, h, w, dev, sp)
         last_act = bufs['last'] if net.nb else bufs['fea']
-        wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w)
+        wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w, keep=(G_trunk,))
         dgrad('lr_conv', G_trunk.view(), G_last, 0, 8, h, w)
         zfirst = True
         if lat:
             dgrad_z('lr_conv', G_trunk.view(), GZ_lr, h, w, 1.0, first=True)
             zfirst = False
         dout = G_last                         # gradient w.r.t. the output of RRDB r (8 groups)
-        GX = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3)] if net.nb else []
+        # RDB gradient buffers [d x(8) | dy conv0(4) | dy conv1(4) | dy conv2(4) | dy conv3(4)]: a rotating set of 3 — unless weight
+        # gradients are wanted: then every RDB gets its own, because its dy slices feed the deferred batched launch
+        GX = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3)] if (net.nb and not need_dw) else []
+        keepalive = []
         for r in reversed(range(net.nb)):
             dout_rrdb = dout
+            G_above = None                    # gradient buffer of RDB k+1 of this RRDB
             for k in reversed(range(3)):
                 X = bufs['rdb'][3 * r + k]
-                G = GX[k]
+                G = A.ActBuf(B, 24, h, w, dev, sp) if need_dw else GX[k]
+                keepalive.append(G)
                 name = 'rrdb%d.rdb%d' % (r, k)
                 scale = 0.2 if k == 2 else 1.0          # d(RDB_k out): RDB3's output enters the RRDB sum scaled by 0.2
-                dy_out = dout_rrdb.view(0, 8) if k == 2 else GX[k + 1].view(0, 8)
+                dy_out = dout_rrdb.view(0, 8) if k == 2 else G_above.view(0, 8)
                 # conv4: y = 0.2*conv(X[0:24]) + x  ->  G[0:24] = 0.2*scale*conv_T(dy_out);  G[0:8] += scale*dy_out;  G[20:24] *= act'
-                wg.conv(name + '.conv4', dy_out, X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * scale)
+                wg.conv(name + '.conv4', dy_out, X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * scale,
+                        keep=(dout_rrdb, G_above, X))
                 dgrad(name + '.conv4', dy_out, G, 0, 24, h, w, alpha=0.2 * scale, extra=dy_out, extra_beta=scale, mask=(X, 20, 24))
                 if lat:
                     dgrad_z(name + '.conv4', dy_out, GZ_lr, h, w, 0.2 * scale, first=zfirst)
                     zfirst = False
                 for i in (3, 2, 1, 0):
                     dy = G.view(8 + 4 * i, 4)            # complete and already multiplied by act'
-                    wg.conv('%s.conv%d' % (name, i), dy, X.view(0, 8 + 4 * i), zview('zlr') if lat else None, h, w)
+                    wg.conv('%s.conv%d' % (name, i), dy, X.view(0, 8 + 4 * i), zview('zlr') if lat else None, h, w, keep=(G, X))
                     last_rdb_conv = (k == 0 and i == 0)
                     dgrad('%s.conv%d' % (name, i), dy, G, 0, 8 + 4 * i, h, w, accumulate=True,
                           extra=dout_rrdb.view(0, 8) if last_rdb_conv else None,      # RRDB skip: d x_rrdb += d out_rrdb
                           mask=(X, 4 + 4 * i, 8 + 4 * i) if i > 0 else None)
                     if lat:
                         dgrad_z('%s.conv%d' % (name, i), dy, GZ_lr, h, w, 1.0, first=False)
-            # GX[0][0:8] now holds d(input of RRDB r) = d(output of RRDB r-1); copy it out of the rotating set
+                G_above = G
+            # G_above[0:8] now holds d(input of RRDB r) = d(output of RRDB r-1); copy it out of the (possibly rotating) set
             nd = A.ActBuf(B, 8, h, w, dev, sp)
-            A.act_combine(nd.view(), B, A_=GX[0].view(0, 8), alpha=1.0)
+            A.act_combine(nd.view(), B, A_=G_above.view(0, 8), alpha=1.0)
             dout = nd
         # d fea = d trunk (shortcut) + d(first RRDB input)
         G_fea = A.ActBuf(B, 8, h, w, dev, sp)
         A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)
         if debug is not None:
             debug['fea'] = G_fea.to_nchw(64)
-        wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w)
+        wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w, keep=(G_fea,))
         dx = None
         if need_dx:
             dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dev)
@@ -349,22 +356,32 @@ class RRDBEngine:
 
 
 class WGrad:
-    """Weight / bias gradient collection (filled by the weight-gradient kernel)."""
+    """Weight / bias gradient collection.  Layers are only RECORDED while the data-gradient pass walks the network; result() runs
+    them all in one batched launch (esr_conv3x3_wgrad_batch), which is why every gradient / activation buffer a record refers to
+    is kept alive here until then."""
 
     def __init__(self, engine, enabled, B):
         self.engine, self.enabled, self.B = engine, enabled, B
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
+        self.descs, self.keep = [], []
 
-    def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1):
+    def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=()):
         if not self.enabled:
             return
         c = self.mods[name]
-        dw, db = A.conv3x3_wgrad(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device)
+        d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device)
+        self.descs.append(d)
+        self.keep.extend(keep)
         self.grads[c.weight] = dw
         if c.bias is not None:
             self.grads[c.bias] = db
+        else:
+            self.keep.append(db)
 
     def result(self):
+        if self.enabled and self.descs:
+            A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device)
+            self.descs, self.keep = [], []
         return self.grads

@@ -178,6 +178,13 @@ typedef struct {
 } esr_wgrad_desc;
 int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d);   /* depends on B, H, W, cout, cin_main, lat only; <0: bad argument */
 int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream);
+/* The weight gradients of MANY layers in one launch (a whole backward pass): with hundreds of layers there are enough
+ * (layer, 32-input-channel tile, 32-output-channel tile) blocks to fill the chip without splitting the pixel sum, so the per-layer
+ * reduction traffic and launch tails disappear.  `descs` is a HOST array (its workspace fields are ignored); `workspace` is caller-
+ * owned device memory of at least esr_conv3x3_wgrad_batch_workspace_bytes(descs, n) bytes (descriptor table + partial sums).
+ * All dy / x buffers must stay alive and unmodified until the launch has run; every layer must use the same operand format. */
+int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc* descs, int n);
+int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
 
 int esr_version(void);
 
