@@ -510,8 +510,6 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     return a;
 }
 
-static inline int p_groups(const esr_wgrad_desc& d) { return wgrad_plan(&d, 1).ngroups; }
-
 static inline int64_t wgrad_partial_floats(const WgradPlan& p) {
     return p.nslices == 1 ? 0 : (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
 }
@@ -522,15 +520,29 @@ static size_t wgrad_lds(int npl) {
 }
 
 // batch layout inside the caller's workspace: [WgradArgs table][int4 workgroup map][fp32 partial sums]
-struct BatchPlan { int target; int64_t nwg, table_bytes, map_bytes, partial_floats; };
+// Work unit = one (layer, input tile, output tile) block over one image tile.  Every layer's pixel sum is cut into as many slices as
+// it takes to keep a workgroup's share near total / 768 (three waves of workgroups over the chip): with hundreds of equal layers
+// that is one slice each (no partial sums at all), a few big high-resolution layers get several, a small net gets many.
+struct BatchPlan { int64_t unit, nwg, table_bytes, map_bytes, partial_floats; };
+static WgradPlan batch_entry_plan(const esr_wgrad_desc* d, int64_t unit) {
+    WgradPlan p = wgrad_plan(d, 1);
+    const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * d->B;
+    int64_t ns = (ntiles + unit - 1) / unit;
+    if (ns > ntiles) ns = ntiles;
+    if (ns < 1) ns = 1;
+    p.nslices = (int)ns;
+    return p;
+}
 static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
     BatchPlan b{};
-    int64_t groups = 0;
-    for (int i = 0; i < n; ++i) groups += wgrad_plan(&descs[i], 1).ngroups;
-    // enough workgroups for two waves over the chip; beyond that the pixel sum is not split at all
-    b.target = groups >= 512 ? 1 : 512;
+    int64_t work = 0;
     for (int i = 0; i < n; ++i) {
-        const WgradPlan p = wgrad_plan(&descs[i], b.target == 1 ? 1 : (int)((512 * (int64_t)p_groups(descs[i]) + groups - 1) / groups));
+        const WgradPlan p = wgrad_plan(&descs[i], 1);
+        work += (int64_t)p.ngroups * p.tiles_x * p.tiles_y * descs[i].B;
+    }
+    b.unit = work / 768 > 0 ? work / 768 : 1;
+    for (int i = 0; i < n; ++i) {
+        const WgradPlan p = batch_entry_plan(&descs[i], b.unit);
         b.nwg += (int64_t)p.ngroups * p.nslices;
         b.partial_floats += wgrad_partial_floats(p);
     }
@@ -585,15 +597,13 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
     }
     if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
     const BatchPlan b = batch_plan(descs, n);
-    int64_t groups = 0;
-    for (int i = 0; i < n; ++i) groups += p_groups(descs[i]);
     std::vector<WgradArgs> table(n);
     std::vector<int4> map((size_t)b.nwg);
     float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
     int64_t w = 0, pf = 0;
     int max_red = 0;
     for (int i = 0; i < n; ++i) {
-        const WgradPlan p = wgrad_plan(&descs[i], b.target == 1 ? 1 : (int)((512 * (int64_t)p_groups(descs[i]) + groups - 1) / groups));
+        const WgradPlan p = batch_entry_plan(&descs[i], b.unit);
         table[i] = wgrad_args(&descs[i], p, partials + pf);
         pf += wgrad_partial_floats(p);
         // slice-major inside a layer so that co-running workgroups of one layer read different images

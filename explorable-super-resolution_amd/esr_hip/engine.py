@@ -27,6 +27,7 @@ class RRDBEngine:
         self._packed = None
         self._packed_t = None
         self._bufs = {}
+        self._gpool, self._gpool_key = {}, None
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
@@ -220,6 +221,19 @@ class RRDBEngine:
         dg = dg.detach()
         dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
         wg = WGrad(self, need_dw, B)
+        # gradient buffers come from a per-engine pool and go back to it when this pass is over: their zero borders (which the conv
+        # kernels rely on and no producer ever writes) survive, so a steady-state step does no buffer memsets at all.  Everything
+        # runs on one stream, so the next pass may reuse them as soon as its kernels are enqueued behind this one's.
+        pool_key = (B, h, w, str(dev), sp)
+        if self._gpool_key != pool_key:
+            self._gpool, self._gpool_key = {}, pool_key
+        taken = []
+
+        def galloc(Bb, ncg, Hh, Ww):
+            free = self._gpool.setdefault((ncg, Hh, Ww), [])
+            buf = free.pop() if free else A.ActBuf(Bb, ncg, Hh, Ww, dev, sp)
+            taken.append(buf)
+            return buf
 
         def zview(bufname):
             return bufs[bufname].view() if bufname in bufs else None
@@ -251,16 +265,16 @@ class RRDBEngine:
             conv(pt[name, 'z'], dy, B, Hh, Ww, lat1, alpha=alpha, out=gz.view(), use_bias=False, **kw)
 
         # ---- HR part
-        G_g = A.ActBuf(B, 1, H, W, dev, sp)
+        G_g = galloc(B, 1, H, W)
         A.pack_nchw(dg, G_g.view(), 0, net.out_nc)
-        G_hr0 = A.ActBuf(B, 8, H, W, dev, sp)
-        GZ_hr = A.ActBuf(B, 1, H, W, dev, sp) if (has_lat and lat) else None
-        GZ_lr = A.ActBuf(B, 1, h, w, dev, sp) if has_lat else None
+        G_hr0 = galloc(B, 8, H, W)
+        GZ_hr = galloc(B, 1, H, W) if (has_lat and lat) else None
+        GZ_lr = galloc(B, 1, h, w) if has_lat else None
         wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W, keep=(G_g,))
         dgrad('hr1', G_g.view(), G_hr0, 0, 8, H, W, mask=(bufs['hr0'], 0, 8))
         if GZ_hr is not None:
             dgrad_z('hr1', G_g.view(), GZ_hr, H, W, 1.0, first=True)
-        G_up = A.ActBuf(B, 8, H, W, dev, sp)
+        G_up = galloc(B, 8, H, W)
         src_act = bufs['ups'][-1] if self.n_up else bufs['trunk']
         wg.conv('hr0', G_hr0.view(), src_act.view(), zview('zhr') if lat else None, H, W, keep=(G_hr0,))
         dgrad('hr0', G_hr0.view(), G_up, 0, 8, H, W, mask=(src_act, 0, 8) if self.n_up else None)
@@ -277,10 +291,10 @@ class RRDBEngine:
             Hj, Wj = s * h, s * w
             below = bufs['ups'][j - 1] if j > 0 else bufs['trunk']
             wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f, keep=(cur_g,))
-            tmp = A.ActBuf(B, 8, Hj, Wj, dev, sp)
+            tmp = galloc(B, 8, Hj, Wj)
             dgrad('up%d' % j, cur_g.view(), tmp, 0, 8, Hj, Wj)
             s //= f
-            nxt_g = A.ActBuf(B, 8, s * h, s * w, dev, sp)
+            nxt_g = galloc(B, 8, s * h, s * w)
             A.act_combine(nxt_g.view(), B, Bv=tmp.view(), beta=1.0, s=f, mask=below.view() if j > 0 else None)
             cur_g = nxt_g
             del tmp
@@ -289,7 +303,7 @@ class RRDBEngine:
             debug['trunk'] = G_trunk.to_nchw(64)
         # ---- trunk: trunk = fea + LR_conv(last)
         nrdb = 3 * net.nb
-        G_last = A.ActBuf(B, 8, h, w, dev, sp)
+        G_last = galloc(B, 8, h, w)
         last_act = bufs['last'] if net.nb else bufs['fea']
         wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w, keep=(G_trunk,))
         dgrad('lr_conv', G_trunk.view(), G_last, 0, 8, h, w)
@@ -300,14 +314,14 @@ class RRDBEngine:
         dout = G_last                         # gradient w.r.t. the output of RRDB r (8 groups)
         # RDB gradient buffers [d x(8) | dy conv0(4) | dy conv1(4) | dy conv2(4) | dy conv3(4)]: a rotating set of 3 — unless weight
         # gradients are wanted: then every RDB gets its own, because its dy slices feed the deferred batched launch
-        GX = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3)] if (net.nb and not need_dw) else []
+        GX = [galloc(B, 24, h, w) for _ in range(3)] if (net.nb and not need_dw) else []
         keepalive = []
         for r in reversed(range(net.nb)):
             dout_rrdb = dout
             G_above = None                    # gradient buffer of RDB k+1 of this RRDB
             for k in reversed(range(3)):
                 X = bufs['rdb'][3 * r + k]
-                G = A.ActBuf(B, 24, h, w, dev, sp) if need_dw else GX[k]
+                G = galloc(B, 24, h, w) if need_dw else GX[k]
                 keepalive.append(G)
                 name = 'rrdb%d.rdb%d' % (r, k)
                 scale = 0.2 if k == 2 else 1.0          # d(RDB_k out): RDB3's output enters the RRDB sum scaled by 0.2
@@ -330,11 +344,11 @@ class RRDBEngine:
                         dgrad_z('%s.conv%d' % (name, i), dy, GZ_lr, h, w, 1.0, first=False)
                 G_above = G
             # G_above[0:8] now holds d(input of RRDB r) = d(output of RRDB r-1); copy it out of the (possibly rotating) set
-            nd = A.ActBuf(B, 8, h, w, dev, sp)
+            nd = galloc(B, 8, h, w)
             A.act_combine(nd.view(), B, A_=G_above.view(0, 8), alpha=1.0)
             dout = nd
         # d fea = d trunk (shortcut) + d(first RRDB input)
-        G_fea = A.ActBuf(B, 8, h, w, dev, sp)
+        G_fea = galloc(B, 8, h, w)
         A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)
         if debug is not None:
             debug['fea'] = G_fea.to_nchw(64)
@@ -342,7 +356,7 @@ class RRDBEngine:
         dx = None
         if need_dx:
             dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dev)
-            G_x = A.ActBuf(B, 1, h, w, dev, sp)
+            G_x = galloc(B, 1, h, w)
             conv(pt['fea', 'm0'], G_fea.view(), B, h, w, 3, out=G_x.view(), use_bias=False)
             A.unpack_grad_nchw(G_x.view(), dx, Ct, h0, w0, c0=Ct - 3, nc=3, pad=pad)
             if has_lat:
@@ -352,7 +366,10 @@ class RRDBEngine:
                 A.unpack_grad_nchw(GZ_lr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, down=sf, **kw)
                 if GZ_hr is not None:
                     A.unpack_grad_nchw(GZ_hr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, accumulate=True, **kw)
-        return dx, wg.result()
+        grads = wg.result()                   # the batched weight-gradient launch is enqueued here, before the buffers are recycled
+        for buf in taken:
+            self._gpool[buf.ncg, buf.H, buf.W].append(buf)
+        return dx, grads
 
 
 class WGrad:
