@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
 
 // ---- weight packing: [M][K][3][3] fp32 -> [kstep = cp*9+tap][mtile][hi|lo][lane][8] bf16
 __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int dim1, const int* __restrict__ kmap, int ncg_in,
-                                    const int* __restrict__ mmap, int mtiles, int transposed, int npl, uint4* __restrict__ out, int total) {
+                                    const int* __restrict__ mmap, int mtiles, int transposed, int npl, float scale, uint4* __restrict__ out, int total) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (kstep, mtile, lane)
     if (idx >= total) return;
     const int lane = idx & 63;
@@ -486,7 +486,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
         float v = 0.f;
         if (kch >= 0 && mch >= 0)
             v = transposed ? w[((long long)kch * dim1 + mch) * 9 + (8 - t)] : w[((long long)mch * dim1 + kch) * 9 + t];
-        split_bf16(v, hi[e], lo[e]);
+        split_bf16(v * scale, hi[e], lo[e]);
     }
     uint4* o = out + ((size_t)(ks * mtiles + m) * npl) * 64 + lane;
     o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
@@ -577,13 +577,13 @@ extern "C" size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split) {
 }
 
 extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* kmap, int ncg_in, const int32_t* mmap,
-                                     int mtiles, int transposed, int split, void* wpack, esr_stream_t stream) {
+                                     int mtiles, int transposed, int split, float scale, void* wpack, esr_stream_t stream) {
     if (!w || !kmap || !mmap || !wpack || ncg_in <= 0 || mtiles <= 0) return ESR_E_ARG;
     const int ncp = (ncg_in + 1) / 2;
     const int total = ncp * 9 * mtiles * 64;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w, kmap,
-                       ncg_in, mmap, mtiles, transposed, split ? 2 : 1, (uint4*)wpack, total);
+                       ncg_in, mmap, mtiles, transposed, split ? 2 : 1, scale, (uint4*)wpack, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }

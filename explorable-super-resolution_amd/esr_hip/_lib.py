@@ -38,7 +38,7 @@ _SIGS = {
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
     'esr_conv_wpack_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'esr_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_float, C.c_void_p, C.c_void_p]),
     'esr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(ActView), C.c_void_p]),
     'esr_unpack_nchw': (C.c_int, [C.POINTER(ActView), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -121,9 +121,54 @@ class PackedConv:
             self.bias = torch.zeros(self.mtiles * 32, dtype=torch.float32, device=dev)
         check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], self.kmap.data_ptr(), self.ncg_in,
                                              self.mmap.data_ptr(), self.mtiles, 1 if self.transposed else 0, 1 if self.split else 0,
-                                             self.wpack.data_ptr(), stream_ptr()), 'esr_pack_conv_weights')
+                                             1.0, self.wpack.data_ptr(), stream_ptr()), 'esr_pack_conv_weights')
         if self.bias_p is not None and not self.transposed:
             self.bias[:w.shape[0]].copy_(self.bias_p.detach().float())
+        self._key = key
+        return self
+
+
+class PackedSum:
+    """Data-gradient pack whose K axis concatenates the output channels of SEVERAL conv layers: one launch then evaluates
+    sum_i scale_i * conv_T(W_i)[rows] (dy_i) with the dy_i stored back to back in one gradient buffer — the backward of a dense
+    block is itself a dense block (reference block.py:230-235 run backwards).  pieces: [(weight, scale)], K order = list order;
+    rows: per piece, the indices into that weight's input-channel axis that form the M axis (same count for every piece)."""
+
+    def __init__(self, pieces, rows, split=True):
+        self.pieces, self.rows, self.split = pieces, rows, split
+        self.transposed = True
+        self._key = None
+        self.wpack = None
+        self.bias = None
+
+    def get(self):
+        key = tuple((w.data_ptr(), w._version) for w, _ in self.pieces)
+        if key == self._key:
+            return self
+        dev = self.pieces[0][0].device
+        require_gpu(self.pieces[0][0], 'conv weight')
+        nrows = len(self.rows[0])
+        mt = (nrows + 31) // 32
+        if self.wpack is None:
+            self.mtiles, self.m_channels = mt, nrows
+            self.maps, off, g = [], [], 0
+            for (w, _), rows in zip(self.pieces, self.rows):
+                assert w.shape[0] % 16 == 0 and len(rows) == nrows
+                kmap = torch.arange(w.shape[0], dtype=torch.int32, device=dev)
+                mmap = torch.tensor(list(rows) + [-1] * (mt * 32 - nrows), dtype=torch.int32, device=dev)
+                self.maps.append((kmap, mmap, g))
+                g += w.shape[0] // 8
+            self.ncg_in = g
+            self.wpack = torch.empty(_lib.lib.esr_conv_wpack_bytes(g, mt * 32, 1 if self.split else 0), dtype=torch.uint8, device=dev)
+            self.bias = torch.zeros(mt * 32, dtype=torch.float32, device=dev)
+            self.chunk_bytes = _lib.lib.esr_conv_wpack_bytes(2, mt * 32, 1 if self.split else 0)
+        for (w, scale), (kmap, mmap, g0) in zip(self.pieces, self.maps):
+            wd = w.detach()
+            if wd.dtype != torch.float32 or not wd.is_contiguous():
+                wd = wd.float().contiguous()
+            check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], kmap.data_ptr(), wd.shape[0] // 8, mmap.data_ptr(),
+                                                 self.mtiles, 1, 1 if self.split else 0, float(scale),
+                                                 self.wpack.data_ptr() + (g0 // 2) * self.chunk_bytes, stream_ptr()), 'esr_pack_conv_weights')
         self._key = key
         return self
 

@@ -26,6 +26,7 @@ class RRDBEngine:
         self.split = True
         self._packed = None
         self._packed_t = None
+        self._packed_rdb_t = None
         self._bufs = {}
         self._gpool, self._gpool_key = {}, None
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
@@ -37,6 +38,7 @@ class RRDBEngine:
             self.split = split
             self._packed = None
             self._packed_t = None
+            self._packed_rdb_t = None
             self._bufs = {}
 
     # ------------------------------------------------------------------ weights
@@ -73,6 +75,8 @@ class RRDBEngine:
         if self._packed_t is None:
             d = {}
             for name, c, lat in self._convs():
+                if name.startswith('rrdb'):
+                    continue                  # dense blocks: packed_rdb_t()
                 main = c.weight.shape[1] - lat
                 for j in range((main + 63) // 64):
                     d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
@@ -82,6 +86,33 @@ class RRDBEngine:
         for p in self._packed_t.values():
             p.get()
         return self._packed_t
+
+    def packed_rdb_t(self):
+        """Data-gradient packs of the dense blocks in "mirrored" form.  With the gradients of an RDB's five conv outputs stored as
+        G' = [dy conv4 (8 groups) | dy conv3 (4) | dy conv2 | dy conv1 | dy conv0], the gradient of block c+1 (the output of conv c) is
+        ONE conv over the first 8 + 4(3-c) groups of G' — sum_{i>c} W_i^T[rows of block c+1] * dy_i — masked by LeakyReLU', written
+        right behind them; the gradient of the RDB input is one conv over all 24 groups.  Per RDB: 'g3'..'g0' (32 rows), 'gx' (64 rows),
+        'gz' (latent rows).  conv4's 0.2 (and the RRDB's 0.2 for the third RDB) is folded into its piece of every pack."""
+        if self._packed_rdb_t is None:
+            d = {}
+            mods = {name: (c, lat) for name, c, lat in self._convs()}
+            for r in range(self.net.nb):
+                for k in range(3):
+                    name = 'rrdb%d.rdb%d' % (r, k)
+                    ws = [mods['%s.conv%d' % (name, i)][0].weight for i in range(5)]
+                    lat = mods[name + '.conv0'][1]
+                    s4 = 0.2 * (0.2 if k == 2 else 1.0)
+                    pieces = [(ws[4], s4), (ws[3], 1.0), (ws[2], 1.0), (ws[1], 1.0), (ws[0], 1.0)]
+                    for c in (3, 2, 1, 0):
+                        rows = list(range(lat + 64 + 32 * c, lat + 96 + 32 * c))
+                        d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self.split)
+                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self.split)
+                    if lat:
+                        d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self.split)
+            self._packed_rdb_t = d
+        for p in self._packed_rdb_t.values():
+            p.get()
+        return self._packed_rdb_t
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B, h, w, dev, keep):
@@ -302,51 +333,51 @@ class RRDBEngine:
         if debug is not None:
             debug['trunk'] = G_trunk.to_nchw(64)
         # ---- trunk: trunk = fea + LR_conv(last)
-        nrdb = 3 * net.nb
-        G_last = galloc(B, 8, h, w)
         last_act = bufs['last'] if net.nb else bufs['fea']
+        pr = self.packed_rdb_t() if net.nb else {}
+        # RDB gradient buffers G' (see packed_rdb_t): 4 rotating ones — unless weight gradients are wanted: then every RDB keeps its
+        # own, because its dy slices feed the deferred batched launch
+        ring = [galloc(B, 24, h, w) for _ in range(4)] if (net.nb and not need_dw) else []
+        nseq = 3 * net.nb
+
+        def gbuf(n):                          # n-th RDB in backward order (n = 0: last RDB of the last RRDB)
+            return ring[n % 4] if ring else galloc(B, 24, h, w)
+
+        G_cur = gbuf(0) if net.nb else None
+        G_first = G_cur if net.nb else galloc(B, 8, h, w)      # receives d(output of the last RRDB) = d(LR_conv input)
         wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w, keep=(G_trunk,))
-        dgrad('lr_conv', G_trunk.view(), G_last, 0, 8, h, w)
+        dgrad('lr_conv', G_trunk.view(), G_first, 0, 8, h, w)
         zfirst = True
         if lat:
             dgrad_z('lr_conv', G_trunk.view(), GZ_lr, h, w, 1.0, first=True)
             zfirst = False
-        dout = G_last                         # gradient w.r.t. the output of RRDB r (8 groups)
-        # RDB gradient buffers [d x(8) | dy conv0(4) | dy conv1(4) | dy conv2(4) | dy conv3(4)]: a rotating set of 3 — unless weight
-        # gradients are wanted: then every RDB gets its own, because its dy slices feed the deferred batched launch
-        GX = [galloc(B, 24, h, w) for _ in range(3)] if (net.nb and not need_dw) else []
-        keepalive = []
+        dout = G_first                        # holds d(input of RRDB 0) in groups 0:8 when the loop is done
+        n = 0
         for r in reversed(range(net.nb)):
-            dout_rrdb = dout
-            G_above = None                    # gradient buffer of RDB k+1 of this RRDB
+            G_rrdb = G_cur                    # its groups 0:8 = d(output of RRDB r), needed again for the RRDB's skip connection
             for k in reversed(range(3)):
                 X = bufs['rdb'][3 * r + k]
-                G = galloc(B, 24, h, w) if need_dw else GX[k]
-                keepalive.append(G)
+                G = G_cur
                 name = 'rrdb%d.rdb%d' % (r, k)
-                scale = 0.2 if k == 2 else 1.0          # d(RDB_k out): RDB3's output enters the RRDB sum scaled by 0.2
-                dy_out = dout_rrdb.view(0, 8) if k == 2 else G_above.view(0, 8)
-                # conv4: y = 0.2*conv(X[0:24]) + x  ->  G[0:24] = 0.2*scale*conv_T(dy_out);  G[0:8] += scale*dy_out;  G[20:24] *= act'
-                wg.conv(name + '.conv4', dy_out, X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * scale,
-                        keep=(dout_rrdb, G_above, X))
-                dgrad(name + '.conv4', dy_out, G, 0, 24, h, w, alpha=0.2 * scale, extra=dy_out, extra_beta=scale, mask=(X, 20, 24))
+                s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
+                wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
+                for c in (3, 2, 1, 0):
+                    g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
+                    conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4), use_bias=False,
+                         mask_src=X.view(8 + 4 * c, 4), mask_cg=(0, 4), mask_slope=0.2)
+                    wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if lat:
-                    dgrad_z(name + '.conv4', dy_out, GZ_lr, h, w, 0.2 * scale, first=zfirst)
+                    kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
+                    conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz)
                     zfirst = False
-                for i in (3, 2, 1, 0):
-                    dy = G.view(8 + 4 * i, 4)            # complete and already multiplied by act'
-                    wg.conv('%s.conv%d' % (name, i), dy, X.view(0, 8 + 4 * i), zview('zlr') if lat else None, h, w, keep=(G, X))
-                    last_rdb_conv = (k == 0 and i == 0)
-                    dgrad('%s.conv%d' % (name, i), dy, G, 0, 8 + 4 * i, h, w, accumulate=True,
-                          extra=dout_rrdb.view(0, 8) if last_rdb_conv else None,      # RRDB skip: d x_rrdb += d out_rrdb
-                          mask=(X, 4 + 4 * i, 8 + 4 * i) if i > 0 else None)
-                    if lat:
-                        dgrad_z('%s.conv%d' % (name, i), dy, GZ_lr, h, w, 1.0, first=False)
-                G_above = G
-            # G_above[0:8] now holds d(input of RRDB r) = d(output of RRDB r-1); copy it out of the (possibly rotating) set
-            nd = galloc(B, 8, h, w)
-            A.act_combine(nd.view(), B, A_=G_above.view(0, 8), alpha=1.0)
-            dout = nd
+                # d(RDB input) = s_out*dy_out + sum_i W_i^T dy_i  (+ d(out of the RRDB) for its first RDB: the RRDB skip connection),
+                # written where the next RDB in backward order expects its dy_out
+                n += 1
+                G_next = gbuf(n) if n < nseq else galloc(B, 8, h, w)
+                kw = dict(res2=G_rrdb.view(0, 8), beta2=1.0) if k == 0 else {}
+                conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw)
+                G_cur = G_next
+            dout = G_cur
         # d fea = d trunk (shortcut) + d(first RRDB input)
         G_fea = galloc(B, 8, h, w)
         A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)

@@ -96,9 +96,12 @@ size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split);
  *   mmap[mtiles*32] : for each output row the index into the "M" channel axis, or -1 (zero)
  *   transposed = 0 : forward     — M axis = dim 0 (cout_w), K axis = dim 1 (cin_w), tap (dy,dx) as stored
  *   transposed = 1 : data-grad   — M axis = dim 1 (cin_w),  K axis = dim 0 (cout_w), tap flipped (2-dy,2-dx)
- * kmap/mmap are device int32 arrays. */
+ * kmap/mmap are device int32 arrays; every weight is multiplied by `scale` before it is split.
+ * The pack is chunk-major ([pair of K groups][tap][mtile][hi|lo][lane]): the K axis of one launch may concatenate several tensors
+ * by packing each at byte offset  first_group/2 * esr_conv_wpack_bytes(2, mtiles*32, split)  of one buffer (first_group even) —
+ * how the dense-block data gradient sums  W_5^T*dy_5 + ... + W_j^T*dy_j  in a single conv (block.py:230-235 backwards). */
 int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* kmap, int ncg_in,
-                          const int32_t* mmap, int mtiles, int transposed, int split, void* wpack,
+                          const int32_t* mmap, int mtiles, int transposed, int split, float scale, void* wpack,
                           esr_stream_t stream);
 
 /* ---- layout conversion at the module boundary ----
