@@ -14,10 +14,16 @@ Inference rotates three RDB buffers; a forward that must be differentiated keeps
 activations) and the backward re-uses the same conv kernel with transposed/flipped weight packs (data gradient), a
 pixel-contraction MFMA kernel (weight gradient) and the gradient buffers laid out exactly like the activations.
 """
+import weakref
+
 import torch
 
 from . import act as A
 from ._lib import EsrError
+
+
+class _Lease:
+    pass
 
 
 class RRDBEngine:
@@ -116,11 +122,31 @@ class RRDBEngine:
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B, h, w, dev, keep):
+        """Activation buffers, cached per shape (their zero borders are written once).  A differentiable forward (keep=True) LEASES
+        its set until the autograd node that saved it is gone: a second differentiable forward in the meantime (two generator
+        calls before one backward) gets a fresh, uncached set instead of overwriting saved activations."""
         key = (B, h, w, str(dev), keep)
-        if key in self._bufs:
-            return self._bufs[key]
+        cached = self._bufs.get(key)
+        if cached is not None:
+            busy = cached.get('_busy')
+            if not keep or busy is None or busy() is None:
+                return self._lease(cached) if keep else cached
+            return self._lease(self._new_buffers(B, h, w, dev, keep))
         if len(self._bufs) > 2:
             self._bufs.clear()
+        d = self._new_buffers(B, h, w, dev, keep)
+        self._bufs[key] = d
+        return self._lease(d) if keep else d
+
+    @staticmethod
+    def _lease(d):
+        lease = _Lease()
+        d['_busy'] = weakref.ref(lease)
+        out = dict(d)
+        out['_lease'] = lease          # lives exactly as long as the caller's copy (the autograd context)
+        return out
+
+    def _new_buffers(self, B, h, w, dev, keep):
         net, sp = self.net, self.split
         sf = net.upscale
         d = {}
@@ -142,7 +168,6 @@ class RRDBEngine:
             ups.append(A.ActBuf(B, 8, s * h, s * w, dev, sp))
         d['ups'] = ups
         d['hr0'] = A.ActBuf(B, 8, sf * h, sf * w, dev, sp)
-        self._bufs[key] = d
         return d
 
     # ------------------------------------------------------------------ forward

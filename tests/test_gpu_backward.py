@@ -185,3 +185,21 @@ def test_rrdb_parameter_gradients_match_reference_golden(name, nb, sf, lat):
         if np.abs(f[idx].numpy() - dig[j][2:]).max() > 0.2 * scale + 1e-6:
             bad.append((k, 'samples', float(np.abs(f[idx].numpy() - dig[j][2:]).max() / scale)))
     assert not bad, bad[:5]
+
+
+def test_two_forwards_before_backward_keep_their_own_activations():
+    """Two differentiable generator calls before any backward (e.g. a GAN step evaluating G twice): the second call must not
+    overwrite the activations the first one saved."""
+    net = _rrdb(1, 4, 0).to(DEV)
+    x1 = _f4_input(1, 4, 0).to(DEV).requires_grad_(True)
+    x2 = (1.0 - _f4_input(1, 4, 0)).to(DEV).requires_grad_(True)
+    # reference: one at a time
+    refs = []
+    for x in (x1, x2):
+        y = net(x)
+        g, = torch.autograd.grad((y * y).sum(), x)
+        refs.append(g.clone())
+    y1, y2 = net(x1), net(x2)
+    g2, = torch.autograd.grad((y2 * y2).sum(), x2)
+    g1, = torch.autograd.grad((y1 * y1).sum(), x1)
+    assert torch.equal(g1, refs[0]) and torch.equal(g2, refs[1])
