@@ -189,3 +189,34 @@ def test_c1_end_to_end_matches_reference_golden():
     with torch.no_grad():
         y = G.eval()(xin)
     assert rel_l2(y.cpu().numpy(), g['c1_lat3/out']) < 1e-4
+
+
+@pytest.mark.parametrize('precision,tol', [('split', 1e-4), ('bf16', 3e-2)])
+def test_c5_style_x8_blurry_kernel_eval_forward(precision, tol):
+    """BASELINE configs[4] in miniature: x8 generator, non-bicubic CEM kernel ('blurry_cubic_2.0': margin 12 LR pixels), eval mode,
+    in the fp32-class mode (bar 1e-3, asserted at 1e-4) and in the reduced-precision single-MFMA mode the reference has no
+    counterpart of (its tolerance is the mode's own: bf16 operands, ~1e-2)."""
+    import CEM.CEMnet as C
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    sf, nb = 8, 2
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel='blurry_cubic_2.0')
+    G = cem.WrapArchitecture_PyTorch(_rrdb(nb, sf, 0))
+    fill_formula_weights(G, gain=1.0)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    G = G.to(DEV).eval()
+    G.generated_image_model.set_precision(precision)
+    x = seeded_uniform((2, 3, 9, 11), 301)
+    with torch.no_grad():
+        y = G(x.to(DEV)).cpu()
+    t = co.CEMTaps(sf, 'blurry_cubic_2.0')
+    assert t.margins_LR == int(cem.invalidity_margins_LR) == 12
+    xp = torch.nn.functional.pad(x, (t.margins_LR,) * 4, mode='replicate')
+    gen = ro.rrdb_forward(sd, xp, nb, sf, 0, prefix='generated_image_model.model')
+    ref = co.cem_combine(xp, gen, t, crop=True)
+    assert y.shape == ref.shape == (2, 3, 72, 88)
+    assert rel_l2(y.numpy(), ref.numpy()) < tol
+    # whatever the generator's precision, the CEM keeps the output consistent with the LR input (fp32 filters)
+    back = co.downscale_op(y, t)
+    assert float((back - x)[..., 3:-3, 3:-3].abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
+    imresize.kernels = {}
