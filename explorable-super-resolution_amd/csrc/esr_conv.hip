@@ -25,6 +25,7 @@
 //                  v_permlane32_swap so that every lane stores one full 16-byte pixel vector
 #include "esr_common.h"
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -493,6 +494,36 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
     if (npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
 }
 
+// many weight tensors in one launch: block b packs entry map[b].x, elements map[b].y*256 .. (a training step re-packs every layer)
+struct PackEntry {
+    const float* w; const int* kmap; const int* mmap; uint4* out;
+    int dim0, dim1, ncg_in, mtiles, transposed, npl, total; float scale;
+};
+__global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ table, const int2* __restrict__ map) {
+    const int2 m = map[blockIdx.x];
+    const PackEntry e = table[m.x];
+    const int idx = m.y * 256 + threadIdx.x;
+    if (idx >= e.total) return;
+    const int lane = idx & 63;
+    const int mt = (idx >> 6) % e.mtiles;
+    const int ks = (idx >> 6) / e.mtiles;
+    const int cp = ks / 9, t = ks % 9;
+    const int cg = 2 * cp + (lane >> 5);
+    const int mch = e.mmap[mt * 32 + (lane & 31)];
+    uint32_t hi[8], lo[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int kch = cg < e.ncg_in ? e.kmap[cg * 8 + c] : -1;
+        float v = 0.f;
+        if (kch >= 0 && mch >= 0)
+            v = e.transposed ? e.w[((long long)kch * e.dim1 + mch) * 9 + (8 - t)] : e.w[((long long)mch * e.dim1 + kch) * 9 + t];
+        split_bf16(v * e.scale, hi[c], lo[c]);
+    }
+    uint4* o = e.out + ((size_t)(ks * e.mtiles + mt) * e.npl) * 64 + lane;
+    o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    if (e.npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+}
+
 struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
 // Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
@@ -584,6 +615,57 @@ extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, cons
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w, kmap,
                        ncg_in, mmap, mtiles, transposed, split ? 2 : 1, scale, (uint4*)wpack, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+static int64_t pack_batch_blocks(const esr_pack_desc* descs, int n) {
+    int64_t nb = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].w || !descs[i].kmap || !descs[i].mmap || !descs[i].wpack || descs[i].ncg_in <= 0 || descs[i].mtiles <= 0) return ESR_E_ARG;
+        const int64_t total = (int64_t)((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
+        nb += (total + 255) / 256;
+    }
+    return nb;
+}
+
+extern "C" int64_t esr_pack_batch_workspace_bytes(const esr_pack_desc* descs, int n) {
+    if (!descs || n <= 0) return ESR_E_ARG;
+    const int64_t nb = pack_batch_blocks(descs, n);
+    if (nb < 0) return nb;
+    return ((int64_t)n * sizeof(PackEntry) + 255) / 256 * 256 + nb * (int64_t)sizeof(int2);
+}
+
+extern "C" int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
+    if (!descs || n <= 0 || !workspace) return ESR_E_ARG;
+    const int64_t need = esr_pack_batch_workspace_bytes(descs, n);
+    if (need < 0 || workspace_bytes < need) return ESR_E_ARG;
+    const int64_t nb = pack_batch_blocks(descs, n);
+    std::vector<PackEntry> table(n);
+    std::vector<int2> map((size_t)nb);
+    int64_t b = 0;
+    for (int i = 0; i < n; ++i) {
+        PackEntry& e = table[i];
+        e.w = descs[i].w; e.kmap = descs[i].kmap; e.mmap = descs[i].mmap; e.out = (uint4*)descs[i].wpack;
+        e.dim0 = descs[i].cout_w; e.dim1 = descs[i].cin_w; e.ncg_in = descs[i].ncg_in; e.mtiles = descs[i].mtiles;
+        e.transposed = descs[i].transposed; e.npl = descs[i].split ? 2 : 1; e.scale = descs[i].scale;
+        e.total = ((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
+        for (int j = 0; j < (e.total + 255) / 256; ++j) map[(size_t)b++] = make_int2(i, j);
+    }
+    const size_t tb = ((size_t)n * sizeof(PackEntry) + 255) / 256 * 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(PackEntry), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
+    if (hipMemcpyAsync((char*)workspace + tb, map.data(), (size_t)nb * sizeof(int2), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return ESR_E_LAUNCH;     // the host vectors go out of scope
+    return nb;
+}
+
+extern "C" int esr_pack_batch_run(const void* workspace, int n, int64_t nblocks, esr_stream_t stream) {
+    if (!workspace || n <= 0 || nblocks <= 0) return ESR_E_ARG;
+    const size_t tb = ((size_t)n * sizeof(PackEntry) + 255) / 256 * 256;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)workspace,
+                       (const int2*)((const char*)workspace + tb));
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }

@@ -33,12 +33,21 @@ class WgradDesc(C.Structure):
                 ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_floats', C.c_int64)]
 
 
+class PackDesc(C.Structure):
+    """esr_pack_desc (include/esr_hip.h)."""
+    _fields_ = [('w', C.c_void_p), ('cout_w', C.c_int32), ('cin_w', C.c_int32), ('kmap', C.c_void_p), ('ncg_in', C.c_int32), ('mmap', C.c_void_p),
+                ('mtiles', C.c_int32), ('transposed', C.c_int32), ('split', C.c_int32), ('scale', C.c_float), ('wpack', C.c_void_p)]
+
+
 _SIGS = {
     'esr_version': (C.c_int, []),
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
     'esr_conv_wpack_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'esr_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p]),
+    'esr_pack_batch_workspace_bytes': (C.c_int64, [C.POINTER(PackDesc), C.c_int]),
+    'esr_pack_batch_upload': (C.c_int64, [C.POINTER(PackDesc), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'esr_pack_batch_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'esr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(ActView), C.c_void_p]),
     'esr_unpack_nchw': (C.c_int, [C.POINTER(ActView), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -104,28 +104,87 @@ class PackedConv:
         self.m_channels = len([m for m in mmap if m >= 0])
         return (torch.tensor(kmap, dtype=torch.int32, device=dev), torch.tensor(mmap, dtype=torch.int32, device=dev))
 
-    def get(self):
+    # -- pieces the engine's batched re-pack is assembled from (esr_pack_batch_*); get() is the stand-alone path
+    def key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, None if self.bias_p is None else (self.bias_p.data_ptr(), self.bias_p._version))
+
+    def stale(self):
+        return self.key() != self._key
+
+    def prepare(self):
         w = self.weight
         require_gpu(w, 'conv weight')
-        key = (w.data_ptr(), w._version, None if self.bias_p is None else (self.bias_p.data_ptr(), self.bias_p._version))
-        if key == self._key:
-            return self
-        dev = w.device
-        wd = w.detach()
-        if wd.dtype != torch.float32 or not wd.is_contiguous():
-            wd = wd.float().contiguous()
         if self.wpack is None:
+            dev = w.device
             self.kmap, self.mmap = self._maps(dev)
             nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, 1 if self.split else 0)
             self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.bias = torch.zeros(self.mtiles * 32, dtype=torch.float32, device=dev)
-        check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], self.kmap.data_ptr(), self.ncg_in,
-                                             self.mmap.data_ptr(), self.mtiles, 1 if self.transposed else 0, 1 if self.split else 0,
-                                             1.0, self.wpack.data_ptr(), stream_ptr()), 'esr_pack_conv_weights')
-        if self.bias_p is not None and not self.transposed:
-            self.bias[:w.shape[0]].copy_(self.bias_p.detach().float())
-        self._key = key
+            bp = self.bias_p
+            if bp is not None and not self.transposed and bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == self.mtiles * 32:
+                self.bias, self._bias_shared = bp.detach(), True        # the kernel reads the parameter itself: always current
+            else:
+                self.bias, self._bias_shared = torch.zeros(self.mtiles * 32, dtype=torch.float32, device=dev), False
         return self
+
+    def jobs(self):
+        """[(fp32 contiguous weight tensor, kmap, ncg_in, mmap, mtiles, transposed, scale, destination pointer)]"""
+        wd = self.weight.detach()
+        if wd.dtype != torch.float32 or not wd.is_contiguous():
+            wd = wd.float().contiguous()
+        self._wd = wd                             # keeps a converted copy alive until the pack has run
+        return [(wd, self.kmap, self.ncg_in, self.mmap, self.mtiles, 1 if self.transposed else 0, 1.0, self.wpack.data_ptr())]
+
+    def after_pack(self):
+        if self.bias_p is not None and not self.transposed and not self._bias_shared:
+            self.bias[:self.weight.shape[0]].copy_(self.bias_p.detach().float())
+        if self._bias_shared and self.bias.data_ptr() != self.bias_p.data_ptr():
+            self.bias = self.bias_p.detach()      # the parameter's storage was replaced
+        self._key = self.key()
+
+    def get(self):
+        if not self.stale():
+            return self
+        self.prepare()
+        run_pack_jobs(self.jobs(), self.split)
+        self.after_pack()
+        return self
+
+
+def run_pack_jobs(jobs, split):
+    for wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst in jobs:
+        check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles,
+                                             transposed, 1 if split else 0, float(scale), dst, stream_ptr()), 'esr_pack_conv_weights')
+
+
+class PackBatch:
+    """All weight packs of an engine re-packed by ONE launch (esr_pack_batch_*).  The descriptor table lives on the device and is
+    re-uploaded only when a pointer changes, so a training step costs one kernel instead of ~1700 tiny ones."""
+
+    def __init__(self):
+        self.ptr_key, self.ws, self.n, self.nblocks = None, None, 0, 0
+
+    def run(self, packs, split):
+        jobs = []
+        for pk in packs:
+            pk.prepare()
+            jobs += pk.jobs()
+        ptr_key = tuple((j[0].data_ptr(), j[7]) for j in jobs)
+        if ptr_key != self.ptr_key:
+            arr = (_lib.PackDesc * len(jobs))()
+            for d, (wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst) in zip(arr, jobs):
+                d.w, d.cout_w, d.cin_w = wd.data_ptr(), wd.shape[0], wd.shape[1]
+                d.kmap, d.ncg_in, d.mmap, d.mtiles = kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles
+                d.transposed, d.split, d.scale, d.wpack = transposed, 1 if split else 0, float(scale), dst
+            need = _lib.lib.esr_pack_batch_workspace_bytes(arr, len(jobs))
+            check(min(need, 0), 'esr_pack_batch_workspace_bytes')
+            self.ws = torch.empty(int(need), dtype=torch.uint8, device=jobs[0][0].device)
+            nb = _lib.lib.esr_pack_batch_upload(arr, len(jobs), self.ws.data_ptr(), self.ws.numel(), stream_ptr())
+            check(min(nb, 0), 'esr_pack_batch_upload')
+            self.ptr_key, self.n, self.nblocks = ptr_key, len(jobs), int(nb)
+        check(_lib.lib.esr_pack_batch_run(self.ws.data_ptr(), self.n, self.nblocks, stream_ptr()), 'esr_pack_batch_run')
+        for pk in packs:
+            pk.after_pack()
 
 
 class PackedSum:
@@ -141,17 +200,20 @@ class PackedSum:
         self.wpack = None
         self.bias = None
 
-    def get(self):
-        key = tuple((w.data_ptr(), w._version) for w, _ in self.pieces)
-        if key == self._key:
-            return self
-        dev = self.pieces[0][0].device
-        require_gpu(self.pieces[0][0], 'conv weight')
-        nrows = len(self.rows[0])
-        mt = (nrows + 31) // 32
+    def key(self):
+        return tuple((w.data_ptr(), w._version) for w, _ in self.pieces)
+
+    def stale(self):
+        return self.key() != self._key
+
+    def prepare(self):
         if self.wpack is None:
+            dev = self.pieces[0][0].device
+            require_gpu(self.pieces[0][0], 'conv weight')
+            nrows = len(self.rows[0])
+            mt = (nrows + 31) // 32
             self.mtiles, self.m_channels = mt, nrows
-            self.maps, off, g = [], [], 0
+            self.maps, g = [], 0
             for (w, _), rows in zip(self.pieces, self.rows):
                 assert w.shape[0] % 16 == 0 and len(rows) == nrows
                 kmap = torch.arange(w.shape[0], dtype=torch.int32, device=dev)
@@ -162,14 +224,27 @@ class PackedSum:
             self.wpack = torch.empty(_lib.lib.esr_conv_wpack_bytes(g, mt * 32, 1 if self.split else 0), dtype=torch.uint8, device=dev)
             self.bias = torch.zeros(mt * 32, dtype=torch.float32, device=dev)
             self.chunk_bytes = _lib.lib.esr_conv_wpack_bytes(2, mt * 32, 1 if self.split else 0)
+        return self
+
+    def jobs(self):
+        out, self._wd = [], []
         for (w, scale), (kmap, mmap, g0) in zip(self.pieces, self.maps):
             wd = w.detach()
             if wd.dtype != torch.float32 or not wd.is_contiguous():
                 wd = wd.float().contiguous()
-            check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], kmap.data_ptr(), wd.shape[0] // 8, mmap.data_ptr(),
-                                                 self.mtiles, 1, 1 if self.split else 0, float(scale),
-                                                 self.wpack.data_ptr() + (g0 // 2) * self.chunk_bytes, stream_ptr()), 'esr_pack_conv_weights')
-        self._key = key
+            self._wd.append(wd)
+            out.append((wd, kmap, wd.shape[0] // 8, mmap, self.mtiles, 1, scale, self.wpack.data_ptr() + (g0 // 2) * self.chunk_bytes))
+        return out
+
+    def after_pack(self):
+        self._key = self.key()
+
+    def get(self):
+        if not self.stale():
+            return self
+        self.prepare()
+        run_pack_jobs(self.jobs(), self.split)
+        self.after_pack()
         return self
 
 
@@ -259,11 +334,15 @@ def conv3x3_dgrad_nchw(dy, weight, split=True):
     return dx
 
 
-def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
-    """esr_wgrad_desc for one conv layer plus its freshly zeroed outputs: returns (desc, dW [cout][cin][3][3], db [cout])."""
+def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device, out=None):
+    """esr_wgrad_desc for one conv layer plus its zeroed outputs: returns (desc, dW [cout][cin][3][3], db [cout]).
+    out = (dW, db): zeroed tensors to accumulate into (e.g. views of one flat buffer) instead of allocating two per layer."""
     cout, cin = wshape[0], wshape[1]
-    dw = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=device)
-    db = torch.zeros(cout, dtype=torch.float32, device=device)
+    if out is None:
+        dw = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=device)
+        db = torch.zeros(cout, dtype=torch.float32, device=device)
+    else:
+        dw, db = out
     nlat = lat if x_lat is not None else 0
     d = _lib.WgradDesc()
     d.dy, d.x = dy, x_main

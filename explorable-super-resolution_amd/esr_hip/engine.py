@@ -35,6 +35,7 @@ class RRDBEngine:
         self._packed_rdb_t = None
         self._bufs = {}
         self._gpool, self._gpool_key = {}, None
+        self._pack_batch = A.PackBatch()
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
@@ -68,11 +69,16 @@ class RRDBEngine:
         out.append(('hr1', m[idx + 2], lat))
         return out
 
+    def _refresh_packs(self):
+        """Re-pack every existing pack (forward and data-gradient ones) in one launch if any parameter changed since the last time."""
+        packs = [p for d in (self._packed, self._packed_t, self._packed_rdb_t) if d for p in d.values()]
+        if any(p.stale() for p in packs):
+            self._pack_batch.run(packs, self.split)
+
     def packed(self):
         if self._packed is None:
             self._packed = {name: A.PackedConv(c.weight, c.bias, lat, split=self.split) for name, c, lat in self._convs()}
-        for p in self._packed.values():
-            p.get()
+        self._refresh_packs()
         return self._packed
 
     def packed_t(self):
@@ -89,8 +95,7 @@ class RRDBEngine:
                 if lat:
                     d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice='latent')
             self._packed_t = d
-        for p in self._packed_t.values():
-            p.get()
+        self._refresh_packs()
         return self._packed_t
 
     def packed_rdb_t(self):
@@ -116,8 +121,7 @@ class RRDBEngine:
                     if lat:
                         d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self.split)
             self._packed_rdb_t = d
-        for p in self._packed_rdb_t.values():
-            p.get()
+        self._refresh_packs()
         return self._packed_rdb_t
 
     # ------------------------------------------------------------------ buffers
@@ -439,12 +443,21 @@ class WGrad:
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
         self.descs, self.keep = [], []
+        if enabled:
+            # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
+            self.offsets, n = {}, 0
+            for name, c in self.mods.items():
+                self.offsets[name] = n
+                n += c.weight.numel() + c.weight.shape[0]
+            self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(self.mods.values())).weight.device)
 
     def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=()):
         if not self.enabled:
             return
         c = self.mods[name]
-        d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device)
+        o, nw = self.offsets[name], c.weight.numel()
+        out = (self.flat[o:o + nw].view(c.weight.shape), self.flat[o + nw:o + nw + c.weight.shape[0]])
+        d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device, out=out)
         self.descs.append(d)
         self.keep.extend(keep)
         self.grads[c.weight] = dw

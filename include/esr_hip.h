@@ -104,6 +104,18 @@ int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* 
                           const int32_t* mmap, int mtiles, int transposed, int split, float scale, void* wpack,
                           esr_stream_t stream);
 
+/* The same for MANY tensors in one launch (a training step changes every layer's weights).  `descs` is a HOST array; upload once
+ * into caller-owned device `workspace` (>= esr_pack_batch_workspace_bytes), then esr_pack_batch_run re-packs all of them from the
+ * CURRENT contents of their `w` whenever the parameters changed — no host traffic in steady state.  upload returns the number of
+ * workgroups to pass to run (> 0), or ESR_E_*; it must be repeated when any pointer in the descriptors changes. */
+typedef struct {
+    const float* w; int32_t cout_w, cin_w; const int32_t* kmap; int32_t ncg_in; const int32_t* mmap;
+    int32_t mtiles, transposed, split; float scale; void* wpack;
+} esr_pack_desc;
+int64_t esr_pack_batch_workspace_bytes(const esr_pack_desc* descs, int n);
+int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
+int esr_pack_batch_run(const void* workspace, int n, int64_t nblocks, esr_stream_t stream);
+
 /* ---- layout conversion at the module boundary ----
  * fp32 NCHW -> act view.  Writes channels [c0, c0+nc) of `src` ([B][C][h][w]; image b starts at
  * src + b*src_batch_stride floats, 0 = C*h*w — lets the HR-resolution latent be read through the raw

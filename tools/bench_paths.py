@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Secondary measurements of the callers around the hot path (not the headline bench): the generator training step at the C3
+per-GPU shape and Z-search iterations at the C4 shape, both through the product's model wrapper / Z_optimizer.
+
+    python tools/bench_paths.py c3 [--batch 32] [--steps 10]        RRDB-23 x4 + CEM, lat 3, 52x52 LR crops, L1 pixel loss, Adam
+    python tools/bench_paths.py c4 [--batch 64] [--steps 10]        Z search: STD_increase on one 128x128 LR image, Adam on Z
+Under torchrun (one process per GPU) c3 all-reduces the gradients over RCCL and c4 shards the Z batch.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd'))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def make_opt(is_train, lat=3, nb=23):
+    from options.options import dict_to_nonedict
+    return dict_to_nonedict({
+        'model': 'srragan', 'scale': 4, 'gpu_ids': [0], 'range': [0, 1], 'is_train': is_train,
+        'path': {'models': '/tmp/esr_models', 'log': '/tmp/esr_log', 'pretrain_model_G': None},
+        'network_G': {'which_model_G': 'RRDB_net', 'CEM_arch': 1, 'sigmoid_range_limit': 0, 'latent_input': 'all_layers',
+                      'latent_input_domain': 'HR_downscaled', 'latent_channels': lat, 'norm_type': None, 'mode': 'CNA', 'nf': 64, 'nb': nb,
+                      'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
+        'network_D': None, 'test': {'kernel': None}, 'datasets': {'train': {'patch_size': 208}},
+        'train': {'pixel_weight': 1, 'pixel_criterion': 'l1', 'lr_G': 1e-4, 'pixel_domain': 'HR', 'grad_accumulation_steps_G': 1,
+                  'lr_scheme': 'MultiStepLR', 'lr_steps': [100000], 'lr_gamma': 0.5}})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('which', choices=['c3', 'c4'])
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--nb', type=int, default=23)
+    a = ap.parse_args()
+    from esr_hip import dist as D
+    D.init_from_env()
+    import contextlib
+    import io
+    import models
+    torch.manual_seed(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.create_model(make_opt(a.which == 'c3', nb=a.nb))
+    sync = torch.cuda.synchronize
+    if a.which == 'c3':
+        B = a.batch or 32
+        data = {'LR': torch.rand(B, 3, 52, 52, device=dev), 'HR': torch.rand(B, 3, 208, 208, device=dev),
+                'Z': torch.rand(B, 3, 208, 208, device=dev) * 2 - 1}
+        for _ in range(2):
+            model.feed_data(data); model.optimize_parameters()
+        sync(); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            model.feed_data(data); model.optimize_parameters()
+        sync(); dt = (time.perf_counter() - t0) / a.steps
+        if D.rank() == 0:
+            print('c3 generator step (RRDB-%d x4 + CEM, lat 3, %d x 52x52 per GPU, %d GPU(s)): %.1f ms/step, %.0f LR crops/s, l_g_pix %.4f, peak %.1f GB'
+                  % (a.nb, B, D.world_size(), dt * 1e3, B * D.world_size() / dt, model.get_current_log()['l_g_pix'], torch.cuda.max_memory_allocated() / 2 ** 30))
+    else:
+        from Z_optimization import Z_optimizer
+        B = a.batch or 64
+        lr = torch.rand(1, 3, 128, 128, device=dev)
+        lo, hi = D.shard_range(B)
+        model.feed_data({'LR': lr.expand(hi - lo, -1, -1, -1), 'Z': torch.zeros(hi - lo, 3, 512, 512, device=dev)}, need_GT=False)
+        model.test()
+        zo = Z_optimizer(objective='STD_increase', Z_size=[512, 512], model=model, Z_range=1, max_iters=2, data={'LR': lr, 'STD_increment': 0.01},
+                         initial_LR=0.1, batch_size=B)
+        zo.optimize()                       # warm-up (2 iterations)
+        zo.max_iters = a.steps
+        sync(); t0 = time.perf_counter()
+        zo.optimize()
+        sync(); dt = (time.perf_counter() - t0) / a.steps
+        if D.rank() == 0:
+            print('c4 Z search (RRDB-%d x4 + CEM, %d Z samples of 512x512 over %d GPU(s)): %.1f ms/iteration, %.2f Z-iterations/s, loss %.3e -> %.3e, peak %.1f GB'
+                  % (a.nb, B, D.world_size(), dt * 1e3, B / dt, zo.loss_values[0], zo.loss_values[-1], torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+if __name__ == '__main__':
+    main()
