@@ -183,7 +183,7 @@ def main():
                          'mfma_bf16_issue_frac_of_measured_1.79PF': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
             cb, xs, ys = cpu_baseline(G, cem)
             out['cpu_baseline'] = cb
             with torch.no_grad():
