@@ -9,57 +9,61 @@ import functools
 
 import torch
 import torch.nn as nn
-from torch.nn import init
 
 import models.modules.architecture as arch
 
 
+_WEIGHTED = (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)
+
+
+def _is_cem_filter(m):
+    """CEM taps are constants and keep their values (reference networks.py:29-31 checks the same marker attribute)."""
+    return bool(getattr(m, 'filter_layer', False))
+
+
+def _init_module(m, kind, scale=1.0, std=0.02):
+    """One module's initialisation; semantics of the reference's weights_init_{normal,kaiming,orthogonal} (networks.py:14-60):
+    conv / linear weights drawn per `kind` (kaiming: fan_in normal, then * scale), biases zero, BatchNorm affine = identity
+    (weight ~ N(1, std) for 'normal')."""
+    if isinstance(m, _WEIGHTED):
+        if kind == 'kaiming' and _is_cem_filter(m):
+            return
+        with torch.no_grad():
+            if kind == 'normal':
+                m.weight.normal_(0.0, std)
+            elif kind == 'kaiming':
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in')
+                m.weight.mul_(scale)
+            else:
+                nn.init.orthogonal_(m.weight, gain=1)
+            if m.bias is not None:
+                m.bias.zero_()
+    elif isinstance(m, nn.BatchNorm2d):
+        with torch.no_grad():
+            if kind == 'normal':
+                m.weight.normal_(1.0, std)
+            else:
+                m.weight.fill_(1.0)
+            m.bias.zero_()
+
+
 def weights_init_normal(m, std=0.02):
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1 or classname.find('Linear') != -1:
-        init.normal_(m.weight.data, 0.0, std)
-        if m.bias is not None:
-            m.bias.data.zero_()
-    elif classname.find('BatchNorm2d') != -1:
-        init.normal_(m.weight.data, 1.0, std)
-        init.constant_(m.bias.data, 0.0)
+    _init_module(m, 'normal', std=std)
 
 
 def weights_init_kaiming(m, scale=1):
-    if 'filter_layer' in m.__dict__ and m.__getattribute__('filter_layer'):
-        return      # CEM taps are constants (reference networks.py:29-31)
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1 or classname.find('Linear') != -1:
-        init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
-        m.weight.data *= scale
-        if m.bias is not None:
-            m.bias.data.zero_()
-    elif classname.find('BatchNorm2d') != -1:
-        init.constant_(m.weight.data, 1.0)
-        init.constant_(m.bias.data, 0.0)
+    _init_module(m, 'kaiming', scale=scale)
 
 
 def weights_init_orthogonal(m):
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1 or classname.find('Linear') != -1:
-        init.orthogonal_(m.weight.data, gain=1)
-        if m.bias is not None:
-            m.bias.data.zero_()
-    elif classname.find('BatchNorm2d') != -1:
-        init.constant_(m.weight.data, 1.0)
-        init.constant_(m.bias.data, 0.0)
+    _init_module(m, 'orthogonal')
 
 
 def init_weights(net, init_type='kaiming', scale=1, std=0.02):
-    print('initialization method [{:s}]'.format(init_type))
-    if init_type == 'normal':
-        net.apply(functools.partial(weights_init_normal, std=std))
-    elif init_type == 'kaiming':
-        net.apply(functools.partial(weights_init_kaiming, scale=scale))
-    elif init_type == 'orthogonal':
-        net.apply(weights_init_orthogonal)
-    else:
+    if init_type not in ('normal', 'kaiming', 'orthogonal'):
         raise NotImplementedError('initialization method [{:s}] not implemented'.format(init_type))
+    print('initialization method [{:s}]'.format(init_type))
+    net.apply(functools.partial(_init_module, kind=init_type, scale=scale, std=std))
 
 
 def define_G(opt, CEM=None, num_latent_channels=None, **kwargs):
