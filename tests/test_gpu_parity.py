@@ -220,3 +220,19 @@ def test_c5_style_x8_blurry_kernel_eval_forward(precision, tol):
     back = co.downscale_op(y, t)
     assert float((back - x)[..., 3:-3, 3:-3].abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
     imresize.kernels = {}
+
+
+def test_hip_graph_replay_is_bit_identical():
+    """esr_hip.graph.GraphedForward: the whole CEM-wrapped forward captured into a HIP graph replays to the same bits, follows new
+    inputs, and is re-captured after a parameter update."""
+    import CEM.CEMnet as C
+    from esr_hip.graph import GraphedForward
+    G = _cem(4, None, None).WrapArchitecture_PyTorch(_rrdb(1, 4, 0)).to(DEV).eval()
+    fast = GraphedForward(G)
+    xs = [seeded_uniform((1, 3, 16, 20), 400 + i).to(DEV) for i in range(3)]
+    with torch.no_grad():
+        for x in xs:
+            assert torch.equal(G(x), fast(x))
+        for p in G.generated_image_model.parameters():
+            p.mul_(0.5)
+        assert torch.equal(G(xs[0]), fast(xs[0]))
