@@ -203,10 +203,14 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
     }
 }
 
-// One output tile per workgroup, single LDS stage, 2-3 workgroups resident per CU: latency hiding comes from the co-resident
-// workgroups instead of an in-workgroup pipeline (the persistent multi-stage variant measured slower).
-template <int NPL, int MT, int EPI>
-__global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3_tile_kernel(const ConvArgs a) {
+// One output tile per workgroup.
+//   NST == 1: single LDS stage, 2 workgroups resident per CU: latency hiding comes from the co-resident workgroup instead of an
+//             in-workgroup pipeline (the persistent multi-stage variant measured slower).  Large launches.
+//   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
+//             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
+//             and nobody else covers its DMA waits.
+template <int NPL, int MT, int EPI, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
     const int plane_bytes = a.NPIX_L * 16;
     constexpr int NWI = 9 * MT * NPL;
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    float* const s_bias = (float*)(smem + stage_bytes);
+    float* const s_bias = (float*)(smem + NST * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
-    const unsigned char* const sb = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
-    const unsigned char* const sa = smem + 2 * NPL * plane_bytes + lane * 16;
+    const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
+    const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
 #ifdef ESR_ABL_TERMS
     constexpr int NTERM = NPL == 2 ? ESR_ABL_TERMS : 1;   // ablation build: wrong results, timing only
 #else
@@ -252,21 +256,42 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
     constexpr int NM = MT * R * NTERM;
     constexpr int NL = (MT + R) * NPL;
     constexpr int NSLOT = NM > NL ? NM : NL;
-    for (int cp = 0; cp < a.ncp; ++cp) {
-        const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
-        ESR_TR();
+    if (NST == 2) {                           // prologue: chunk 0 -> stage 0
+        const Bases<NPL> bs = make_bases<NPL, MT>(a, 0, fs.b, lane);
 #pragma unroll
-        for (int op = 0; op < NOPS; ++op) {
+        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+    }
+    for (int cp = 0; cp < a.ncp; ++cp) {
+        const int st = NST == 2 ? (cp & 1) : 0;
+        const unsigned char* const sb = sb0 + st * stage_bytes;
+        const unsigned char* const sa = sa0 + st * stage_bytes;
+        ESR_TR();
+        if (NST == 1) {
+            const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) {
 #ifdef ESR_ABL_NOWDMA
-            if (op >= NACT && cp > 0) continue;
+                if (op >= NACT && cp > 0) continue;
 #endif
 #ifdef ESR_ABL_NOADMA
-            if (op < NACT && cp > 0) continue;
+                if (op < NACT && cp > 0) continue;
 #endif
-            dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+                dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+            }
+            ESR_TR();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (cp + 1 < a.ncp) {
+            // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
+            // everything EXCEPT the NOPS copies just issued (every wave issues exactly NOPS per chunk, see dma_op / setup_tile)
+            const Bases<NPL> bs = make_bases<NPL, MT>(a, cp + 1, fs.b, lane);
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave);
+            ESR_TR();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS) : "memory");
+        } else {
+            ESR_TR();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        ESR_TR();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ESR_TR();
         __syncthreads();
         ESR_TR();
@@ -310,7 +335,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? WGS_MT1 : WGS_MT2) void conv3x3
                     if (og != mg) continue;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const unsigned char* const pr = smem + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
+                        const unsigned char* const pr = smem + st * stage_bytes + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
                         const uint2 h = *(const uint2*)pr;
                         float x0 = bf2f(h.x & 0xFFFF), x1 = __uint_as_float(h.x & 0xFFFF0000u), x2 = bf2f(h.y & 0xFFFF), x3 = __uint_as_float(h.y & 0xFFFF0000u);
                         if (NPL == 2) {
@@ -563,20 +588,30 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI>
-int launch(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI>;
+template <int NPL, int MT, int EPI, int NST>
+int launch_nst(const ConvArgs& a, hipStream_t s) {
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const size_t lds = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPL * 1024 + (size_t)MT * 32 * 4;
+    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPL * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
+}
+
+template <int NPL, int MT, int EPI>
+int launch(const ConvArgs& a, hipStream_t s) {
+    // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
+    // geometry is chosen for two resident single-stage workgroups)
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
+    const bool two = force ? force == 2 : ntiles <= 320;
+    return two ? launch_nst<NPL, MT, EPI, 2>(a, s) : launch_nst<NPL, MT, EPI, 1>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
