@@ -68,6 +68,98 @@ __global__ void cem_lrfilter_kernel(const float* __restrict__ x, int h, int w, c
     out[idx] = acc;
 }
 
+// ---- LDS-tiled versions of the two filters with many taps per output (k = 17..45: 300-2000 MACs per output pixel).
+// The per-thread global-memory versions above re-read every input ~k^2 times through L1/L2 and run at ~1/60 of the VALU rate; here a
+// workgroup stages the (replicate-clamped) input window once, every inner-loop operand is a conflict-free ds_read_b32 plus a
+// wave-uniform tap that lives in SGPRs, and each thread carries several independent accumulators.
+
+constexpr int LT_TY = 16, LT_TX = 64;     // lrfilter output tile: 16 rows x 64 columns, 4 outputs (x, x+16, x+32, x+48) per thread
+
+__global__ __launch_bounds__(256) void cem_lrfilter_tiled_kernel(const float* __restrict__ x, int h, int w, const float* __restrict__ taps, int k,
+                                                               float* __restrict__ out, int pitch) {
+    extern __shared__ float tile[];          // (LT_TY + k - 1) rows x pitch; pitch % 32 == 16: two rows of 16 lanes hit disjoint banks
+    const int p = k / 2;
+    const int x0 = blockIdx.x * LT_TX, y0 = blockIdx.y * LT_TY;
+    const long long bc = blockIdx.z;
+    const float* src = x + bc * h * (long long)w;
+    const int rows = LT_TY + k - 1, cols = LT_TX + k - 1;
+    for (int e = threadIdx.x; e < rows * cols; e += 256) {
+        const int r = e / cols, c = e - r * cols;
+        tile[r * pitch + c] = src[(long long)clampi(y0 + r - p, 0, h - 1) * w + clampi(x0 + c - p, 0, w - 1)];
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int a = 0; a < k; ++a) {
+        const float* row = tile + (ty + a) * pitch + tx;
+        const float* tr = taps + a * k;
+        for (int c = 0; c < k; ++c) {
+            const float t = tr[c];
+            a0 = fmaf(t, row[c], a0);
+            a1 = fmaf(t, row[c + 16], a1);
+            a2 = fmaf(t, row[c + 32], a2);
+            a3 = fmaf(t, row[c + 48], a3);
+        }
+    }
+    const int Y = y0 + ty;
+    if (Y < h) {
+        float* o = out + (bc * h + Y) * (long long)w + x0 + tx;
+        if (x0 + tx < w) o[0] = a0;
+        if (x0 + tx + 16 < w) o[16] = a1;
+        if (x0 + tx + 32 < w) o[32] = a2;
+        if (x0 + tx + 48 < w) o[48] = a3;
+    }
+}
+
+constexpr int DT = 16;                       // downscale output tile: 16 x 16 low-resolution pixels, one per thread
+
+// The input window is stored de-interleaved by column phase — plane[col % sf][row][col / sf] — so that for a given tap the 16 lanes of
+// an output row (input columns sf apart) read consecutive words; qpitch % 8 == 4 for sf = 4 (sf * qpitch % 32 == 16) spreads the rows.
+__global__ __launch_bounds__(256) void cem_downscale_tiled_kernel(const float* __restrict__ y, int h, int w, int sf, int pre, const float* __restrict__ taps,
+                                                                int k, const float* __restrict__ lr, int lr_pad, float* __restrict__ d, int qpitch,
+                                                                int rows) {
+    extern __shared__ float tile[];          // [sf][rows][qpitch]
+    const int p = k / 2, Hh = h * sf, Wh = w * sf;
+    const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
+    const long long bc = blockIdx.z;
+    const float* src = y + bc * Hh * (long long)Wh;
+    const int Yb = sf * i0 + pre - p, Xb = sf * j0 + pre - p;        // window origin in the high-resolution frame
+    const int cols = (DT - 1) * sf + k;
+    const int lg = (sf & (sf - 1)) == 0 ? __builtin_ctz(sf) : -1;    // power-of-two factors: shifts instead of divisions
+    for (int r = threadIdx.x >> 6; r < rows; r += 4) {               // a wave per row: coalesced reads, no index divisions
+        const float* grow = src + (long long)clampi(Yb + r, 0, Hh - 1) * Wh;
+        for (int c = threadIdx.x & 63; c < cols; c += 64) {
+            const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+            tile[(ph * rows + r) * qpitch + q] = grow[clampi(Xb + c, 0, Wh - 1)];
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int a = 0; a < k; ++a) {
+        const float* tr = taps + a * k;
+        const int r = ty * sf + a;
+        for (int ph = 0; ph < sf; ++ph) {     // taps of one column phase: consecutive words of that phase's plane, no index divisions
+            const float* pl = tile + (ph * rows + r) * qpitch + tx;
+            int c = ph, q = 0;
+            for (; c + sf < k; c += 2 * sf, q += 2) {
+                acc0 = fmaf(tr[c], pl[q], acc0);
+                acc1 = fmaf(tr[c + sf], pl[q + 1], acc1);
+            }
+            if (c < k) acc0 = fmaf(tr[c], pl[q], acc0);
+        }
+    }
+    const int i = i0 + ty, j = j0 + tx;
+    if (i < h && j < w) {
+        float acc = acc0 + acc1;
+        if (lr) {
+            const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
+            acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
+        }
+        d[(bc * h + i) * (long long)w + j] = acc;
+    }
+}
+
 template <bool TWO>
 __global__ void cem_upscale_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf, int pre,
                                    const float* __restrict__ taps, int k, const float* __restrict__ g, int crop, int mode, float range,
@@ -121,6 +213,83 @@ __global__ void cem_upscale_kernel(const float* __restrict__ f, const float* __r
     out[idx] = r;
 }
 
+constexpr int UT_Y = 16, UT_X = 64;          // upscale output tile: 16 x 64 high-resolution pixels, 4 rows per wave, one pixel per thread
+
+// Same arithmetic and edge rules as cem_upscale_kernel (polyphase: only taps that land on a sample; the replicate pad of the
+// zero-stuffed image replicates a sample column only when pre == 0), with the low-resolution window and the taps staged in LDS and
+// the per-tap index divisions replaced by increments.
+template <bool TWO>
+__global__ __launch_bounds__(256) void cem_upscale_tiled_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf, int pre,
+                                                              const float* __restrict__ taps, int k, const float* __restrict__ g, int crop, int mode,
+                                                              float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc) {
+    extern __shared__ float sm[];             // taps [k*k] | window 1 [wr][wc] | window 2 [wr][wc]
+    float* const st = sm;
+    float* const w1 = sm + k * k;
+    float* const w2 = w1 + wr * wc;
+    const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
+    const long long bc = blockIdx.z;
+    const int xo0 = blockIdx.x * UT_X, yo0 = blockIdx.y * UT_Y;
+    // low-resolution window origin: the first sample any output of the tile can touch (floor division, may be negative)
+    const int fy = yo0 + crop - p - pre, fx = xo0 + crop - p - pre;
+    const int ib = (fy >= 0 ? fy / sf : -((-fy + sf - 1) / sf)), jb = (fx >= 0 ? fx / sf : -((-fx + sf - 1) / sf));
+    for (int e = threadIdx.x; e < k * k; e += 256) st[e] = taps[e];
+    const float* s1 = f + bc * h * (long long)w;
+    const float* s2 = TWO ? f2 + bc * h * (long long)w : nullptr;
+    for (int e = threadIdx.x; e < wr * wc; e += 256) {
+        const int r = e / wc, c = e - r * wc;
+        const int i = ib + r, j = jb + c;
+        const bool in = i >= 0 && i < h && j >= 0 && j < w;
+        w1[e] = in ? s1[(long long)i * w + j] : 0.f;
+        if (TWO) w2[e] = in ? s2[(long long)i * w + j] : 0.f;
+    }
+    __syncthreads();
+    const int xo = xo0 + (threadIdx.x & 63), yo = yo0 + (threadIdx.x >> 6);
+#pragma unroll 1
+    for (int rr = 0; rr < UT_Y; rr += 4) {
+        const int yq = yo + rr;
+        if (xo >= Wo || yq >= Ho) continue;
+        const int Y = yq + crop, X = xo + crop;
+        float u1 = 0.f, u2 = 0.f;
+        int a0 = (pre + p - Y) % sf; if (a0 < 0) a0 += sf;
+        int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
+        const int jfirst = (X + b0 - p - pre) / sf - jb;          // exact: X + b0 - p == pre (mod sf); may be negative only outside the frame
+        auto row_accum = [&](int a, int il) {                     // il: window row
+            const float* tr = st + a * k;
+            const float* r1 = w1 + il * wc;
+            const float* r2 = w2 + il * wc;
+            int jl = jfirst;
+            for (int b = b0; b < k; b += sf, ++jl) {
+                const int xx = X + b - p;
+                if (xx < 0 || xx >= Wh) continue;
+                u1 = fmaf(tr[b], r1[jl], u1);
+                if (TWO) u2 = fmaf(tr[b], r2[jl], u2);
+            }
+            if (pre == 0) {
+                for (int b = 0; X + b - p < 0 && b < k; ++b) {
+                    u1 = fmaf(tr[b], r1[-jb], u1);                // sample column 0
+                    if (TWO) u2 = fmaf(tr[b], r2[-jb], u2);
+                }
+            }
+        };
+        int il = (Y + a0 - p - pre) / sf - ib;
+        for (int a = a0; a < k; a += sf, ++il) {
+            const int yy = Y + a - p;
+            if (yy < 0 || yy >= Hh) continue;
+            row_accum(a, il);
+        }
+        if (pre == 0)
+            for (int a = 0; Y + a - p < 0 && a < k; ++a) row_accum(a, -ib);
+        const long long go = (bc * Hh + Y) * (long long)Wh + X;
+        const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
+        float r;
+        if (mode == 0) r = u1;
+        else if (mode == 1) r = g[go] + u1;
+        else if (mode == 2) r = u1 + tanhf(g[go] - u2) * range;
+        else { r = u1; out2[idx] = g[go] - u2; }
+        out[idx] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k, const float* lr,
@@ -129,6 +298,21 @@ extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int
     if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
     const long long total = (long long)B * C * h * w;
     ESR_CLEAR_ERR();
+    {
+        const int rows = (DT - 1) * sf + k, qcols = (rows + sf - 1) / sf + 1;
+        int qpitch = qcols;
+        while ((sf * qpitch) % 32 != 16 && qpitch < qcols + 32) ++qpitch;      // rows of 16 lanes on disjoint banks (possible for sf = 2^n <= 16)
+        if ((sf * qpitch) % 32 != 16) qpitch = qcols | 1;
+        const size_t lds = (size_t)sf * rows * qpitch * 4;
+        if (lds <= 150 * 1024 && (long long)B * C <= 65535) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)cem_downscale_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(cem_downscale_tiled_kernel, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w,
+                               sf, pre, taps, k, lr, lr_pad, d, qpitch, rows);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
     hipLaunchKernelGGL(cem_downscale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, h, w, sf, pre, taps, k,
                        lr, lr_pad, d, total);
     ESR_CHECK_LAUNCH();
@@ -139,6 +323,19 @@ extern "C" int esr_cem_lrfilter(const float* x, int B, int C, int h, int w, cons
     if (!x || !taps || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || k < 1 || !(k & 1)) return ESR_E_ARG;
     const long long total = (long long)B * C * h * w;
     ESR_CLEAR_ERR();
+    {
+        int pitch = LT_TX + k - 1;
+        pitch += (16 - pitch % 32 + 32) % 32;                                   // pitch % 32 == 16
+        const size_t lds = (size_t)(LT_TY + k - 1) * pitch * 4;
+        if (lds <= 150 * 1024 && (long long)B * C <= 65535) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)cem_lrfilter_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(cem_lrfilter_tiled_kernel, dim3((w + LT_TX - 1) / LT_TX, (h + LT_TY - 1) / LT_TY, B * C), dim3(256), lds, (hipStream_t)stream,
+                               x, h, w, taps, k, out, pitch);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
     hipLaunchKernelGGL(cem_lrfilter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, h, w, taps, k, out,
                        total);
     ESR_CHECK_LAUNCH();
@@ -155,6 +352,23 @@ extern "C" int esr_cem_upscale(const float* f, const float* f2, int B, int C, in
     const long long total = (long long)B * C * (h * sf - 2 * crop) * (w * sf - 2 * crop);
     const dim3 grid((unsigned)((total + 255) / 256));
     ESR_CLEAR_ERR();
+    {
+        // low-resolution window of one 16 x 64 output tile: every sample within +-p of it
+        const int wr = (UT_Y + 2 * (k / 2)) / sf + 3, wc = (UT_X + 2 * (k / 2)) / sf + 3;
+        const size_t lds = ((size_t)k * k + (size_t)(mode >= 2 ? 2 : 1) * wr * wc + (mode >= 2 ? 0 : 0)) * 4 + (mode >= 2 ? 0 : (size_t)wr * wc * 4);
+        const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
+        if (lds <= 60 * 1024 && (long long)B * C <= 65535) {
+            const dim3 tg((Wo + UT_X - 1) / UT_X, (Ho + UT_Y - 1) / UT_Y, B * C);
+            if (mode >= 2)
+                hipLaunchKernelGGL(cem_upscale_tiled_kernel<true>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode,
+                                   range, out, out2, wr, wc);
+            else
+                hipLaunchKernelGGL(cem_upscale_tiled_kernel<false>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode,
+                                   range, out, out2, wr, wc);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
     if (mode >= 2)
         hipLaunchKernelGGL(cem_upscale_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode, range,
                            out, out2, total);
