@@ -29,9 +29,15 @@
 
 namespace {
 
-constexpr int NW = 4;          // waves per workgroup
-constexpr int NTHREADS = 256;
-constexpr int MAXS = 3;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+#ifndef ESR_NW
+#define ESR_NW 4
+#endif
+#ifndef ESR_MAXS
+#define ESR_MAXS 3
+#endif
+constexpr int NW = ESR_NW;     // waves per workgroup
+constexpr int NTHREADS = 64 * NW;
+constexpr int MAXS = ESR_MAXS;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
 // Measured on MI355X (RRDB-23 forward, ms): MT1/MT2 resident workgroups 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is
 // power-limited under this kernel: beyond the overlap that reaches the power cap, more resident waves cost clock.
 #ifndef ESR_WGS_MT1
