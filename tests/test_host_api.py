@@ -269,3 +269,30 @@ def test_z_optimizer_loop_logic():
     oz = Optimizable_Z([2, 1, 4, 4], Z_range=0.5, device='cpu')
     oz.Z.data.fill_(100.)
     assert float(oz().max()) <= 0.5
+
+
+def test_cabi_argument_validation_without_a_gpu():
+    """Error behaviour of the C-ABI (include/esr_hip.h: 0 on success, negative ESR_E_* otherwise, never throws): bad descriptors are
+    rejected by the host-side checks before anything touches a device, so this runs on the CPU-only box."""
+    import ctypes as C
+    from esr_hip import _lib
+    h = _lib.load_library()
+    E_ARG, E_UNSUPPORTED = -1, -2
+    assert h.esr_conv3x3(None, None) == E_ARG
+    d = _lib.Conv3x3Desc()                                   # all-zero descriptor: no input view, no weights
+    assert h.esr_conv3x3(C.byref(d), None) == E_ARG
+    assert h.esr_pack_conv_weights(None, 32, 64, None, 8, None, 1, 0, 1, 1.0, None, None) == E_ARG
+    assert h.esr_pack_nchw(None, 0, 1, 3, 8, 8, 0, 3, 0, 1, None, None) < 0
+    assert h.esr_cem_downscale(None, 1, 3, 8, 8, 4, 1, None, 17, None, 0, None, None) == E_ARG
+    assert h.esr_cem_lrfilter(None, 1, 3, 8, 8, None, 27, None, None) == E_ARG
+    assert h.esr_cem_upscale(None, None, 1, 3, 8, 8, 4, 1, None, 17, None, 0, 0, 0.0, None, None, None) == E_ARG
+    w = _lib.WgradDesc()
+    assert h.esr_conv3x3_wgrad(C.byref(w), None) == E_ARG
+    assert h.esr_conv3x3_wgrad_workspace_floats(C.byref(w)) == E_ARG
+    assert h.esr_conv3x3_wgrad_batch(None, 0, None, 0, None) == E_ARG
+    assert h.esr_pack_batch_run(None, 0, 0, None) == E_ARG
+    # sizes are pure host arithmetic
+    assert h.esr_conv_wpack_bytes(24, 64, 1) == 12 * 9 * 2 * 2 * 1024 and h.esr_conv_wpack_bytes(8, 32, 0) == 4 * 9 * 1 * 1 * 1024
+    w.B, w.H, w.W, w.cout, w.cin_main = 2, 16, 40, 64, 192   # 2 images x (2 x 2) tiles of 8x32 pixels; 6 input tiles x 2 output tiles
+    n = h.esr_conv3x3_wgrad_workspace_floats(C.byref(w))
+    assert n == 12 * 8 * 9 * 1024 + 2 * 8 * 32               # every tile its own slice (8), 9 x 32 x 32 partial block + bias partials
