@@ -21,12 +21,20 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) 
     lo = f2bf(x - bf2f(hi));
 }
 
+// fp16 element <-> float (round to nearest even)
+__device__ __forceinline__ uint32_t f2h(float x) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+// 16-bit element of format FMT (0 bf16, 1 f16) <-> float
+template <int FMT> __device__ __forceinline__ float e2f(uint32_t e) { return FMT ? h2f(e) : bf2f(e); }
+template <int FMT> __device__ __forceinline__ uint32_t f2e(float x) { return FMT ? f2h(x) : f2bf(x); }
+
 // device-side mirror of esr_act_view (strides in 16-byte vectors)
 struct DView {
     const uint4* hi;
     const uint4* lo;
     long long bs, cs;
     int ncg;
+    int fmt;
 };
 
 static inline DView to_dview(const esr_act_view& v) {
@@ -36,6 +44,7 @@ static inline DView to_dview(const esr_act_view& v) {
     d.bs = v.batch_stride;
     d.cs = v.cg_stride;
     d.ncg = v.hi ? v.ncg : 0;
+    d.fmt = v.fmt;
     return d;
 }
 

@@ -74,9 +74,15 @@ struct ConvArgs {
 #endif
 };
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int FMT>
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+    if (FMT) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// two floats -> packed 16-bit pair of format FMT (round to nearest even); low half = first argument
+template <int FMT>
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi);
 
 // two floats -> packed bf16x2 (round to nearest even); low half = first argument
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -84,6 +90,8 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+template <> __device__ __forceinline__ uint32_t cvt_pk<0>(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t cvt_pk<1>(float lo, float hi) { return f2h(lo) | (f2h(hi) << 16); }
 
 // Asynchronous global -> LDS copy, 16 bytes per lane: LDS destination = (wave-uniform) lds_dst + lane*16.
 // Issued through inline asm on purpose: hipcc treats the builtin form as a pending LDS write and drains vmcnt(0) in front of
@@ -191,20 +199,21 @@ __device__ __forceinline__ void swap_halves(const uint4& x, uint32_t (&d)[2][2])
     const auto s1 = __builtin_amdgcn_permlane32_swap(x.y, x.w, false, false);
     d[0][0] = s0[0]; d[0][1] = s1[0]; d[1][0] = s0[1]; d[1][1] = s1[1];
 }
+template <int FMT>
 __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (&rv)[2][4]) {
     uint32_t d[2][2];
     swap_halves(q.h, d);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        rv[k][0] = bf2f(d[k][0] & 0xFFFF); rv[k][1] = __uint_as_float(d[k][0] & 0xFFFF0000u);
-        rv[k][2] = bf2f(d[k][1] & 0xFFFF); rv[k][3] = __uint_as_float(d[k][1] & 0xFFFF0000u);
+        rv[k][0] = e2f<FMT>(d[k][0] & 0xFFFF); rv[k][1] = e2f<FMT>(d[k][0] >> 16);
+        rv[k][2] = e2f<FMT>(d[k][1] & 0xFFFF); rv[k][3] = e2f<FMT>(d[k][1] >> 16);
     }
     if (has_lo) {
         swap_halves(q.l, d);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            rv[k][0] += bf2f(d[k][0] & 0xFFFF); rv[k][1] += __uint_as_float(d[k][0] & 0xFFFF0000u);
-            rv[k][2] += bf2f(d[k][1] & 0xFFFF); rv[k][3] += __uint_as_float(d[k][1] & 0xFFFF0000u);
+            rv[k][0] += e2f<FMT>(d[k][0] & 0xFFFF); rv[k][1] += e2f<FMT>(d[k][0] >> 16);
+            rv[k][2] += e2f<FMT>(d[k][1] & 0xFFFF); rv[k][3] += e2f<FMT>(d[k][1] >> 16);
         }
     }
 }
@@ -215,8 +224,9 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
-template <int NPL, int MT, int EPI, int NST>
+template <int NPL, int MT, int EPI, int NST, int FMT>
 __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
+    static_assert(FMT == 0 || NPL == 1, "f16 is a single-plane format");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                 if (i < NM) {
                     const int term = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
                     const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
-                    acc[m][r] = mfma(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+                    acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
                 }
 #ifdef ESR_ABL_NOLDS
                 if (t < 8 && i < NL && cp == 0) load_frag(t + 1, i, cb ^ 1);
@@ -343,10 +353,10 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                     for (int r = 0; r < R; ++r) {
                         const unsigned char* const pr = smem + st * stage_bytes + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
                         const uint2 h = *(const uint2*)pr;
-                        float x0 = bf2f(h.x & 0xFFFF), x1 = __uint_as_float(h.x & 0xFFFF0000u), x2 = bf2f(h.y & 0xFFFF), x3 = __uint_as_float(h.y & 0xFFFF0000u);
+                        float x0 = e2f<FMT>(h.x & 0xFFFF), x1 = e2f<FMT>(h.x >> 16), x2 = e2f<FMT>(h.y & 0xFFFF), x3 = e2f<FMT>(h.y >> 16);
                         if (NPL == 2) {
                             const uint2 l = *(const uint2*)(pr + plane_bytes);
-                            x0 += bf2f(l.x & 0xFFFF); x1 += __uint_as_float(l.x & 0xFFFF0000u); x2 += bf2f(l.y & 0xFFFF); x3 += __uint_as_float(l.y & 0xFFFF0000u);
+                            x0 += e2f<FMT>(l.x & 0xFFFF); x1 += e2f<FMT>(l.x >> 16); x2 += e2f<FMT>(l.y & 0xFFFF); x3 += e2f<FMT>(l.y >> 16);
                         }
                         acc[mg / 4][r][(mg % 4) * 4 + 0] = fmaf(a.resin_scale, x0, acc[mg / 4][r][(mg % 4) * 4 + 0]);
                         acc[mg / 4][r][(mg % 4) * 4 + 1] = fmaf(a.resin_scale, x1, acc[mg / 4][r][(mg % 4) * 4 + 1]);
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                         }
                         if constexpr (HAS_R1) {
                             float rv[2][4];
-                            res_unpack(q1[m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
+                            res_unpack<FMT>(q1[m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                         }
                         if constexpr (HAS_R2) {
                             float rv[2][4];
-                            res_unpack(q2[m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
+                            res_unpack<FMT>(q2[m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                                 if (ch0 + i >= a.cout) v[k][i] = 0.f;     // channels past cout stay zero in the buffer
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
-                                const uint32_t h = cvt_pk_bf16(v[k][2 * j], v[k][2 * j + 1]);
+                                const uint32_t h = cvt_pk<FMT>(v[k][2 * j], v[k][2 * j + 1]);
                                 hi[k][j] = h;
                                 lo[k][j] = 0;
                                 if (NPL == 2)
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 
 // ---- weight packing: [M][K][3][3] fp32 -> [kstep = cp*9+tap][mtile][hi|lo][lane][8] bf16
 __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int dim1, const int* __restrict__ kmap, int ncg_in,
-                                    const int* __restrict__ mmap, int mtiles, int transposed, int npl, float scale, uint4* __restrict__ out, int total) {
+                                    const int* __restrict__ mmap, int mtiles, int transposed, int npl, int f16, float scale, uint4* __restrict__ out, int total) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (kstep, mtile, lane)
     if (idx >= total) return;
     const int lane = idx & 63;
@@ -518,7 +528,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
         float v = 0.f;
         if (kch >= 0 && mch >= 0)
             v = transposed ? w[((long long)kch * dim1 + mch) * 9 + (8 - t)] : w[((long long)mch * dim1 + kch) * 9 + t];
-        split_bf16(v * scale, hi[e], lo[e]);
+        if (f16) { hi[e] = f2h(v * scale); lo[e] = 0; }
+        else split_bf16(v * scale, hi[e], lo[e]);
     }
     uint4* o = out + ((size_t)(ks * mtiles + m) * npl) * 64 + lane;
     o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
@@ -528,7 +539,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
 // many weight tensors in one launch: block b packs entry map[b].x, elements map[b].y*256 .. (a training step re-packs every layer)
 struct PackEntry {
     const float* w; const int* kmap; const int* mmap; uint4* out;
-    int dim0, dim1, ncg_in, mtiles, transposed, npl, total; float scale;
+    int dim0, dim1, ncg_in, mtiles, transposed, npl, f16, total; float scale;
 };
 __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ table, const int2* __restrict__ map) {
     const int2 m = map[blockIdx.x];
@@ -548,7 +559,8 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ table, c
         float v = 0.f;
         if (kch >= 0 && mch >= 0)
             v = e.transposed ? e.w[((long long)kch * e.dim1 + mch) * 9 + (8 - t)] : e.w[((long long)mch * e.dim1 + kch) * 9 + t];
-        split_bf16(v * e.scale, hi[c], lo[c]);
+        if (e.f16) { hi[c] = f2h(v * e.scale); lo[c] = 0; }
+        else split_bf16(v * e.scale, hi[c], lo[c]);
     }
     uint4* o = e.out + ((size_t)(ks * e.mtiles + mt) * e.npl) * 64 + lane;
     o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
@@ -594,9 +606,9 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI, int NST>
+template <int NPL, int MT, int EPI, int NST, int FMT>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -610,29 +622,41 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI>
+template <int NPL, int MT, int EPI, int FMT>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool two = force ? force == 2 : ntiles <= 320;
-    return two ? launch_nst<NPL, MT, EPI, 2>(a, s) : launch_nst<NPL, MT, EPI, 1>(a, s);
+    return two ? launch_nst<NPL, MT, EPI, 2, FMT>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
-template <int NPL, int MT>
+template <int NPL, int MT, int FMT>
 int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
+    if (FMT == 1) {              // f16: the inference forward only (no data-gradient epilogues)
+        switch (epi) {
+            case 0: return launch<NPL, MT, 0, FMT>(a, s);
+            case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT>(a, s);
+            case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT>(a, s);
+            case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT>(a, s);
+            case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT>(a, s);
+            case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT>(a, s);
+            case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT>(a, s);
+            default: return ESR_E_UNSUPPORTED;
+        }
+    }
     switch (epi) {
-        case 0: return launch<NPL, MT, 0>(a, s);
-        case EPI_RES1: return launch<NPL, MT, EPI_RES1>(a, s);
-        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2>(a, s);
-        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN>(a, s);
-        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2>(a, s);
-        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW>(a, s);
-        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2>(a, s);
-        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK>(a, s);
-        case EPI_MASK: return launch<NPL, MT, EPI_MASK>(a, s);
+        case 0: return launch<NPL, MT, 0, FMT>(a, s);
+        case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT>(a, s);
+        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT>(a, s);
+        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT>(a, s);
+        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT>(a, s);
+        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT>(a, s);
+        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT>(a, s);
+        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT>(a, s);
+        case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
 }
@@ -645,7 +669,7 @@ extern "C" void esr_debug_trace(void* buf) { g_trace = (unsigned long long*)buf;
 
 extern "C" size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split) {
     const int ncp = (ncg_in + 1) / 2, mt = (cout + 31) / 32;
-    return (size_t)ncp * 9 * mt * (split ? 2 : 1) * 64 * 16;
+    return (size_t)ncp * 9 * mt * (split == 1 ? 2 : 1) * 64 * 16;
 }
 
 extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* kmap, int ncg_in, const int32_t* mmap,
@@ -655,7 +679,7 @@ extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, cons
     const int total = ncp * 9 * mtiles * 64;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w, kmap,
-                       ncg_in, mmap, mtiles, transposed, split ? 2 : 1, scale, (uint4*)wpack, total);
+                       ncg_in, mmap, mtiles, transposed, split == 1 ? 2 : 1, split == 2 ? 1 : 0, scale, (uint4*)wpack, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -689,7 +713,7 @@ extern "C" int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void
         PackEntry& e = table[i];
         e.w = descs[i].w; e.kmap = descs[i].kmap; e.mmap = descs[i].mmap; e.out = (uint4*)descs[i].wpack;
         e.dim0 = descs[i].cout_w; e.dim1 = descs[i].cin_w; e.ncg_in = descs[i].ncg_in; e.mtiles = descs[i].mtiles;
-        e.transposed = descs[i].transposed; e.npl = descs[i].split ? 2 : 1; e.scale = descs[i].scale;
+        e.transposed = descs[i].transposed; e.npl = descs[i].split == 1 ? 2 : 1; e.f16 = descs[i].split == 2 ? 1 : 0; e.scale = descs[i].scale;
         e.total = ((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
         for (int j = 0; j < (e.total + 255) / 256; ++j) map[(size_t)b++] = make_int2(i, j);
     }
@@ -719,6 +743,12 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->in1.H * ups != d->H || d->in1.W * ups != d->W) return ESR_E_ARG;
     if (d->in0.hi && (d->in0.H != d->H || d->in0.W != d->W)) return ESR_E_ARG;
     const bool split = d->in1.lo != nullptr;
+    const bool f16 = d->in1.fmt == ESR_FMT_F16;
+    if (f16 && split) return ESR_E_ARG;
+    // one element format per launch
+    if ((d->in0.hi && d->in0.fmt != d->in1.fmt) || (d->out.hi && d->out.fmt != d->in1.fmt) || (d->out2.hi && d->out2.fmt != d->in1.fmt) ||
+        (d->res1.hi && d->res1.fmt != d->in1.fmt) || (d->res2.hi && d->res2.fmt != d->in1.fmt) || (d->mask_src.hi && d->mask_src.fmt != d->in1.fmt))
+        return ESR_E_ARG;
     if (d->in0.hi && ((d->in0.lo != nullptr) != split)) return ESR_E_ARG;
     const int mt = (d->cout + 31) / 32;
     if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches
@@ -781,6 +811,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->out2.hi) epi |= EPI_OUT2;
     if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
-    if (split) return mt == 1 ? launch_epi<2, 1>(a, epi, s) : launch_epi<2, 2>(a, epi, s);
-    return mt == 1 ? launch_epi<1, 1>(a, epi, s) : launch_epi<1, 2>(a, epi, s);
+    if (f16) return mt == 1 ? launch_epi<1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1>(a, epi, s);
+    if (split) return mt == 1 ? launch_epi<2, 1, 0>(a, epi, s) : launch_epi<2, 2, 0>(a, epi, s);
+    return mt == 1 ? launch_epi<1, 1, 0>(a, epi, s) : launch_epi<1, 2, 0>(a, epi, s);
 }

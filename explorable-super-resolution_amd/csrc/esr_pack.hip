@@ -9,7 +9,7 @@ namespace {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ void pack_nchw_kernel(const float* __restrict__ src, long long sbs, int C, int h, int w, int c0, int nc, int pad, int down, uint4* hi,
-                                 uint4* lo, long long bs, long long cs, int ncg, int Hd, int Wd, long long total) {
+                                 uint4* lo, long long bs, long long cs, int ncg, int Hd, int Wd, int fmt, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int Wp = Wd + 2, Hp = Hd + 2;
@@ -42,7 +42,8 @@ __global__ void pack_nchw_kernel(const float* __restrict__ src, long long sbs, i
                 v = (1.f - ly) * ((1.f - lx) * p[r0 + q0] + lx * p[r0 + q1]) + ly * ((1.f - lx) * p[r1 + q0] + lx * p[r1 + q1]);
             }
         }
-        split_bf16(v, vh[e], vl[e]);
+        if (fmt == ESR_FMT_F16) { vh[e] = f2h(v); vl[e] = 0; }
+        else split_bf16(v, vh[e], vl[e]);
     }
     const long long o = b * bs + cg * cs + (long long)Y * Wp + X;
     hi[o] = make_uint4(vh[0] | (vh[1] << 16), vh[2] | (vh[3] << 16), vh[4] | (vh[5] << 16), vh[6] | (vh[7] << 16));
@@ -50,7 +51,7 @@ __global__ void pack_nchw_kernel(const float* __restrict__ src, long long sbs, i
 }
 
 __global__ void unpack_nchw_kernel(const uint4* __restrict__ hi, const uint4* __restrict__ lo, long long bs, long long cs, int H, int W,
-                                   int nc, float* __restrict__ dst, long long total) {
+                                   int nc, float* __restrict__ dst, int fmt, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, cg, y, x)
     if (idx >= total) return;
     const int ncg = (nc + 7) / 8;
@@ -71,7 +72,7 @@ __global__ void unpack_nchw_kernel(const uint4* __restrict__ hi, const uint4* __
         if (ch >= nc) break;
         const uint32_t hb = (e & 1) ? (hw[e >> 1] >> 16) : (hw[e >> 1] & 0xFFFF);
         const uint32_t lb = (e & 1) ? (lw[e >> 1] >> 16) : (lw[e >> 1] & 0xFFFF);
-        dst[((long long)(b * nc + ch) * H + y) * W + x] = bf2f(hb) + bf2f(lb);
+        dst[((long long)(b * nc + ch) * H + y) * W + x] = fmt == ESR_FMT_F16 ? h2f(hb) : bf2f(hb) + bf2f(lb);
     }
 }
 
@@ -89,11 +90,12 @@ extern "C" int esr_pack_nchw(const float* src, int64_t src_batch_stride, int B, 
     if ((h + 2 * pad) % down || (w + 2 * pad) % down) return ESR_E_ARG;
     const int Hd = (h + 2 * pad) / down, Wd = (w + 2 * pad) / down;
     if (dst->H != Hd || dst->W != Wd || dst->ncg * 8 < nc) return ESR_E_ARG;
+    if (dst->fmt == ESR_FMT_F16 && dst->lo) return ESR_E_ARG;      // f16 is a single-plane format
     const long long total = (long long)B * dst->ncg * (Hd + 2) * (Wd + 2);
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long long)(src_batch_stride ? src_batch_stride : (int64_t)C * h * w), C, h, w, c0, nc, pad,
-                       down, (uint4*)dst->hi, (uint4*)dst->lo, (long long)dst->batch_stride, (long long)dst->cg_stride, dst->ncg, Hd, Wd, total);
+                       down, (uint4*)dst->hi, (uint4*)dst->lo, (long long)dst->batch_stride, (long long)dst->cg_stride, dst->ncg, Hd, Wd, dst->fmt, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -103,7 +105,7 @@ extern "C" int esr_unpack_nchw(const esr_act_view* src, int B, int nc, float* ds
     const long long total = (long long)B * ((nc + 7) / 8) * src->H * src->W;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(unpack_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src->hi,
-                       (const uint4*)src->lo, (long long)src->batch_stride, (long long)src->cg_stride, src->H, src->W, nc, dst, total);
+                       (const uint4*)src->lo, (long long)src->batch_stride, (long long)src->cg_stride, src->H, src->W, nc, dst, src->fmt, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -119,4 +121,4 @@ extern "C" int esr_zero(void* p, int64_t n16, esr_stream_t stream) {
     return ESR_OK;
 }
 
-extern "C" int esr_version(void) { return 100; }
+extern "C" int esr_version(void) { return 101; }

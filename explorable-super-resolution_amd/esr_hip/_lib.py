@@ -13,7 +13,7 @@ class EsrError(RuntimeError):
 class ActView(C.Structure):
     """esr_act_view (include/esr_hip.h)."""
     _fields_ = [('hi', C.c_void_p), ('lo', C.c_void_p), ('ncg', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('batch_stride', C.c_int64), ('cg_stride', C.c_int64)]
+                ('batch_stride', C.c_int64), ('cg_stride', C.c_int64), ('fmt', C.c_int32)]
 
 
 class Conv3x3Desc(C.Structure):

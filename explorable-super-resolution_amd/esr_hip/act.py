@@ -17,14 +17,22 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 2 / 'f16' = fp16
+def fmt_code(split):
+    if split in ('f16', 2):
+        return 2
+    return 1 if split else 0
+
+
 class ActBuf:
     """[B][CG][H+2][W+2][8] bf16 `hi` (+ `lo`) planes.  Allocated zeroed, so the 1-pixel border the conv kernels
     rely on is zero from the start; producers never write it."""
 
     def __init__(self, B, ncg, H, W, device, split=True):
         self.B, self.ncg, self.H, self.W, self.split = B, ncg, H, W, split
+        self.code = fmt_code(split)
         self.hi = torch.zeros(B, ncg, H + 2, W + 2, 8, dtype=torch.int16, device=device)
-        self.lo = torch.zeros_like(self.hi) if split else None
+        self.lo = torch.zeros_like(self.hi) if self.code == 1 else None
         self.cg_stride = (H + 2) * (W + 2)
         self.batch_stride = ncg * self.cg_stride
 
@@ -32,11 +40,11 @@ class ActBuf:
         ncg = self.ncg - cg0 if ncg is None else ncg
         assert 0 <= cg0 and cg0 + ncg <= self.ncg
         off = cg0 * self.cg_stride * 16
-        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.split else None, ncg, self.H, self.W,
-                       self.batch_stride, self.cg_stride)
+        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.code == 1 else None, ncg, self.H, self.W,
+                       self.batch_stride, self.cg_stride, 1 if self.code == 2 else 0)
 
     def nbytes(self):
-        return self.hi.numel() * 2 * (2 if self.split else 1)
+        return self.hi.numel() * 2 * (2 if self.code == 1 else 1)
 
     def to_nchw(self, nc, cg0=0):
         """Debug/test helper: unpack channels [cg0*8, cg0*8+nc) to fp32 NCHW."""
@@ -46,7 +54,7 @@ class ActBuf:
         return out
 
 
-NO_VIEW = ActView(None, None, 0, 0, 0, 0, 0)
+NO_VIEW = ActView(None, None, 0, 0, 0, 0, 0, 0)
 
 
 def pack_nchw(src, dst_view, c0, nc, pad=0, down=1, hw=None, batch_stride=0, channels=None):
@@ -118,7 +126,7 @@ class PackedConv:
         if self.wpack is None:
             dev = w.device
             self.kmap, self.mmap = self._maps(dev)
-            nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, 1 if self.split else 0)
+            nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, fmt_code(self.split))
             self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             bp = self.bias_p
             if bp is not None and not self.transposed and bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == self.mtiles * 32:
@@ -154,7 +162,7 @@ class PackedConv:
 def run_pack_jobs(jobs, split):
     for wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst in jobs:
         check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles,
-                                             transposed, 1 if split else 0, float(scale), dst, stream_ptr()), 'esr_pack_conv_weights')
+                                             transposed, fmt_code(split), float(scale), dst, stream_ptr()), 'esr_pack_conv_weights')
 
 
 class PackBatch:
@@ -175,7 +183,7 @@ class PackBatch:
             for d, (wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst) in zip(arr, jobs):
                 d.w, d.cout_w, d.cin_w = wd.data_ptr(), wd.shape[0], wd.shape[1]
                 d.kmap, d.ncg_in, d.mmap, d.mtiles = kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles
-                d.transposed, d.split, d.scale, d.wpack = transposed, 1 if split else 0, float(scale), dst
+                d.transposed, d.split, d.scale, d.wpack = transposed, fmt_code(split), float(scale), dst
             need = _lib.lib.esr_pack_batch_workspace_bytes(arr, len(jobs))
             check(min(need, 0), 'esr_pack_batch_workspace_bytes')
             self.ws = torch.empty(int(need), dtype=torch.uint8, device=jobs[0][0].device)
@@ -221,9 +229,9 @@ class PackedSum:
                 self.maps.append((kmap, mmap, g))
                 g += w.shape[0] // 8
             self.ncg_in = g
-            self.wpack = torch.empty(_lib.lib.esr_conv_wpack_bytes(g, mt * 32, 1 if self.split else 0), dtype=torch.uint8, device=dev)
+            self.wpack = torch.empty(_lib.lib.esr_conv_wpack_bytes(g, mt * 32, fmt_code(self.split)), dtype=torch.uint8, device=dev)
             self.bias = torch.zeros(mt * 32, dtype=torch.float32, device=dev)
-            self.chunk_bytes = _lib.lib.esr_conv_wpack_bytes(2, mt * 32, 1 if self.split else 0)
+            self.chunk_bytes = _lib.lib.esr_conv_wpack_bytes(2, mt * 32, fmt_code(self.split))
         return self
 
     def jobs(self):

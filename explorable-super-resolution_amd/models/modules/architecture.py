@@ -73,8 +73,9 @@ class RRDBNet(nn.Module):
         return self._engine
 
     def set_precision(self, precision):
-        """'split' (default; bf16x3 MFMA, fp32-class accuracy) or 'bf16' (plain bf16 operands, fp32 accumulate)."""
-        assert precision in ('split', 'bf16')
+        """'split' (default; bf16 hi+lo operands, 3 MFMAs per product, fp32-class accuracy), 'bf16' or 'f16' (single-MFMA modes with
+        fp32 accumulation; 'f16' is ~8x more accurate than 'bf16' and inference-only)."""
+        assert precision in ('split', 'bf16', 'f16')
         self.engine.set_precision(precision)
 
     def forward(self, x, pad=0):

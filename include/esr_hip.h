@@ -40,6 +40,12 @@ extern "C" {
 
 typedef void* esr_stream_t;   /* hipStream_t */
 
+/* Element formats of an activation view.  BF16 with a `lo` plane is the fp32-class mode (split operands, 3 MFMAs per product);
+ * BF16 / F16 without `lo` are the single-MFMA reduced-precision modes (the reference has no counterpart; F16 is inference-only:
+ * gradients would need loss scaling).  Weight packs use the matching code in their `split` argument: 0 bf16, 1 split bf16, 2 f16. */
+#define ESR_FMT_BF16 0
+#define ESR_FMT_F16 1
+
 /* A view of `ncg` consecutive channel groups inside an activation buffer. */
 typedef struct {
     void* hi;                /* bf16 planes, NULL = view absent */
@@ -48,6 +54,7 @@ typedef struct {
     int32_t H, W;            /* interior size; the buffer holds (H+2) x (W+2) pixels per group */
     int64_t batch_stride;    /* in 16-byte pixel vectors */
     int64_t cg_stride;       /* in 16-byte pixel vectors (normally (H+2)*(W+2)) */
+    int32_t fmt;             /* element format of the planes: ESR_FMT_BF16 (default; hi [+ lo]) or ESR_FMT_F16 (hi only) */
 } esr_act_view;
 
 /* ---- conv3x3 (+bias, +LeakyReLU, +scaled residuals, + fused nearest upsample of the input) ----
@@ -88,7 +95,7 @@ typedef struct {
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
 
 /* Packed-weight size in bytes for `ncg_in` input groups and `cout` output channels
- * (`split` = 1: hi+lo planes, 0: hi only). */
+ * (`split` = 1: bf16 hi+lo planes; 0: bf16 hi only; 2: f16, one plane). */
 size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split);
 
 /* Pack nn.Conv2d weights [cout_w][cin_w][3][3] (fp32, device) into MFMA fragment order.
