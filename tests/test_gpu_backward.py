@@ -203,3 +203,21 @@ def test_two_forwards_before_backward_keep_their_own_activations():
     g2, = torch.autograd.grad((y2 * y2).sum(), x2)
     g1, = torch.autograd.grad((y1 * y1).sum(), x1)
     assert torch.equal(g1, refs[0]) and torch.equal(g2, refs[1])
+
+
+def test_bf16_mode_backward_is_consistent_with_the_fp32_class_mode():
+    """The single-MFMA 'bf16' mode (BASELINE configs[2] names bf16 for training) runs the same backward plan: its input and weight
+    gradients must agree with the fp32-class mode's to bf16 accuracy (measured: output 1-2 %, gradients up to 9 % in relative L2 with the high-gain formula weights, LeakyReLU sign flips included)."""
+    torch.manual_seed(0)
+    res = {}
+    for prec in ('split', 'bf16'):
+        net = _rrdb(2, 4, 3).to(DEV)
+        net.set_precision(prec)
+        x = _f4_input(2, 4, 3).to(DEV).requires_grad_(True)
+        y = net(x)
+        cot = seeded_uniform(tuple(y.shape), 501, -1.0, 1.0).to(DEV)
+        (y * cot).sum().backward()
+        res[prec] = (y.detach().cpu(), x.grad.cpu(), net.model[0].weight.grad.cpu(), net.model[1].sub[0].RDB2.convs[2][0].weight.grad.cpu())
+    for a, b, name in zip(res['bf16'], res['split'], ('out', 'dx', 'dW fea', 'dW rdb')):
+        assert rel_l2(a.numpy(), b.numpy()) < 0.15, (name, rel_l2(a.numpy(), b.numpy()))
+    assert rel_l2(res['bf16'][0].numpy(), res['split'][0].numpy()) < 2e-2

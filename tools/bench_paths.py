@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--nb', type=int, default=23)
+    ap.add_argument('--precision', default='split', choices=['split', 'bf16'], help="'bf16': single-MFMA operands (C3 names bf16)")
     a = ap.parse_args()
     from esr_hip import dist as D
     D.init_from_env()
@@ -46,6 +47,8 @@ def main():
     dev = torch.device('cuda', torch.cuda.current_device())
     with contextlib.redirect_stdout(io.StringIO()):
         model = models.create_model(make_opt(a.which == 'c3', nb=a.nb))
+    if a.precision != 'split':
+        model.netG.generated_image_model.set_precision(a.precision)
     sync = torch.cuda.synchronize
     if a.which == 'c3':
         B = a.batch or 32
@@ -58,7 +61,7 @@ def main():
             model.feed_data(data); model.optimize_parameters()
         sync(); dt = (time.perf_counter() - t0) / a.steps
         if D.rank() == 0:
-            print('c3 generator step (RRDB-%d x4 + CEM, lat 3, %d x 52x52 per GPU, %d GPU(s)): %.1f ms/step, %.0f LR crops/s, l_g_pix %.4f, peak %.1f GB'
+            print('c3 generator step [' + a.precision + '] (RRDB-%d x4 + CEM, lat 3, %d x 52x52 per GPU, %d GPU(s)): %.1f ms/step, %.0f LR crops/s, l_g_pix %.4f, peak %.1f GB'
                   % (a.nb, B, D.world_size(), dt * 1e3, B * D.world_size() / dt, model.get_current_log()['l_g_pix'], torch.cuda.max_memory_allocated() / 2 ** 30))
     else:
         from Z_optimization import Z_optimizer
@@ -75,7 +78,7 @@ def main():
         zo.optimize()
         sync(); dt = (time.perf_counter() - t0) / a.steps
         if D.rank() == 0:
-            print('c4 Z search (RRDB-%d x4 + CEM, %d Z samples of 512x512 over %d GPU(s)): %.1f ms/iteration, %.2f Z-iterations/s, loss %.3e -> %.3e, peak %.1f GB'
+            print('c4 Z search [' + a.precision + '] (RRDB-%d x4 + CEM, %d Z samples of 512x512 over %d GPU(s)): %.1f ms/iteration, %.2f Z-iterations/s, loss %.3e -> %.3e, peak %.1f GB'
                   % (a.nb, B, D.world_size(), dt * 1e3, B / dt, zo.loss_values[0], zo.loss_values[-1], torch.cuda.max_memory_allocated() / 2 ** 30))
 
 
