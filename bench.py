@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default='split', choices=['split', 'bf16', 'f16'], help="experiments: the headline is 'split' (fp32-class)")
+    ap.add_argument('--precision', default='split', choices=['split', 'f16x2', 'bf16', 'f16'], help="experiments: the headline is 'split' (fp32-class)")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
     args = ap.parse_args()
     if args.batch != BATCH:
@@ -168,10 +168,11 @@ def main():
         out = {
             'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'f32', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'f32', 'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
                        'arithmetic': {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
-                                      'f16': 'f16 MFMA operands, fp32 accumulate'}[args.precision],
+                                      'f16': 'f16 MFMA operands, fp32 accumulate',
+                                      'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate'}[args.precision],
                        'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
@@ -179,9 +180,9 @@ def main():
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
                          'generator_ms_per_step': conv_ms,
                          'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
                          # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
-                         'mfma_bf16_issue_frac_of_measured_1.79PF': (3 if args.precision == 'split' else 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
+                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only

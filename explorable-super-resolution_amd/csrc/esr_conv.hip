@@ -152,20 +152,20 @@ struct Bases {
     const uint4* p[2 * NPL];
     const uint4* w;
 };
-template <int NPL, int MT>
+template <int NPL, int MT, int NPW>
 __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b, int lane) {
     Bases<NPL> r;
 #pragma unroll
     for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
-    r.w = a.wpack + (size_t)cp * (9 * MT * NPL) * 64 + lane;
+    r.w = a.wpack + (size_t)cp * (9 * MT * NPW) * 64 + lane;
     return r;
 }
 
 // the DMA of one step is a list of independent 1 KiB instructions so that it can be issued in slices between MFMAs:
 // ops [0, 2*NPL*MAXS) = activation slot s, plane (group, hi|lo);  then ceil(9*MT*NPL / NW) weight-fragment ops
-template <int NPL, int MT>
+template <int NPL, int MT, int NPW>
 __device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave) {
-    constexpr int NWI = 9 * MT * NPL, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
+    constexpr int NWI = 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
     if (op < NACT) {
         const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
         const int so = s == 0 ? f.soff0 : (s == 1 ? f.soff1 : f.soff2);
@@ -226,14 +226,16 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
 //             and nobody else covers its DMA waits.
 template <int NPL, int MT, int EPI, int NST, int FMT>
 __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
-    static_assert(FMT == 0 || NPL == 1, "f16 is a single-plane format");
+    // weight planes: bf16 packs carry hi (+ lo with split activations); f16 packs are always one plane — with f16 hi+lo activations
+    // that is the 2-MFMA mode (Whi*Xlo + Whi*Xhi)
+    constexpr int NPW = FMT ? 1 : NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
-    constexpr int NWI = 9 * MT * NPL;
+    constexpr int NWI = 9 * MT * NPW;
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
     float* const s_bias = (float*)(smem + NST * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
@@ -267,15 +269,15 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #ifdef ESR_ABL_TERMS
     constexpr int NTERM = NPL == 2 ? ESR_ABL_TERMS : 1;   // ablation build: wrong results, timing only
 #else
-    constexpr int NTERM = NPL == 2 ? 3 : 1;
+    constexpr int NTERM = NPL == 2 ? (NPW == 2 ? 3 : 2) : 1;
 #endif
     constexpr int NM = MT * R * NTERM;
     constexpr int NL = (MT + R) * NPL;
     constexpr int NSLOT = NM > NL ? NM : NL;
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
-        const Bases<NPL> bs = make_bases<NPL, MT>(a, 0, fs.b, lane);
+        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
 #pragma unroll
-        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave);
     }
     for (int cp = 0; cp < a.ncp; ++cp) {
         const int st = NST == 2 ? (cp & 1) : 0;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
         if (NST == 1) {
-            const Bases<NPL> bs = make_bases<NPL, MT>(a, cp, fs.b, lane);
+            const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
 #pragma unroll
             for (int op = 0; op < NOPS; ++op) {
 #ifdef ESR_ABL_NOWDMA
@@ -292,16 +294,16 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #ifdef ESR_ABL_NOADMA
                 if (op < NACT && cp > 0) continue;
 #endif
-                dma_op<NPL, MT>(fs, bs, op, lds0, plane_bytes, wave);
+                dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave);
             }
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (cp + 1 < a.ncp) {
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
             // everything EXCEPT the NOPS copies just issued (every wave issues exactly NOPS per chunk, see dma_op / setup_tile)
-            const Bases<NPL> bs = make_bases<NPL, MT>(a, cp + 1, fs.b, lane);
+            const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 1, fs.b, lane);
 #pragma unroll
-            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave);
+            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS) : "memory");
         } else {
@@ -311,12 +313,12 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         ESR_TR();
         __syncthreads();
         ESR_TR();
-        uint4 fa[2][MT][NPL], fb[2][R][NPL];
+        uint4 fa[2][MT][NPW], fb[2][R][NPL];
         auto load_frag = [&](int t, int k, int buf) {
             const int tapoff = ((t / 3) * P + (t % 3)) * 16;
             const int grp = k / (MT + R), idx = k % (MT + R);
-            const int pl_a = NPL == 2 ? 1 - grp : 0, pl_b = grp;
-            if (idx < MT) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPL + pl_a) * 1024);
+            const int pl_a = NPW == 2 ? 1 - grp : 0, pl_b = grp;
+            if (idx < MT) { if (NPW == 2 || grp == 0) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPW + pl_a) * 1024); }
             else fb[buf][idx - MT][pl_b] = *(const uint4*)(sb + (idx - MT) * NW * 512 + tapoff + pl_b * plane_bytes);
         };
 #pragma unroll
@@ -327,7 +329,8 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) {
                 if (i < NM) {
-                    const int term = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
+                    // terms, last to first: Whi*Xhi, Whi*Xlo, Wlo*Xhi — a mode with fewer terms drops from the front of that list
+                    const int term = i / (MT * R) + (NPL == 2 ? 3 - NTERM : 0), rem = i % (MT * R), r = rem % R, m = rem / R;
                     const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
                     acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
                 }
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                                 hi[k][j] = h;
                                 lo[k][j] = 0;
                                 if (NPL == 2)
-                                    lo[k][j] = cvt_pk_bf16(v[k][2 * j] - __uint_as_float(h << 16), v[k][2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
+                                    lo[k][j] = cvt_pk<FMT>(v[k][2 * j] - e2f<FMT>(h & 0xFFFF), v[k][2 * j + 1] - e2f<FMT>(h >> 16));
                             }
                         }
                         // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
@@ -614,7 +617,8 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPL * 1024) + (size_t)MT * 32 * 4;
+    constexpr int NPW = FMT ? 1 : NPL;
+    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NTHREADS), lds, s, a);
@@ -744,7 +748,6 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->in0.hi && (d->in0.H != d->H || d->in0.W != d->W)) return ESR_E_ARG;
     const bool split = d->in1.lo != nullptr;
     const bool f16 = d->in1.fmt == ESR_FMT_F16;
-    if (f16 && split) return ESR_E_ARG;
     // one element format per launch
     if ((d->in0.hi && d->in0.fmt != d->in1.fmt) || (d->out.hi && d->out.fmt != d->in1.fmt) || (d->out2.hi && d->out2.fmt != d->in1.fmt) ||
         (d->res1.hi && d->res1.fmt != d->in1.fmt) || (d->res2.hi && d->res2.fmt != d->in1.fmt) || (d->mask_src.hi && d->mask_src.fmt != d->in1.fmt))
@@ -811,6 +814,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->out2.hi) epi |= EPI_OUT2;
     if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
+    if (f16 && split) return mt == 1 ? launch_epi<2, 1, 1>(a, epi, s) : launch_epi<2, 2, 1>(a, epi, s);
     if (f16) return mt == 1 ? launch_epi<1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1>(a, epi, s);
     if (split) return mt == 1 ? launch_epi<2, 1, 0>(a, epi, s) : launch_epi<2, 2, 0>(a, epi, s);
     return mt == 1 ? launch_epi<1, 1, 0>(a, epi, s) : launch_epi<1, 2, 0>(a, epi, s);

@@ -42,7 +42,7 @@ __global__ void pack_nchw_kernel(const float* __restrict__ src, long long sbs, i
                 v = (1.f - ly) * ((1.f - lx) * p[r0 + q0] + lx * p[r0 + q1]) + ly * ((1.f - lx) * p[r1 + q0] + lx * p[r1 + q1]);
             }
         }
-        if (fmt == ESR_FMT_F16) { vh[e] = f2h(v); vl[e] = 0; }
+        if (fmt == ESR_FMT_F16) { vh[e] = f2h(v); vl[e] = f2h(v - h2f(vh[e])); }
         else split_bf16(v, vh[e], vl[e]);
     }
     const long long o = b * bs + cg * cs + (long long)Y * Wp + X;
@@ -72,7 +72,7 @@ __global__ void unpack_nchw_kernel(const uint4* __restrict__ hi, const uint4* __
         if (ch >= nc) break;
         const uint32_t hb = (e & 1) ? (hw[e >> 1] >> 16) : (hw[e >> 1] & 0xFFFF);
         const uint32_t lb = (e & 1) ? (lw[e >> 1] >> 16) : (lw[e >> 1] & 0xFFFF);
-        dst[((long long)(b * nc + ch) * H + y) * W + x] = fmt == ESR_FMT_F16 ? h2f(hb) : bf2f(hb) + bf2f(lb);
+        dst[((long long)(b * nc + ch) * H + y) * W + x] = fmt == ESR_FMT_F16 ? h2f(hb) + h2f(lb) : bf2f(hb) + bf2f(lb);
     }
 }
 
@@ -90,7 +90,6 @@ extern "C" int esr_pack_nchw(const float* src, int64_t src_batch_stride, int B, 
     if ((h + 2 * pad) % down || (w + 2 * pad) % down) return ESR_E_ARG;
     const int Hd = (h + 2 * pad) / down, Wd = (w + 2 * pad) / down;
     if (dst->H != Hd || dst->W != Wd || dst->ncg * 8 < nc) return ESR_E_ARG;
-    if (dst->fmt == ESR_FMT_F16 && dst->lo) return ESR_E_ARG;      // f16 is a single-plane format
     const long long total = (long long)B * dst->ncg * (Hd + 2) * (Wd + 2);
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,

@@ -17,11 +17,22 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 2 / 'f16' = fp16
+# operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 'f16' = one fp16 plane,
+# 'f16x2' = fp16 hi+lo activation planes with single-plane fp16 weights
 def fmt_code(split):
-    if split in ('f16', 2):
+    """Weight-pack format code of include/esr_hip.h (0 bf16, 1 split bf16, 2 f16)."""
+    if split in ('f16', 'f16x2'):
         return 2
     return 1 if split else 0
+
+
+def act_planes(split):
+    """(number of activation planes, esr_act_view.fmt)"""
+    if split == 'f16':
+        return 1, 1
+    if split == 'f16x2':
+        return 2, 1
+    return (2, 0) if split else (1, 0)
 
 
 class ActBuf:
@@ -30,9 +41,9 @@ class ActBuf:
 
     def __init__(self, B, ncg, H, W, device, split=True):
         self.B, self.ncg, self.H, self.W, self.split = B, ncg, H, W, split
-        self.code = fmt_code(split)
+        self.nplanes, self.fmt = act_planes(split)
         self.hi = torch.zeros(B, ncg, H + 2, W + 2, 8, dtype=torch.int16, device=device)
-        self.lo = torch.zeros_like(self.hi) if self.code == 1 else None
+        self.lo = torch.zeros_like(self.hi) if self.nplanes == 2 else None
         self.cg_stride = (H + 2) * (W + 2)
         self.batch_stride = ncg * self.cg_stride
 
@@ -40,11 +51,11 @@ class ActBuf:
         ncg = self.ncg - cg0 if ncg is None else ncg
         assert 0 <= cg0 and cg0 + ncg <= self.ncg
         off = cg0 * self.cg_stride * 16
-        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.code == 1 else None, ncg, self.H, self.W,
-                       self.batch_stride, self.cg_stride, 1 if self.code == 2 else 0)
+        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.nplanes == 2 else None, ncg, self.H, self.W,
+                       self.batch_stride, self.cg_stride, self.fmt)
 
     def nbytes(self):
-        return self.hi.numel() * 2 * (2 if self.code == 1 else 1)
+        return self.hi.numel() * 2 * self.nplanes
 
     def to_nchw(self, nc, cg0=0):
         """Debug/test helper: unpack channels [cg0*8, cg0*8+nc) to fp32 NCHW."""

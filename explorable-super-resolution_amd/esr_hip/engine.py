@@ -40,7 +40,7 @@ class RRDBEngine:
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
-        split = {'split': True, 'bf16': False, 'f16': 'f16'}[precision]
+        split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2'}[precision]
         if split != self.split:
             self.split = split
             self._packed = None
@@ -267,8 +267,8 @@ class RRDBEngine:
     # ------------------------------------------------------------------ backward
     def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False, debug=None):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
-        if self.split == 'f16':
-            raise NotImplementedError("precision 'f16' is an inference mode: fp16 gradients underflow without loss scaling; "
+        if self.split in ('f16', 'f16x2'):
+            raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
         net, sp = self.net, self.split
         sf = net.upscale

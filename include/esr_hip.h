@@ -41,8 +41,9 @@ extern "C" {
 typedef void* esr_stream_t;   /* hipStream_t */
 
 /* Element formats of an activation view.  BF16 with a `lo` plane is the fp32-class mode (split operands, 3 MFMAs per product);
- * BF16 / F16 without `lo` are the single-MFMA reduced-precision modes (the reference has no counterpart; F16 is inference-only:
- * gradients would need loss scaling).  Weight packs use the matching code in their `split` argument: 0 bf16, 1 split bf16, 2 f16. */
+ * BF16 / F16 without `lo` are the single-MFMA reduced-precision modes; F16 with `lo` is the 2-MFMA mode (f16 weights x f16 hi+lo
+ * activations).  The reference has no counterpart of these; the F16 modes are inference-only (gradients would need loss scaling).
+ * Weight packs use the matching code in their `split` argument: 0 bf16, 1 split bf16 (hi+lo), 2 f16 (always one plane). */
 #define ESR_FMT_BF16 0
 #define ESR_FMT_F16 1
 
