@@ -12,13 +12,13 @@
 //   tile           TH x TW output pixels per workgroup, flattened with pitch P = TW+2 so that the 32-pixel MFMA
 //                  columns are 32 CONSECUTIVE LDS vectors for every tap (conflict-free b128 reads); the 2
 //                  pitch-padding columns compute garbage that is masked at the store
-//   execution      two interchangeable schedules over the same tile geometry, DMA list, tap schedule and epilogue:
-//                  (T, default) one tile per 4-wave workgroup, K loop over chunks of 2 channel groups x 9 taps: LDS-DMA
-//                  (global_load_lds) of the chunk's input tile AND weight fragments -> barrier -> MFMAs out of LDS ->
-//                  barrier; 2-3 workgroups per CU hide each other's DMA waits and epilogues.
-//                  (P) persistent: one workgroup per CU walks its tiles with the DMA running 1-2 steps ahead of the
-//                  MFMAs (counted s_waitcnt keeps younger DMA / stores in flight); kept for the one-wave-per-SIMD
-//                  experiments documented in DESIGN.md
+//   execution      one tile per 4-wave workgroup, K loop over chunks of 2 channel groups x 9 taps: LDS-DMA (global_load_lds) of the
+//                  chunk's input tile AND weight fragments -> barrier -> MFMAs out of LDS -> barrier.  Large launches: one LDS
+//                  stage, two workgroups per CU cover each other's DMA waits and epilogues (NST = 1).  Launches with no more
+//                  tiles than CUs: two LDS stages, the next chunk's DMA in flight under the MFMAs (NST = 2).  A persistent
+//                  multi-stage variant and 8-wave workgroups were measured and dropped (DESIGN.md sections 4 and 5).
+//   precision      element format FMT (bf16 / f16) x activation planes NPL: bf16 hi+lo = the fp32-class mode below; f16 hi+lo
+//                  with single-plane f16 weights = 2 MFMAs; one plane = 1 MFMA (precision table)
 //   split-bf16     x = hi + lo (both bf16).  acc += Wlo*Xhi + Whi*Xlo + Whi*Xhi  (3 MFMAs, lo*lo dropped: 2^-16)
 //   epilogue       compile-time specialised (EPI bits): bias, LeakyReLU, alpha*y + beta1*r1 + beta2*r2, act' mask
 //                  (data-gradient use), re-split to hi/lo via v_cvt_pk_bf16_f32, pairs of channel groups exchanged with
