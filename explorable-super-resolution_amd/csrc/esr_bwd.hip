@@ -8,6 +8,7 @@
 //   ReplicationPad2d            codes/CEM/CEMnet.py:70-71,286-295                           -> fold the pad ring into the edge pixels
 //   bilinear /sf of the latent  codes/models/modules/architecture.py:284                    -> spread each LR gradient over its taps
 #include "esr_common.h"
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -238,7 +239,7 @@ __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int NPL>
+template <int NPL, int NST>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,12 +312,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
         }                                                                                                                        \
     } while (0)
 
+    // NST == 2: two LDS stages, the next tile's copies in flight under the MFMAs, one workgroup per CU.
+    // NST == 1: one stage, two workgroups per CU cover each other's DMA waits (same trade as the conv kernel; selected by the host).
     int tile = slice;
     int cur = 0;
-    if (tile < ntiles) ESR_WG_ISSUE(tile, lds0);
+    if (NST == 2 && tile < ntiles) ESR_WG_ISSUE(tile, lds0);
     for (; tile < ntiles; tile += a.nslices) {
         const int nxt = tile + a.nslices;
-        if (nxt < ntiles) {
+        if (NST == 1) {
+            ESR_WG_ISSUE(tile, lds0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (nxt < ntiles) {
             ESR_WG_ISSUE(nxt, lds0 + (cur ^ 1) * STAGE);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NY) : "memory");     // everything but the copies just issued
         } else {
@@ -353,7 +359,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
             }
         }
         __syncthreads();
-        cur ^= 1;
+        if (NST == 2) cur ^= 1;
     }
     // ---- reduce the 4 waves through LDS (two passes of at most 5 taps: 4 x 5 x 4 KiB = 80 KiB).  A workgroup that owns its
     // (input tile, output tile) alone (nslices == 1) adds straight into dW / db; otherwise its partial sums go to the workspace.
@@ -403,22 +409,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 
 #undef ESR_WG_ISSUE
 
-template <int NPL>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
+template <int NPL, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    wgrad_body<NPL>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
+    wgrad_body<NPL, NST>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
 }
 
 // Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
 // slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
-template <int NPL>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
+template <int NPL, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
-    wgrad_body<NPL>(a, group, slice, smem);
+    wgrad_body<NPL, NST>(a, group, slice, smem);
 }
 
 // dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
@@ -514,9 +520,13 @@ static inline int64_t wgrad_partial_floats(const WgradPlan& p) {
     return p.nslices == 1 ? 0 : (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
 }
 
-static size_t wgrad_lds(int npl) {
-    const size_t stage2 = (size_t)2 * npl * (WG_X_BYTES + WG_Y_BYTES), red = (size_t)4 * 5 * 1024 * 4;
-    return stage2 > red ? stage2 : red;
+static int wgrad_stages() {                 // experiments: ESR_WGRAD_STAGES=1|2
+    static const int v = getenv("ESR_WGRAD_STAGES") ? atoi(getenv("ESR_WGRAD_STAGES")) : 1;
+    return v == 2 ? 2 : 1;
+}
+static size_t wgrad_lds(int npl, int nst) {
+    const size_t stages = (size_t)nst * npl * (WG_X_BYTES + WG_Y_BYTES), red = (size_t)4 * 5 * 1024 * 4;
+    return stages > red ? stages : red;
 }
 
 // batch layout inside the caller's workspace: [WgradArgs table][int4 workgroup map][fp32 partial sums]
@@ -566,10 +576,12 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const WgradPlan p = wgrad_plan(d);
     const WgradArgs a = wgrad_args(d, p, d->workspace);
     const bool split = d->dy.lo != nullptr;
-    void (*k)(const WgradArgs) = split ? conv3x3_wgrad_kernel<2> : conv3x3_wgrad_kernel<1>;
+    const int nst = wgrad_stages();
+    void (*k)(const WgradArgs) = split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2> : conv3x3_wgrad_kernel<2, 1>)
+                                       : (nst == 2 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<1, 1>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1, nst), (hipStream_t)stream, a);
     ESR_CHECK_LAUNCH();
     if (p.nslices > 1) {
         const long long nred = (long long)p.ngroups * 9 * 1024 + p.mt * 32;
@@ -616,10 +628,12 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
     if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(WgradArgs), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
     if (hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), (size_t)b.nwg * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
         return ESR_E_LAUNCH;
-    void (*k)(const WgradArgs*, const int4*) = split ? conv3x3_wgrad_batch_kernel<2> : conv3x3_wgrad_batch_kernel<1>;
+    const int nst = wgrad_stages();
+    void (*k)(const WgradArgs*, const int4*) = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2> : conv3x3_wgrad_batch_kernel<2, 1>)
+                                                     : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2> : conv3x3_wgrad_batch_kernel<1, 1>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1), s, (const WgradArgs*)workspace,
+    hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
                        (const int4*)((char*)workspace + b.table_bytes));
     ESR_CHECK_LAUNCH();
     if (max_red > 0) {
