@@ -236,3 +236,25 @@ def test_hip_graph_replay_is_bit_identical():
         for p in G.generated_image_model.parameters():
             p.mul_(0.5)
         assert torch.equal(G(xs[0]), fast(xs[0]))
+
+
+@pytest.mark.parametrize('sf,kernel', [(4, None), (2, None), (4, 'blurry_cubic_1.0')])
+def test_gpu_lr_synthesis_equals_the_dataset_paths_imresize(sf, kernel):
+    """the LR images the reference's dataset code makes on the CPU with imresize(HR, 1/sf)
+    (LRHR_dataset.py:87; replicate-pad, anti-aliasing filter, stride) are what DownscaleOP computes on the GPU with the strided-blur
+    kernel — whole image, borders included — and Mask_Invalid_Regions_PyTorch applies the same loss mask to both images."""
+    import CEM.CEMnet as C
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    net = cem.WrapArchitecture_PyTorch(generated_image=None, training_patch_size=32 * sf).to(DEV)
+    hr = seeded_uniform((2, 3, 24 * sf, 20 * sf), 601)
+    lr_gpu = net.DownscaleOP(hr.to(DEV)).cpu().numpy()
+    for b in range(2):
+        ref = imresize(hr[b].permute(1, 2, 0).numpy().astype(np.float64), scale_factor=[1.0 / sf], kernel=kernel)
+        np.testing.assert_allclose(lr_gpu[b].transpose(1, 2, 0), ref, atol=2e-6)
+    a, b2 = seeded_uniform((1, 3, 32 * sf, 32 * sf), 602).to(DEV), seeded_uniform((1, 3, 32 * sf, 32 * sf), 603).to(DEV)
+    ma, mb = cem.Mask_Invalid_Regions_PyTorch(a, b2)
+    m = int(cem.invalidity_margins_HR)
+    assert float(ma[..., :m, :].abs().max()) == 0 and torch.equal(ma[..., m:-m, m:-m], a[..., m:-m, m:-m]) and torch.equal(mb[..., m:-m, m:-m], b2[..., m:-m, m:-m])
+    imresize.kernels = {}
