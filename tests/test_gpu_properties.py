@@ -1,0 +1,108 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL configs[1] size (RRDB-23 x4 + CEM, 32 x 3 x 128 x 128), where the
+CPU oracle is too slow to be the checker: consistency, idempotence and linearity of the CEM projection,
+identity of zero-weight residual blocks, exactness of batch sharding (the data-parallel decomposition), adjointness of the data
+gradient.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cem_oracle as co
+from oracle.weights import seeded_uniform
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def full():
+    import contextlib
+    import io
+    import CEM.CEMnet as C
+    import models.modules.architecture as arch
+    import models.networks as networks
+    torch.manual_seed(0)
+    cem = C.CEMnet(C.Get_CEM_Conf(4))
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, upscale=4, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input=None, num_latent_channels=0)
+    G = cem.WrapArchitecture_PyTorch(net)
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)
+    G = G.to(DEV).eval()
+    x = torch.rand(32, 3, 128, 128, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        y = G(x)
+    return cem, G, x, y
+
+
+def test_full_size_output_is_consistent_with_the_lr_input(full):
+    """D(out) == x in the interior (target < 1e-5), with the HIP downsampler on the whole batch and with the CPU oracle's on one image."""
+    cem, G, x, y = full
+    assert y.shape == (32, 3, 512, 512) and bool(torch.isfinite(y).all())
+    m = int(cem.invalidity_margins_LR)
+    with torch.no_grad():
+        d = G.DownscaleOP(y)
+    assert float(((d - x)[..., m:-m, m:-m] ** 2).mean().sqrt()) < 1e-5
+    d0 = co.downscale_op(y[:1].cpu(), co.CEMTaps(4))
+    assert float((d0 - x[:1].cpu())[..., m:-m, m:-m].abs().max()) < 1e-5
+
+
+def test_batch_sharding_is_exact(full):
+    """The data-parallel decomposition: any shard of the batch, processed alone, gives bit-identical images (no cross-image state)."""
+    cem, G, x, y = full
+    with torch.no_grad():
+        assert torch.equal(G(x[8:16]), y[8:16])
+        assert torch.equal(G(x[31:32]), y[31:32])
+
+
+def test_projection_is_idempotent_and_affine_in_g(full):
+    """CEM(x, .) of an image that is already consistent with x returns it (interior); out(x, g1 + g2) - out(x, g1) is the null-space
+    component of g2, independent of x and g1 (the projector is affine in g)."""
+    cem, G, x, y = full
+    import CEM.CEMnet as C
+    P = C.CEMnet(C.Get_CEM_Conf(4)).WrapArchitecture_PyTorch(generated_image=None).to(DEV).train()       # train mode: no pad / crop
+    xs, ys = x[:4], y[:4]
+    with torch.no_grad():
+        again = P([xs, ys])
+        m = int(cem.invalidity_margins_HR)
+        assert float((again - ys)[..., m:-m, m:-m].abs().max()) < 2e-5
+        g1, g2 = torch.rand_like(ys), torch.rand_like(ys)
+        lhs = P([xs, g1 + g2]) - P([xs, g1])
+        rhs = P([torch.zeros_like(xs), g2])
+        assert float((lhs - rhs).abs().max()) < 2e-5
+
+
+def test_zero_weight_blocks_are_identities():
+    """An RDB with zero conv weights is the identity (block.py:235), so an RRDB of three such RDBs is x -> 0.2*x + x = 1.2*x
+    (block.py:270) and the trunk of nb such RRDBs reduces to fea + LR_conv(1.2^nb * fea)."""
+    import models.modules.architecture as arch
+    from oracle import rrdb_oracle as ro
+    from oracle.weights import fill_formula_weights
+    net = arch.RRDBNet(3, 3, 64, 4, upscale=4, num_latent_channels=0)
+    fill_formula_weights(net, gain=1.0)
+    for r in range(4):
+        for p in net.model[1].sub[r].parameters():
+            p.data.zero_()
+    x = seeded_uniform((2, 3, 20, 24), 701)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        y = net.to(DEV)(x.to(DEV)).cpu()
+    # oracle on the same weights (zero blocks included) and the analytic statement about the trunk
+    yo = ro.rrdb_forward(sd, x, 4, 4, 0, prefix='model')
+    assert float((y - yo).norm() / yo.norm()) < 1e-4
+    cap = {}
+    ro.rrdb_forward(sd, x, 4, 4, 0, prefix='model', capture=cap)
+    fea = torch.nn.functional.conv2d(x, sd['model.0.weight'], sd['model.0.bias'], padding=1)
+    trunk = fea + torch.nn.functional.conv2d(1.2 ** 4 * fea, sd['model.1.sub.4.weight'], sd['model.1.sub.4.bias'], padding=1)
+    assert float((cap['trunk'] - trunk).abs().max()) < 1e-4 * float(trunk.abs().max())
+
+
+def test_data_gradient_is_the_adjoint_of_the_forward_conv():
+    """<conv(a), b> == <a, conv^T(b)> for the linear part (a conv without activation), at a mid-size shape, both sides on the GPU."""
+    from esr_hip import act as A
+    a = seeded_uniform((4, 96, 37, 53), 801, -1, 1).to(DEV)
+    b = seeded_uniform((4, 64, 37, 53), 802, -1, 1).to(DEV)
+    w = (seeded_uniform((64, 96, 3, 3), 803, -1, 1) * 0.05).to(DEV)
+    La = A.conv3x3_nchw(a, w, None, 1.0)
+    Ltb = A.conv3x3_dgrad_nchw(b, w)
+    lhs, rhs = float((La.double() * b.double()).sum()), float((a.double() * Ltb.double()).sum())
+    assert abs(lhs - rhs) < 2e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
