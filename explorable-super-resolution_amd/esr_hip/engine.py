@@ -265,7 +265,7 @@ class RRDBEngine:
         return g, bufs
 
     # ------------------------------------------------------------------ backward
-    def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False, debug=None):
+    def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
         if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
@@ -343,9 +343,6 @@ class RRDBEngine:
         dgrad('hr0', G_hr0.view(), G_up, 0, 8, H, W, mask=(src_act, 0, 8) if self.n_up else None)
         if GZ_hr is not None:
             dgrad_z('hr0', G_hr0.view(), GZ_hr, H, W, 1.0, first=False)
-        if debug is not None:
-            debug['hr0'] = G_hr0.to_nchw(64)
-            debug['up_last'] = G_up.to_nchw(64)
         del G_hr0, G_g
         # ---- upsamplers (reverse): conv data-gradient at the upsampled size, then sum-pool = adjoint of nearest upsample
         cur_g, s = G_up, sf if sf != 3 else 3
@@ -362,8 +359,6 @@ class RRDBEngine:
             cur_g = nxt_g
             del tmp
         G_trunk = cur_g
-        if debug is not None:
-            debug['trunk'] = G_trunk.to_nchw(64)
         # ---- trunk: trunk = fea + LR_conv(last)
         last_act = bufs['last'] if net.nb else bufs['fea']
         pr = self.packed_rdb_t() if net.nb else {}
@@ -413,8 +408,6 @@ class RRDBEngine:
         # d fea = d trunk (shortcut) + d(first RRDB input)
         G_fea = galloc(B, 8, h, w)
         A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)
-        if debug is not None:
-            debug['fea'] = G_fea.to_nchw(64)
         wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w, keep=(G_fea,))
         dx = None
         if need_dx:
