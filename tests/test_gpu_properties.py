@@ -106,3 +106,37 @@ def test_data_gradient_is_the_adjoint_of_the_forward_conv():
     Ltb = A.conv3x3_dgrad_nchw(b, w)
     lhs, rhs = float((La.double() * b.double()).sum()), float((a.double() * Ltb.double()).sum())
     assert abs(lhs - rhs) < 2e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+def test_full_size_c5_x8_non_bicubic_is_consistent():
+    """BASELINE configs[4] at its full size on one GPU: RRDB-23 x8, 'blurry_cubic_2.0' CEM kernel, batch 16 of 256x256 -> 2048x2048
+    (the generator runs on 280x280 padded frames; ~60 GB of activation buffers): finite, and downsample-consistent with its input.
+    Exercises the >2^31-element buffers and the 12-pixel margin / 45-tap kernels."""
+    import contextlib
+    import io
+    import CEM.CEMnet as C
+    from CEM.imresize_CEM import imresize
+    import models.modules.architecture as arch
+    import models.networks as networks
+    if torch.cuda.get_device_properties(0).total_memory < 120 * 2 ** 30:
+        pytest.skip('needs ~70 GB of device memory')
+    imresize.kernels = {}
+    torch.manual_seed(0)
+    cem = C.CEMnet(C.Get_CEM_Conf(8), upscale_kernel='blurry_cubic_2.0')
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, upscale=8, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input=None, num_latent_channels=0)
+    G = cem.WrapArchitecture_PyTorch(net)
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)
+    G = G.to(DEV).eval()
+    x = torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(6)).to(DEV)
+    with torch.no_grad():
+        y = G(x)
+        assert y.shape == (16, 3, 2048, 2048) and bool(torch.isfinite(y).all())
+        d = G.DownscaleOP(y)
+    m = int(cem.invalidity_margins_LR)
+    assert m == 12
+    assert float(((d - x)[..., m:-m, m:-m] ** 2).mean().sqrt()) < 1e-5
+    del G, y, d
+    torch.cuda.empty_cache()
+    imresize.kernels = {}

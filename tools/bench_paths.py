@@ -4,6 +4,7 @@ per-GPU shape and Z-search iterations at the C4 shape, both through the product'
 
     python tools/bench_paths.py c3 [--batch 32] [--steps 10]        RRDB-23 x4 + CEM, lat 3, 52x52 LR crops, L1 pixel loss, Adam
     python tools/bench_paths.py c4 [--batch 64] [--steps 10]        Z search: STD_increase on one 128x128 LR image, Adam on Z
+    python tools/bench_paths.py c5 [--batch 16] [--precision f16]   inference: RRDB-23 x8, 'blurry_cubic_2.0' CEM kernel, 256x256 -> 2048x2048
 Under torchrun (one process per GPU) c3 all-reduces the gradients over RCCL and c4 shards the Z batch.
 """
 import argparse
@@ -30,16 +31,52 @@ def make_opt(is_train, lat=3, nb=23):
                   'lr_scheme': 'MultiStepLR', 'lr_steps': [100000], 'lr_gamma': 0.5}})
 
 
+def c5(a, D):
+    import contextlib
+    import io
+    import CEM.CEMnet as C
+    import models.modules.architecture as arch
+    import models.networks as networks
+    torch.manual_seed(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    cem = C.CEMnet(C.Get_CEM_Conf(8), upscale_kernel='blurry_cubic_2.0')
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=a.nb, gc=32, upscale=8, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input=None, num_latent_channels=0)
+    G = cem.WrapArchitecture_PyTorch(net)
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)
+    G = G.to(dev).eval()
+    net.set_precision(a.precision)
+    B = a.batch or 16
+    lo, hi = D.shard_range(B)
+    x = torch.rand(hi - lo, 3, 256, 256, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            y = G(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            y = G(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+        d = G.DownscaleOP(y)
+    m = int(cem.invalidity_margins_LR)
+    if D.rank() == 0:
+        print('c5 inference [%s] (RRDB-%d x8 + CEM blurry_cubic_2.0, %d x 256x256 -> 2048x2048 over %d GPU(s)): %.1f ms/batch, %.3e HR pixels/s, '
+              'consistency rmse %.2e, peak %.1f GB' % (a.precision, a.nb, B, D.world_size(), dt * 1e3, B * 2048 * 2048 / dt,
+                                                       float(((d - x)[..., m:-m, m:-m] ** 2).mean().sqrt()), torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('which', choices=['c3', 'c4'])
+    ap.add_argument('which', choices=['c3', 'c4', 'c5'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--nb', type=int, default=23)
-    ap.add_argument('--precision', default='split', choices=['split', 'bf16'], help="'bf16': single-MFMA operands (C3 names bf16)")
+    ap.add_argument('--precision', default='split', choices=['split', 'f16x2', 'f16', 'bf16'], help="'bf16': single-MFMA operands (C3 names bf16); the fp16 modes are inference-only (c5)")
     a = ap.parse_args()
     from esr_hip import dist as D
     D.init_from_env()
+    if a.which == 'c5':
+        return c5(a, D)
     import contextlib
     import io
     import models
