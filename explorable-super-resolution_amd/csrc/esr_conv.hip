@@ -37,7 +37,7 @@ namespace {
 #endif
 constexpr int NW = ESR_NW;     // waves per workgroup
 constexpr int NTHREADS = 64 * NW;
-constexpr int MAXS = ESR_MAXS;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+constexpr int MAXS_BASE = ESR_MAXS;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
 // Measured on MI355X (RRDB-23 forward, ms): MT1/MT2 resident workgroups 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is
 // power-limited under this kernel: beyond the overlap that reaches the power cap, more resident waves cost clock.
 #ifndef ESR_WGS_MT1
@@ -47,7 +47,13 @@ constexpr int MAXS = ESR_MAXS;        // activation DMA slots (64 pixel vectors)
 #define ESR_WGS_MT2 2
 #endif
 constexpr int WGS_MT1 = ESR_WGS_MT1, WGS_MT2 = ESR_WGS_MT2;   // resident workgroups per CU the kernels are built (registers) and tiled (LDS) for
-constexpr int R = 3;           // 32-pixel column tiles per wave: a workgroup tile holds up to NW*R*32 = 384 flattened pixels
+#ifndef ESR_R_MT1
+#define ESR_R_MT1 3
+#endif
+// 32-pixel column tiles per wave (R) and activation DMA slots per wave per plane (MAXS), per M-tile count: a workgroup tile holds up to
+// NW*R*32 flattened pixels.  R = 6 for the 32-channel kernels halves their weight DMA per pixel and shrinks the halo (experiment knob).
+constexpr int r_of(int mt) { return mt == 1 ? ESR_R_MT1 : 3; }
+constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE; }
 
 // epilogue feature bits (template parameter EPI)
 constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
@@ -112,8 +118,8 @@ __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b
 }
 
 struct FetchState {
-    int soff0, soff1, soff2;   // MAXS == 3 activation slots: source vector offset inside a plane, or -1 (lane past the tile)
-    int slot1, slot2;          // LDS slot (64 pixel vectors) each of them fills; slot 0 is `wave`
+    int soff[4];               // up to 4 activation slots: source vector offset inside a plane, or -1 (lane past the tile)
+    int slot[4];               // LDS slot (64 pixel vectors) each of them fills; slot[0] is `wave`
     int b;                     // image index
 };
 
@@ -128,6 +134,7 @@ __device__ __forceinline__ int slot_offset(const ConvArgs& a, int x0, int y0, in
     return (p < a.NPIX_L) ? (inb ? sy * a.Win_p + sx : 0) : -1;
 }
 
+template <int MAXS>
 __device__ __forceinline__ FetchState setup_tile(const ConvArgs& a, int t, int wave, int lane) {
     const int tx = t % a.tiles_x;
     const int r1 = t / a.tiles_x;
@@ -138,11 +145,11 @@ __device__ __forceinline__ FetchState setup_tile(const ConvArgs& a, int t, int w
     // every wave issues exactly MAXS activation slots per plane (a constant instruction count keeps the s_waitcnt
     // bookkeeping static): a slot index past the tile re-fetches this wave's first slot (same data, same destination)
     const int nslots = (a.NPIX_L + 63) >> 6;
-    f.slot1 = (wave + 1 * NW) < nslots ? wave + 1 * NW : wave;
-    f.slot2 = (wave + 2 * NW) < nslots ? wave + 2 * NW : wave;
-    f.soff0 = slot_offset(a, x0, y0, wave * 64 + lane);
-    f.soff1 = slot_offset(a, x0, y0, f.slot1 * 64 + lane);
-    f.soff2 = slot_offset(a, x0, y0, f.slot2 * 64 + lane);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        f.slot[s] = (wave + s * NW) < nslots ? wave + s * NW : wave;
+        f.soff[s] = slot_offset(a, x0, y0, f.slot[s] * 64 + lane);
+    }
     return f;
 }
 
@@ -165,11 +172,12 @@ __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int 
 // ops [0, 2*NPL*MAXS) = activation slot s, plane (group, hi|lo);  then ceil(9*MT*NPL / NW) weight-fragment ops
 template <int NPL, int MT, int NPW>
 __device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave) {
+    constexpr int MAXS = maxs_of(MT);
     constexpr int NWI = 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
     if (op < NACT) {
         const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
-        const int so = s == 0 ? f.soff0 : (s == 1 ? f.soff1 : f.soff2);
-        const int slot = s == 0 ? wave : (s == 1 ? f.slot1 : f.slot2);
+        const int so = f.soff[s];
+        const int slot = f.slot[s];
         if (so >= 0) glds16(bs.p[cgpl] + so, stage + cgpl * plane_bytes + slot * 1024);
     } else if (op < NOPS) {
         int j = (op - NACT) * NW + wave;
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // weight planes: bf16 packs carry hi (+ lo with split activations); f16 packs are always one plane — with f16 hi+lo activations
     // that is the 2-MFMA mode (Whi*Xlo + Whi*Xhi)
     constexpr int NPW = FMT ? 1 : NPL;
+    constexpr int R = r_of(MT), MAXS = maxs_of(MT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #else
 #define ESR_TR() do { } while (0)
 #endif
-    const FetchState fs = setup_tile(a, tile, wave, lane);
+    const FetchState fs = setup_tile<MAXS>(a, tile, wave, lane);
     f32x16 acc[MT][R];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -575,6 +584,7 @@ struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 // Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
 // halo-traffic term, under the LDS budget that keeps `nwg` workgroups resident per CU.
 TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
+    const int R = r_of(mt), MAXS = maxs_of(mt);
     TileCfg best{};
     double best_cost = -1;
     const size_t budget = 160 * 1024;
