@@ -73,6 +73,7 @@ struct ConvArgs {
     float* out_nchw;
     int mask_cg0, mask_cg1;
     float mask_slope;
+    int reverse;                    // walk the tile space backwards (cache-reuse hint)
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
 #ifdef ESR_TRACE
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
-    const int tile = (blockIdx.x % nxcd) * per_xcd + blockIdx.x / nxcd;
-    if (blockIdx.x / nxcd >= per_xcd || tile >= ntiles) return;
+    const int tile_f = (blockIdx.x % nxcd) * per_xcd + blockIdx.x / nxcd;
+    if (blockIdx.x / nxcd >= per_xcd || tile_f >= ntiles) return;
+    const int tile = a.reverse ? ntiles - 1 - tile_f : tile_f;
     if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
     constexpr int NACT = 2 * NPL * MAXS;
     constexpr int NWOP = (NWI + NW - 1) / NW;
@@ -801,6 +803,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg0 = d->mask_cg0;
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
+    a.reverse = d->reverse_order;
 #ifdef ESR_TRACE
     a.trace = g_trace;
 #endif

@@ -23,7 +23,8 @@ class Conv3x3Desc(C.Structure):
                 ('act_slope', C.c_float), ('alpha', C.c_float),
                 ('res1', ActView), ('beta1', C.c_float), ('res2', ActView), ('beta2', C.c_float),
                 ('out', ActView), ('out2', ActView), ('out_nchw', C.c_void_p),
-                ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float)]
+                ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
+                ('reverse_order', C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -1,6 +1,7 @@
 """Device-side containers used by the launch planner: activation buffers in the kernels' channel-group layout
 and packed conv weights.  PyTorch is only the allocator / stream provider here."""
 import ctypes as C
+import os
 
 import torch
 
@@ -267,8 +268,12 @@ class PackedSum:
         return self
 
 
+_launch_parity = 0
+ALTERNATE_ORDER = os.environ.get('ESR_ALTERNATE_ORDER', '1') != '0'
+
+
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
-            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2):
+            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None):
     d = _lib.Conv3x3Desc()
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
@@ -288,6 +293,12 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
     d.mask_src = mask_src if mask_src is not None else NO_VIEW
     d.mask_cg0, d.mask_cg1 = mask_cg
     d.mask_slope = mask_slope
+    # consecutive launches alternate the direction in which they walk the images (cache-reuse hint, see esr_conv3x3_desc)
+    global _launch_parity
+    if reverse is None:
+        reverse = bool(_launch_parity & 1) and ALTERNATE_ORDER
+        _launch_parity += 1
+    d.reverse_order = 1 if reverse else 0
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
 
 

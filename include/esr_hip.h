@@ -91,6 +91,10 @@ typedef struct {
      * act'(mask_src) = (mask_src > 0 ? 1 : mask_slope) AFTER the residual add (LeakyReLU backward of
      * the layer that produced those channels; block.py:18). mask_src.hi == NULL: disabled. */
     esr_act_view mask_src; int32_t mask_cg0, mask_cg1; float mask_slope;
+    /* scheduling hint, no effect on the result: walk the tiles (and so the images) last to first.  Consecutive layers of a network
+     * re-read what the previous launch just touched; alternating the direction lets the tail of one launch, still in the 256 MB
+     * Infinity Cache, be the head of the next. */
+    int32_t reverse_order;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
