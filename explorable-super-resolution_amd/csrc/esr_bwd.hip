@@ -579,7 +579,7 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const int nst = wgrad_stages();
     void (*k)(const WgradArgs) = split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2> : conv3x3_wgrad_kernel<2, 1>)
                                        : (nst == 2 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<1, 1>);
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1, nst), (hipStream_t)stream, a);
     ESR_CHECK_LAUNCH();
@@ -631,7 +631,7 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
     const int nst = wgrad_stages();
     void (*k)(const WgradArgs*, const int4*) = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2> : conv3x3_wgrad_batch_kernel<2, 1>)
                                                      : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2> : conv3x3_wgrad_batch_kernel<1, 1>);
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
                        (const int4*)((char*)workspace + b.table_bytes));

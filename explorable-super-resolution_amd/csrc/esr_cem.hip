@@ -305,8 +305,7 @@ extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int
         if ((sf * qpitch) % 32 != 16) qpitch = qcols | 1;
         const size_t lds = (size_t)sf * rows * qpitch * 4;
         if (lds <= 150 * 1024 && (long long)B * C <= 65535) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)cem_downscale_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            ESR_ALLOW_160K_LDS(cem_downscale_tiled_kernel);
             hipLaunchKernelGGL(cem_downscale_tiled_kernel, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w,
                                sf, pre, taps, k, lr, lr_pad, d, qpitch, rows);
             ESR_CHECK_LAUNCH();
@@ -328,8 +327,7 @@ extern "C" int esr_cem_lrfilter(const float* x, int B, int C, int h, int w, cons
         pitch += (16 - pitch % 32 + 32) % 32;                                   // pitch % 32 == 16
         const size_t lds = (size_t)(LT_TY + k - 1) * pitch * 4;
         if (lds <= 150 * 1024 && (long long)B * C <= 65535) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)cem_lrfilter_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            ESR_ALLOW_160K_LDS(cem_lrfilter_tiled_kernel);
             hipLaunchKernelGGL(cem_lrfilter_tiled_kernel, dim3((w + LT_TX - 1) / LT_TX, (h + LT_TY - 1) / LT_TY, B * C), dim3(256), lds, (hipStream_t)stream,
                                x, h, w, taps, k, out, pitch);
             ESR_CHECK_LAUNCH();

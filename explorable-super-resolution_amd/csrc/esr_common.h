@@ -56,3 +56,16 @@ static inline DView to_dview(const esr_act_view& v) {
         hipError_t e__ = hipGetLastError();                  \
         if (e__ != hipSuccess) return ESR_E_LAUNCH;          \
     } while (0)
+
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB once per (kernel, device): the attribute is per device, and one process may
+// drive several (host threads under nn.DataParallel-style use).  `mask` is a function-local static of the caller.
+#define ESR_ALLOW_160K_LDS(kernel_ptr)                                                                                      \
+    do {                                                                                                                    \
+        static unsigned long long mask__ = 0;   /* benign race: setting the attribute twice is harmless */                  \
+        int dev__ = 0;                                                                                                      \
+        (void)hipGetDevice(&dev__);                                                                                         \
+        if (!(mask__ >> (dev__ & 63) & 1ull)) {                                                                             \
+            (void)hipFuncSetAttribute((const void*)(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+            mask__ |= 1ull << (dev__ & 63);                                                                                 \
+        }                                                                                                                   \
+    } while (0)

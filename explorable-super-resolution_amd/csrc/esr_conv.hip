@@ -624,11 +624,7 @@ unsigned long long* g_trace = nullptr;
 template <int NPL, int MT, int EPI, int NST, int FMT>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT>;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    ESR_ALLOW_160K_LDS(k);
     constexpr int NPW = FMT ? 1 : NPL;
     const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
