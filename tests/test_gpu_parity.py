@@ -258,3 +258,23 @@ def test_gpu_lr_synthesis_equals_the_dataset_paths_imresize(sf, kernel):
     m = int(cem.invalidity_margins_HR)
     assert float(ma[..., :m, :].abs().max()) == 0 and torch.equal(ma[..., m:-m, m:-m], a[..., m:-m, m:-m]) and torch.equal(mb[..., m:-m, m:-m], b2[..., m:-m, m:-m])
     imresize.kernels = {}
+
+
+def test_x3_generator_forward_and_input_gradient():
+    """upscale = 3 (one nearest-x3 upsampler, architecture.py:260-261; the reference's own constructor is broken for it, so there is no
+    golden fixture): forward and d/dx against the oracle, which implements the intended architecture."""
+    net = _rrdb(1, 3, 0)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = seeded_uniform((2, 3, 10, 13), 901)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    y = net(xg)
+    xc = x.clone().requires_grad_(True)
+    yo = ro.rrdb_forward(sd, xc, 1, 3, 0, prefix='model')
+    assert y.shape == yo.shape == (2, 3, 30, 39)
+    assert rel_l2(y.detach().cpu().numpy(), yo.detach().numpy()) < 1e-4
+    cot = seeded_uniform(tuple(yo.shape), 902, -1, 1)
+    (y * cot.to(DEV)).sum().backward()
+    (yo * cot).sum().backward()
+    assert rel_l2(xg.grad.cpu().numpy(), xc.grad.numpy()) < 5e-2
+    assert np.median(np.abs(xg.grad.cpu().numpy() - xc.grad.numpy())) < 2e-4 * np.sqrt((xc.grad.numpy() ** 2).mean())
