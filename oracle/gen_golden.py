@@ -176,6 +176,30 @@ def gen_F4():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_fwd_bwd.npz'), **out)
 
 
+def gen_F7():
+    """RRDBNet with the latent fed to the FIRST layer only ('first_layer_HR_downscaled', architecture.py:245-246,288-299): forward,
+    input gradient and weight-gradient digests.  A separate fixture file so that F4's stays byte-identical."""
+    import models.modules.architecture as arch
+    out = {}
+    for name, nb, sf, lat in [('nb1_x4_lat3_first', 1, 4, 3), ('nb2_x2_lat1_first', 2, 2, 1)]:
+        torch.manual_seed(0)
+        net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu',
+                           mode='CNA', upsample_mode='upconv', latent_input='first_layer_HR_downscaled', num_latent_channels=lat)
+        n = fill_formula_weights(net, gain=1.0)
+        x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 61 + nb + sf + lat, -1.0, 1.0)
+        x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+        x.requires_grad_(True)
+        y = net(x)
+        cot = seeded_uniform(tuple(y.shape), 71 + nb + sf + lat, -1.0, 1.0)
+        (y * cot).sum().backward()
+        out[name + '/out'] = y.detach().numpy()
+        out[name + '/dx'] = x.grad.numpy()
+        out[name + '/dparams'] = np.stack([_param_digest(p.grad) for _, p in net.named_parameters()])
+        out[name + '/nparams'] = np.array([n, sum(p.numel() for p in net.parameters())])
+        print(name, tuple(y.shape), float(y.detach().abs().mean()), float(x.grad.abs().mean()))
+    np.savez_compressed(os.path.join(GOLDEN, 'rrdb_first_layer.npz'), **out)
+
+
 def _wrapped_G(nb, sf, lat=0, kernel=None, gain=1.0):
     import models.modules.architecture as arch
     cem = _cem(sf, kernel)
@@ -237,7 +261,7 @@ def gen_F6():
     np.savez_compressed(os.path.join(GOLDEN, 'c2_rrdb23_probe.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6}
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7}
 
 if __name__ == '__main__':
     _refshim.install()

@@ -278,3 +278,24 @@ def test_x3_generator_forward_and_input_gradient():
     (yo * cot).sum().backward()
     assert rel_l2(xg.grad.cpu().numpy(), xc.grad.numpy()) < 5e-2
     assert np.median(np.abs(xg.grad.cpu().numpy() - xc.grad.numpy())) < 2e-4 * np.sqrt((xc.grad.numpy() ** 2).mean())
+
+
+@pytest.mark.parametrize('name,nb,sf,lat', [('nb1_x4_lat3_first', 1, 4, 3), ('nb2_x2_lat1_first', 2, 2, 1)])
+def test_rrdb_first_layer_latent_matches_reference_golden(name, nb, sf, lat):
+    """latent_input = 'first_layer_HR_downscaled': Z (bilinear / sf) enters fea_conv only; forward and d/dx (LR and Z channels)."""
+    import models.modules.architecture as arch
+    g = load('rrdb_first_layer.npz')
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input='first_layer_HR_downscaled', num_latent_channels=lat)
+    n = fill_formula_weights(net, gain=1.0)
+    assert [n, sum(p.numel() for p in net.parameters())] == [int(v) for v in g[name + '/nparams']]
+    net = net.to(DEV)
+    x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 61 + nb + sf + lat, -1.0, 1.0)
+    x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+    x = x.to(DEV).requires_grad_(True)
+    y = net(x)
+    assert rel_l2(y.detach().cpu().numpy(), g[name + '/out']) < 1e-4
+    cot = seeded_uniform(tuple(y.shape), 71 + nb + sf + lat, -1.0, 1.0).to(DEV)
+    (y * cot).sum().backward()
+    dx, ref = x.grad.cpu().numpy(), g[name + '/dx']
+    assert rel_l2(dx, ref) < 5e-2 and np.median(np.abs(dx - ref)) < 2e-4 * np.sqrt((ref ** 2).mean())

@@ -202,3 +202,33 @@ def test_c2_rrdb23_probe_matches_reference():
         y = co.cem_combine(xp, gen, t, crop=True)
     assert rel_l2(y[:, :, 200:264, 300:364].numpy(), g['crop64']) < 5e-6
     assert rel_l2(y[:, :, 3::8, 5::8].numpy(), g['stride8']) < 5e-6
+
+
+F7_CASES = [('nb1_x4_lat3_first', 1, 4, 3), ('nb2_x2_lat1_first', 2, 2, 1)]
+
+
+def f7_input(nb, sf, lat):
+    x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 61 + nb + sf + lat, -1.0, 1.0)
+    x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+    return x
+
+
+def first_layer_keys(nb, sf, lat):
+    """RRDBNet('first_layer_*'): only fea_conv sees the latent channels."""
+    keys, shapes = rrdb_keys(nb, sf, 0)
+    shapes[0] = (64, 3 + lat, 3, 3)
+    return keys, shapes
+
+
+@pytest.mark.parametrize('name,nb,sf,lat', F7_CASES, ids=[c[0] for c in F7_CASES])
+def test_rrdb_first_layer_latent_matches_reference(name, nb, sf, lat):
+    g = load('rrdb_first_layer.npz')
+    keys, shapes = first_layer_keys(nb, sf, lat)
+    sd = formula_state_dict(keys, shapes)
+    assert int(g[name + '/nparams'][1]) == sum(int(np.prod(s)) for s in shapes)
+    x = f7_input(nb, sf, lat).requires_grad_(True)
+    y = ro.rrdb_forward(sd, x, nb, sf, lat, first_layer_only=True)
+    assert rel_l2(y.detach().numpy(), g[name + '/out']) < 2e-6
+    cot = seeded_uniform(tuple(y.shape), 71 + nb + sf + lat, -1.0, 1.0)
+    (y * cot).sum().backward()
+    assert rel_l2(x.grad.numpy(), g[name + '/dx']) < 5e-6
