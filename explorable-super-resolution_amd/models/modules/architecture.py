@@ -36,6 +36,11 @@ class RRDBNet(nn.Module):
             num_latent_channels, num_latent_channels_HR = 0, 0
         if norm_type is not None:
             raise NotImplementedError('RRDBNet with normalisation layers is not on the RRDB+CEM path (reference default: norm_type=null)')
+        if act_type != 'leakyrelu' or mode != 'CNA':
+            # the fused kernels implement conv -> LeakyReLU(0.2) (what define_G hard-wires, networks.py:97-99) and nothing else
+            raise NotImplementedError("RRDBNet(act_type=%r, mode=%r): the HIP engine implements act_type='leakyrelu', mode='CNA' only" % (act_type, mode))
+        if nf != 64 or out_nc < 1 or in_nc < 1:
+            raise NotImplementedError('RRDBNet(nf=%r): the dense-block buffer layout is built for nf = 64, gc = 32 (the reference ignores gc too)' % nf)
 
         fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, return_module_list=True)
         # NB: like the reference (architecture.py:250) the `gc` argument is ignored: growth channels are 32.

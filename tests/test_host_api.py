@@ -296,3 +296,16 @@ def test_cabi_argument_validation_without_a_gpu():
     w.B, w.H, w.W, w.cout, w.cin_main = 2, 16, 40, 64, 192   # 2 images x (2 x 2) tiles of 8x32 pixels; 6 input tiles x 2 output tiles
     n = h.esr_conv3x3_wgrad_workspace_floats(C.byref(w))
     assert n == 12 * 8 * 9 * 1024 + 2 * 8 * 32               # every tile its own slice (8), 9 x 32 x 32 partial block + bias partials
+
+
+def test_unsupported_generator_configurations_fail_loudly():
+    """What the fused kernels do not implement must raise at construction, never run something else silently."""
+    import models.modules.architecture as arch
+    base = dict(in_nc=3, out_nc=3, nf=64, nb=1, upscale=4, num_latent_channels=0)
+    arch.RRDBNet(**base)
+    for bad in (dict(norm_type='batch'), dict(act_type='relu'), dict(mode='NAC'), dict(nf=32), dict(upsample_mode='nearest')):
+        with pytest.raises(NotImplementedError):
+            arch.RRDBNet(**dict(base, **bad))
+    net = arch.RRDBNet(**dict(base, upsample_mode='pixelshuffle'))          # constructible (state_dict parity), not executable
+    with pytest.raises(Exception):
+        net(torch.zeros(1, 3, 8, 8))
