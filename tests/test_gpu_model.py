@@ -149,3 +149,24 @@ def test_z_optimizer_on_real_generator_matches_oracle_run(objective):
     assert np.median(np.abs(Zg - Zc)) < 2e-4 and rel_l2(Zg, Zc) < 5e-2
     assert float(np.abs(Zg - z0.numpy()).max()) > 1e-3          # it did move
     assert flags0 == flags1 and any(flags1)                     # the model's grad flags are restored after the search
+
+
+def test_z_optimizer_training_mode_leaves_a_differentiable_forward():
+    """The train-time use of the Z search (train.py's optimized-Z step; Z_optimization.py:603,788-795): the model is in training mode,
+    the loss is taken on the HR_unpadder crop, Z starts random, and after the search one more forward with the FOUND Z is left on the
+    model with the generator's parameters attached to the graph, ready for optimize_parameters()-style backward."""
+    from Z_optimization import Z_optimizer
+    m = _model(1, 3, is_train=True)
+    lr = seeded_uniform((2, 3, 24, 26), 231)
+    m.feed_data({'LR': lr, 'HR': seeded_uniform((2, 3, 96, 104), 232), 'Z': torch.zeros(2, 3, 96, 104)})
+    desired = seeded_uniform((2, 3, 96, 104), 233)
+    unpad = m.CEM_net.HR_unpadder
+    zo = Z_optimizer(objective='l1', Z_size=[96, 104], model=m, Z_range=1, max_iters=3, data={'LR': lr, 'desired': unpad(desired)},
+                     initial_LR=0.05, batch_size=2, HR_unpadder=unpad)
+    Z = zo.optimize()
+    assert Z.shape == (2, 3, 96, 104) and float(Z.abs().max()) <= 1.0 and not Z.requires_grad
+    assert len(zo.loss_values) == 3 and all(np.isfinite(zo.loss_values))
+    assert m.fake_H.requires_grad                                   # the final forward carries the generator's graph
+    assert all(p.requires_grad for n, p in m.netG.named_parameters() if 'Filter_OP' not in n)
+    m.fake_H.mean().backward()
+    assert m.netG.generated_image_model.model[0].weight.grad is not None
