@@ -60,10 +60,13 @@ def cpu_baseline(G, cem):
     g = torch.Generator().manual_seed(1)
     x = torch.rand(1, 3, LR_SIZE, LR_SIZE, generator=g)
 
+    keep = {}
+
     def run():
         with torch.no_grad():
             xp = torch.nn.functional.pad(x, (taps.margins_LR,) * 4, mode='replicate')
             gen = ro.rrdb_forward(sd, xp, NB, SF, 0, prefix='generated_image_model.model')
+            keep['gen'] = gen
             return co.cem_combine(xp, gen, taps, crop=True)
     run()
     ts = []
@@ -72,6 +75,7 @@ def cpu_baseline(G, cem):
         y = run()
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
+    cpu_baseline.generator_output = keep['gen']      # the oracle's generator output on the padded frame (parity figure in the bench line)
     return {'value': (SF * LR_SIZE) ** 2 / t, 'unit': 'HR pixels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval), median of 3 runs, %.2f s each' % t}, x, y
 
@@ -83,7 +87,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default='split', choices=['split', 'f16x2', 'bf16', 'f16'], help="experiments: the headline is 'split' (fp32-class)")
+    ap.add_argument('--no-alt-precision', action='store_true', help="skip the extra timing of the 'mixed' fp16 mode")
+    ap.add_argument('--precision', default='split', choices=['split', 'mixed', 'f16x2', 'bf16', 'f16'], help="experiments: the headline is 'split' (fp32-class)")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
     args = ap.parse_args()
     if args.batch != BATCH:
@@ -168,11 +173,13 @@ def main():
         out = {
             'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'f32', 'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'f32', 'mixed': 'f16 hi+lo', 'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
                        'arithmetic': {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
                                       'f16': 'f16 MFMA operands, fp32 accumulate',
-                                      'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate'}[args.precision],
+                                      'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate',
+                                      'mixed': 'f16 hi+lo activations; f16 hi+lo weights (3 MFMAs) in the 6 convs outside the dense blocks, '
+                                               'f16 weights (2 MFMAs) in the 345 dense-block convs; fp32 accumulate'}[args.precision],
                        'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
@@ -180,9 +187,9 @@ def main():
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
                          'generator_ms_per_step': conv_ms,
                          'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 2.08}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
                          # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
-                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
+                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 2.08}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
@@ -192,6 +199,30 @@ def main():
                 yg = G(xs.to(dev)).cpu()
             out['rel_l2_vs_cpu_oracle'] = float((yg - ys).norm() / ys.norm())
             out['rel_max_vs_cpu_oracle'] = float((yg - ys).abs().max() / ys.abs().max())
+            net = G.generated_image_model
+            gen_ref = cpu_baseline.generator_output
+
+            def gen_err():
+                with torch.no_grad():
+                    gg = net(xs.to(dev), pad=MARGIN_LR).cpu()
+                return float((gg - gen_ref).norm() / gen_ref.norm())
+            out['generator_rel_l2_vs_cpu_oracle'] = gen_err()       # the generator alone (the CEM output above is dominated by the LR content)
+            if args.precision == 'split' and not args.no_alt_precision:
+                # NOT the headline: the same workload in the 'mixed' fp16 mode (fp16 hi+lo activations; hi+lo weights in the 6 convs outside
+                # the dense blocks, single-plane weights in the 345 dense-block convs), with its own parity figure
+                net.set_precision('mixed')
+                for _ in range(2):
+                    step()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync()
+                dta = time.perf_counter() - t0
+                out['alt_precision'] = {'mode': 'mixed', 'ms_per_step': dta / args.steps * 1e3, 'value': hr_px * args.steps / dta, 'unit': 'HR pixels/s',
+                                        'generator_rel_l2_vs_cpu_oracle': gen_err(),
+                                        'note': 'not the headline; fp16 hi+lo (22-bit) activations, 11-bit weights in the dense-block convs'}
+                net.set_precision('split')
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

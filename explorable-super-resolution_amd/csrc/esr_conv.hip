@@ -233,11 +233,10 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
-template <int NPL, int MT, int EPI, int NST, int FMT>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW>
 __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
-    // weight planes: bf16 packs carry hi (+ lo with split activations); f16 packs are always one plane — with f16 hi+lo activations
-    // that is the 2-MFMA mode (Whi*Xlo + Whi*Xhi)
-    constexpr int NPW = FMT ? 1 : NPL;
+    // NPW = weight planes: with hi+lo activations, 2 planes = 3 MFMAs per product (Wlo*Xhi + Whi*Xlo + Whi*Xhi), 1 plane = 2
+    static_assert(NPW <= NPL, "a lo weight plane needs hi+lo activations");
     constexpr int R = r_of(MT), MAXS = maxs_of(MT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -542,7 +541,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
         float v = 0.f;
         if (kch >= 0 && mch >= 0)
             v = transposed ? w[((long long)kch * dim1 + mch) * 9 + (8 - t)] : w[((long long)mch * dim1 + kch) * 9 + t];
-        if (f16) { hi[e] = f2h(v * scale); lo[e] = 0; }
+        if (f16) { hi[e] = f2h(v * scale); lo[e] = f2h(v * scale - h2f(hi[e])); }
         else split_bf16(v * scale, hi[e], lo[e]);
     }
     uint4* o = out + ((size_t)(ks * mtiles + m) * npl) * 64 + lane;
@@ -573,7 +572,7 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ table, c
         float v = 0.f;
         if (kch >= 0 && mch >= 0)
             v = e.transposed ? e.w[((long long)kch * e.dim1 + mch) * 9 + (8 - t)] : e.w[((long long)mch * e.dim1 + kch) * 9 + t];
-        if (e.f16) { hi[c] = f2h(v * e.scale); lo[c] = 0; }
+        if (e.f16) { hi[c] = f2h(v * e.scale); lo[c] = f2h(v * e.scale - h2f(hi[c])); }
         else split_bf16(v * e.scale, hi[c], lo[c]);
     }
     uint4* o = e.out + ((size_t)(ks * e.mtiles + mt) * e.npl) * 64 + lane;
@@ -621,11 +620,10 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI, int NST, int FMT>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW>;
     ESR_ALLOW_160K_LDS(k);
-    constexpr int NPW = FMT ? 1 : NPL;
     const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
@@ -634,41 +632,41 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI, int FMT>
+template <int NPL, int MT, int EPI, int FMT, int NPW>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool two = force ? force == 2 : ntiles <= 320;
-    return two ? launch_nst<NPL, MT, EPI, 2, FMT>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT>(a, s);
+    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
-template <int NPL, int MT, int FMT>
+template <int NPL, int MT, int FMT, int NPW>
 int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
     if (FMT == 1) {              // f16: the inference forward only (no data-gradient epilogues)
         switch (epi) {
-            case 0: return launch<NPL, MT, 0, FMT>(a, s);
-            case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT>(a, s);
-            case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT>(a, s);
-            case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT>(a, s);
-            case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT>(a, s);
-            case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT>(a, s);
-            case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT>(a, s);
+            case 0: return launch<NPL, MT, 0, FMT, NPW>(a, s);
+            case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW>(a, s);
+            case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW>(a, s);
+            case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW>(a, s);
+            case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW>(a, s);
+            case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW>(a, s);
+            case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW>(a, s);
             default: return ESR_E_UNSUPPORTED;
         }
     }
     switch (epi) {
-        case 0: return launch<NPL, MT, 0, FMT>(a, s);
-        case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT>(a, s);
-        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT>(a, s);
-        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT>(a, s);
-        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT>(a, s);
-        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT>(a, s);
-        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT>(a, s);
-        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT>(a, s);
-        case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT>(a, s);
+        case 0: return launch<NPL, MT, 0, FMT, NPW>(a, s);
+        case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW>(a, s);
+        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW>(a, s);
+        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW>(a, s);
+        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW>(a, s);
+        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW>(a, s);
+        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW>(a, s);
+        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT, NPW>(a, s);
+        case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
 }
@@ -681,7 +679,7 @@ extern "C" void esr_debug_trace(void* buf) { g_trace = (unsigned long long*)buf;
 
 extern "C" size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split) {
     const int ncp = (ncg_in + 1) / 2, mt = (cout + 31) / 32;
-    return (size_t)ncp * 9 * mt * (split == 1 ? 2 : 1) * 64 * 16;
+    return (size_t)ncp * 9 * mt * ((split == 1 || split == 3) ? 2 : 1) * 64 * 16;
 }
 
 extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, const int32_t* kmap, int ncg_in, const int32_t* mmap,
@@ -691,7 +689,7 @@ extern "C" int esr_pack_conv_weights(const float* w, int cout_w, int cin_w, cons
     const int total = ncp * 9 * mtiles * 64;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w, kmap,
-                       ncg_in, mmap, mtiles, transposed, split == 1 ? 2 : 1, split == 2 ? 1 : 0, scale, (uint4*)wpack, total);
+                       ncg_in, mmap, mtiles, transposed, (split == 1 || split == 3) ? 2 : 1, split >= 2 ? 1 : 0, scale, (uint4*)wpack, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -725,7 +723,7 @@ extern "C" int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void
         PackEntry& e = table[i];
         e.w = descs[i].w; e.kmap = descs[i].kmap; e.mmap = descs[i].mmap; e.out = (uint4*)descs[i].wpack;
         e.dim0 = descs[i].cout_w; e.dim1 = descs[i].cin_w; e.ncg_in = descs[i].ncg_in; e.mtiles = descs[i].mtiles;
-        e.transposed = descs[i].transposed; e.npl = descs[i].split == 1 ? 2 : 1; e.f16 = descs[i].split == 2 ? 1 : 0; e.scale = descs[i].scale;
+        e.transposed = descs[i].transposed; e.npl = (descs[i].split == 1 || descs[i].split == 3) ? 2 : 1; e.f16 = descs[i].split >= 2 ? 1 : 0; e.scale = descs[i].scale;
         e.total = ((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
         for (int j = 0; j < (e.total + 255) / 256; ++j) map[(size_t)b++] = make_int2(i, j);
     }
@@ -823,8 +821,12 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->out2.hi) epi |= EPI_OUT2;
     if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
-    if (f16 && split) return mt == 1 ? launch_epi<2, 1, 1>(a, epi, s) : launch_epi<2, 2, 1>(a, epi, s);
-    if (f16) return mt == 1 ? launch_epi<1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1>(a, epi, s);
-    if (split) return mt == 1 ? launch_epi<2, 1, 0>(a, epi, s) : launch_epi<2, 2, 0>(a, epi, s);
-    return mt == 1 ? launch_epi<1, 1, 0>(a, epi, s) : launch_epi<1, 2, 0>(a, epi, s);
+    int wpl = d->weight_planes;
+    if (wpl == 0) wpl = f16 ? 1 : npl;
+    if (wpl < 1 || wpl > npl || (!f16 && wpl != npl)) return ESR_E_ARG;
+    if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);
+    if (f16 && split) return mt == 1 ? launch_epi<2, 1, 1, 1>(a, epi, s) : launch_epi<2, 2, 1, 1>(a, epi, s);
+    if (f16) return mt == 1 ? launch_epi<1, 1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1, 1>(a, epi, s);
+    if (split) return mt == 1 ? launch_epi<2, 1, 0, 2>(a, epi, s) : launch_epi<2, 2, 0, 2>(a, epi, s);
+    return mt == 1 ? launch_epi<1, 1, 0, 1>(a, epi, s) : launch_epi<1, 2, 0, 1>(a, epi, s);
 }

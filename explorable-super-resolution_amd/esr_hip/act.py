@@ -19,9 +19,11 @@ def stream_ptr():
 
 
 # operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 'f16' = one fp16 plane,
-# 'f16x2' = fp16 hi+lo activation planes with single-plane fp16 weights
+# 'f16x2' = fp16 hi+lo activation planes with single-plane fp16 weights, 'f16x3' = fp16 hi+lo activations AND weights
 def fmt_code(split):
-    """Weight-pack format code of include/esr_hip.h (0 bf16, 1 split bf16, 2 f16)."""
+    """Weight-pack format code of include/esr_hip.h (0 bf16, 1 split bf16, 2 f16, 3 f16 hi+lo)."""
+    if split == 'f16x3':
+        return 3
     if split in ('f16', 'f16x2'):
         return 2
     return 1 if split else 0
@@ -31,7 +33,7 @@ def act_planes(split):
     """(number of activation planes, esr_act_view.fmt)"""
     if split == 'f16':
         return 1, 1
-    if split == 'f16x2':
+    if split in ('f16x2', 'f16x3', 'mixed'):
         return 2, 1
     return (2, 0) if split else (1, 0)
 
@@ -184,18 +186,18 @@ class PackBatch:
     def __init__(self):
         self.ptr_key, self.ws, self.n, self.nblocks = None, None, 0, 0
 
-    def run(self, packs, split):
+    def run(self, packs):
         jobs = []
         for pk in packs:
             pk.prepare()
-            jobs += pk.jobs()
+            jobs += [j + (fmt_code(pk.split),) for j in pk.jobs()]
         ptr_key = tuple((j[0].data_ptr(), j[7]) for j in jobs)
         if ptr_key != self.ptr_key:
             arr = (_lib.PackDesc * len(jobs))()
-            for d, (wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst) in zip(arr, jobs):
+            for d, (wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst, code) in zip(arr, jobs):
                 d.w, d.cout_w, d.cin_w = wd.data_ptr(), wd.shape[0], wd.shape[1]
                 d.kmap, d.ncg_in, d.mmap, d.mtiles = kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles
-                d.transposed, d.split, d.scale, d.wpack = transposed, fmt_code(split), float(scale), dst
+                d.transposed, d.split, d.scale, d.wpack = transposed, code, float(scale), dst
             need = _lib.lib.esr_pack_batch_workspace_bytes(arr, len(jobs))
             check(min(need, 0), 'esr_pack_batch_workspace_bytes')
             self.ws = torch.empty(int(need), dtype=torch.uint8, device=jobs[0][0].device)
@@ -299,6 +301,7 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
         reverse = bool(_launch_parity & 1) and ALTERNATE_ORDER
         _launch_parity += 1
     d.reverse_order = 1 if reverse else 0
+    d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
 
 

@@ -40,7 +40,9 @@ class RRDBEngine:
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
-        split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2'}[precision]
+        # 'mixed': fp16 hi+lo activations everywhere; hi+lo weights (3 MFMAs) in the few layers outside the dense blocks, whose weight
+        # rounding would dominate the output error, single-plane weights (2 MFMAs) in the dense-block convs
+        split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[precision]
         if split != self.split:
             self.split = split
             self._packed = None
@@ -73,11 +75,17 @@ class RRDBEngine:
         """Re-pack every existing pack (forward and data-gradient ones) in one launch if any parameter changed since the last time."""
         packs = [p for d in (self._packed, self._packed_t, self._packed_rdb_t) if d for p in d.values()]
         if any(p.stale() for p in packs):
-            self._pack_batch.run(packs, self.split)
+            self._pack_batch.run(packs)
+
+    def _wfmt(self, name):
+        """Weight format of one layer's forward pack."""
+        if self.split != 'mixed':
+            return self.split
+        return 'f16x2' if name.startswith('rrdb') else 'f16x3'
 
     def packed(self):
         if self._packed is None:
-            self._packed = {name: A.PackedConv(c.weight, c.bias, lat, split=self.split) for name, c, lat in self._convs()}
+            self._packed = {name: A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name)) for name, c, lat in self._convs()}
         self._refresh_packs()
         return self._packed
 
@@ -267,7 +275,7 @@ class RRDBEngine:
     # ------------------------------------------------------------------ backward
     def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
-        if self.split in ('f16', 'f16x2'):
+        if self.split in ('f16', 'f16x2', 'mixed'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
         net, sp = self.net, self.split

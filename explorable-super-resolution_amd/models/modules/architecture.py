@@ -81,7 +81,7 @@ class RRDBNet(nn.Module):
         """'split' (default; bf16 hi+lo operands, 3 MFMAs per product, fp32-class accuracy), 'f16x2' (fp16 weights x fp16 hi+lo activations, 2 MFMAs,
         ~5e-4 on RRDB-23, inference-only), 'bf16' or 'f16' (single-MFMA modes with fp32 accumulation; 'f16' is ~8x more accurate than
         'bf16' and inference-only)."""
-        assert precision in ('split', 'f16x2', 'f16', 'bf16')
+        assert precision in ('split', 'mixed', 'f16x2', 'f16', 'bf16')
         self.engine.set_precision(precision)
 
     def forward(self, x, pad=0):

@@ -43,7 +43,7 @@ typedef void* esr_stream_t;   /* hipStream_t */
 /* Element formats of an activation view.  BF16 with a `lo` plane is the fp32-class mode (split operands, 3 MFMAs per product);
  * BF16 / F16 without `lo` are the single-MFMA reduced-precision modes; F16 with `lo` is the 2-MFMA mode (f16 weights x f16 hi+lo
  * activations).  The reference has no counterpart of these; the F16 modes are inference-only (gradients would need loss scaling).
- * Weight packs use the matching code in their `split` argument: 0 bf16, 1 split bf16 (hi+lo), 2 f16 (always one plane). */
+ * Weight packs use the matching code in their `split` argument: 0 bf16, 1 split bf16 (hi+lo), 2 f16 (one plane), 3 f16 hi+lo. */
 #define ESR_FMT_BF16 0
 #define ESR_FMT_F16 1
 
@@ -95,12 +95,16 @@ typedef struct {
      * re-read what the previous launch just touched; alternating the direction lets the tail of one launch, still in the 256 MB
      * Infinity Cache, be the head of the next. */
     int32_t reverse_order;
+    /* planes of the weight pack: 0 = the format's default (bf16: as many as the activations; f16: one), or 1 / 2 explicitly.
+     * f16 hi+lo activations with 2 weight planes is the 3-MFMA fp16 form (2^-22 operands) used for the few layers whose weight
+     * rounding dominates the output error; with 1 plane it is the 2-MFMA form. */
+    int32_t weight_planes;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
 
 /* Packed-weight size in bytes for `ncg_in` input groups and `cout` output channels
- * (`split` = 1: bf16 hi+lo planes; 0: bf16 hi only; 2: f16, one plane). */
+ * (`split` = 1: bf16 hi+lo planes; 0: bf16 hi only; 2: f16, one plane; 3: f16 hi+lo planes). */
 size_t esr_conv_wpack_bytes(int ncg_in, int cout, int split);
 
 /* Pack nn.Conv2d weights [cout_w][cin_w][3][3] (fp32, device) into MFMA fragment order.

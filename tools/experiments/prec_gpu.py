@@ -12,7 +12,7 @@ for init in ['kaiming0.1', 'formula']:
     x = torch.rand(1, 3, 40, 40)
     ref = ro.rrdb_forward(sd, x, 23, 4, 0, prefix='generated_image_model.model')
     net = G.generated_image_model
-    for prec in ['split', 'f16x2', 'f16', 'bf16']:
+    for prec in ['split', 'mixed', 'f16x2', 'f16', 'bf16']:
         net.set_precision(prec)
         with torch.no_grad():
             y = net(x.cuda()).cpu()
