@@ -25,6 +25,7 @@
 //                  v_permlane32_swap so that every lane stores one full 16-byte pixel vector
 #include "esr_common.h"
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -74,6 +75,7 @@ struct ConvArgs {
     int mask_cg0, mask_cg1;
     float mask_slope;
     int reverse;                    // walk the tile space backwards (cache-reuse hint)
+    int lo_chunks;                  // chunks [0, lo_chunks) carry a lo activation plane, later ones are hi-only (PARTLO kernels)
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
 #ifdef ESR_TRACE
@@ -172,11 +174,13 @@ __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int 
 // the DMA of one step is a list of independent 1 KiB instructions so that it can be issued in slices between MFMAs:
 // ops [0, 2*NPL*MAXS) = activation slot s, plane (group, hi|lo);  then ceil(9*MT*NPL / NW) weight-fragment ops
 template <int NPL, int MT, int NPW>
-__device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave) {
+__device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave,
+                                       bool xlo = true) {
     constexpr int MAXS = maxs_of(MT);
     constexpr int NWI = 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
     if (op < NACT) {
         const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
+        if (!xlo && (cgpl % NPL) == 1) return;      // this chunk's groups have no lo plane
         const int so = f.soff[s];
         const int slot = f.slot[s];
         if (so >= 0) glds16(bs.p[cgpl] + so, stage + cgpl * plane_bytes + slot * 1024);
@@ -227,14 +231,99 @@ __device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (
     }
 }
 
+// EPI_RESIN: the two input groups of chunk cp are in the LDS stage right now; if they belong to the residual slice, add this lane's 4
+// channels of the centre-tap pixel (exactly hi + lo, in fp32) to the matching accumulator rows.
+template <int NPL, int MT, int R, int FMT>
+__device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const ConvArgs& a, const unsigned char* stage, int cp, bool xlo, int P,
+                                                 int plane_bytes, int wave, int lane) {
+#pragma unroll
+    for (int sgrp = 0; sgrp < 2; ++sgrp) {
+        const int og = 2 * cp + sgrp - a.resin_g0;              // output group fed by this input group (uniform)
+        if (og < 0 || og * 8 >= a.cout) continue;
+#pragma unroll
+        for (int mg = 0; mg < MT * 4; ++mg) {
+            if (og != mg) continue;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned char* const pr = stage + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
+                const uint2 h = *(const uint2*)pr;
+                float x0 = e2f<FMT>(h.x & 0xFFFF), x1 = e2f<FMT>(h.x >> 16), x2 = e2f<FMT>(h.y & 0xFFFF), x3 = e2f<FMT>(h.y >> 16);
+                if (NPL == 2 && xlo) {
+                    const uint2 l = *(const uint2*)(pr + plane_bytes);
+                    x0 += e2f<FMT>(l.x & 0xFFFF); x1 += e2f<FMT>(l.x >> 16); x2 += e2f<FMT>(l.y & 0xFFFF); x3 += e2f<FMT>(l.y >> 16);
+                }
+                acc[mg / 4][r][(mg % 4) * 4 + 0] = fmaf(a.resin_scale, x0, acc[mg / 4][r][(mg % 4) * 4 + 0]);
+                acc[mg / 4][r][(mg % 4) * 4 + 1] = fmaf(a.resin_scale, x1, acc[mg / 4][r][(mg % 4) * 4 + 1]);
+                acc[mg / 4][r][(mg % 4) * 4 + 2] = fmaf(a.resin_scale, x2, acc[mg / 4][r][(mg % 4) * 4 + 2]);
+                acc[mg / 4][r][(mg % 4) * 4 + 3] = fmaf(a.resin_scale, x3, acc[mg / 4][r][(mg % 4) * 4 + 3]);
+            }
+        }
+    }
+}
+
+// The MFMAs of one chunk (2 channel groups x 9 taps) out of one LDS stage, with the fragment reads of tap t+1 interleaved between the
+// MFMAs of tap t (sched_barrier-pinned).  XLO: the chunk's activations have a lo plane.  Terms per product, in issue order:
+// Wlo*Xhi (if the weights have a lo plane), Whi*Xlo (if XLO), Whi*Xhi.
+template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP>
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes) {
+    constexpr int NPB = XLO ? NPL : 1;                                   // activation planes read
+    constexpr int NT_FULL = 1 + (NPW == 2 ? 1 : 0) + (NPB == 2 ? 1 : 0);
+    constexpr int NTERM = NT_FULL < NTERM_CAP ? NT_FULL : NTERM_CAP;      // NTERM_CAP < 3 only in ablation builds
+    constexpr int NM = MT * R * NTERM;
+    constexpr int NLA = MT * NPW, NLB = R * NPB, NL = NLA + NLB;
+    constexpr int NSLOT = NM > NL ? NM : NL;
+    uint4 fa[2][MT][NPW], fb[2][R][NPB];
+    // read order inside a tap: [A plane of the first term x MT, B hi x R, then the other A plane x MT (if any), B lo x R (if any)] — what
+    // the first MFMAs of the next tap need comes first
+    auto load_frag = [&](int t, int k, int buf) {
+        const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+        if (k < MT) {
+            const int pl = NPW == 2 ? 1 : 0;
+            fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
+        } else if (k < MT + R) {
+            fb[buf][k - MT][0] = *(const uint4*)(sb + (k - MT) * NW * 512 + tapoff);
+        } else if (NPW == 2 && k < 2 * MT + R) {
+            const int idx = k - MT - R;
+            fa[buf][idx][0] = *(const uint4*)(sa + ((t * MT + idx) * NPW) * 1024);
+        } else {
+            const int idx = k - (NPW == 2 ? 2 * MT + R : MT + R);
+            fb[buf][idx][NPB - 1] = *(const uint4*)(sb + idx * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int cb = t & 1;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NM) {
+                // the NTERM terms are the LAST NTERM entries of [Wlo*Xhi (needs NPW == 2), Whi*Xlo (needs XLO), Whi*Xhi]
+                const int ti = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
+                constexpr int has0 = NPW == 2 ? 1 : 0, has1 = NPB == 2 ? 1 : 0;
+                const int skip = NT_FULL - NTERM;                             // ablation: drop leading terms
+                const int idx = ti + skip;                                    // index into the present-term list
+                const int term = (idx < has0) ? 0 : ((idx < has0 + has1) ? 1 : 2);
+                const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+                acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+            }
+            if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // One output tile per workgroup.
 //   NST == 1: single LDS stage, 2 workgroups resident per CU: latency hiding comes from the co-resident workgroup instead of an
 //             in-workgroup pipeline (the persistent multi-stage variant measured slower).  Large launches.
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
+    // PARTLO: only the first a.lo_chunks chunks of the input carry a lo plane (a dense block's trunk input), the rest are single-plane
+    // intermediates; and the output's lo plane is optional.  Non-PARTLO kernels treat every chunk alike.
+    static_assert(!PARTLO || NPL == 2, "partial lo needs hi+lo activations");
     // NPW = weight planes: with hi+lo activations, 2 planes = 3 MFMAs per product (Wlo*Xhi + Whi*Xlo + Whi*Xhi), 1 plane = 2
     static_assert(NPW <= NPL, "a lo weight plane needs hi+lo activations");
     constexpr int R = r_of(MT), MAXS = maxs_of(MT);
@@ -277,19 +366,22 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
 #ifdef ESR_ABL_TERMS
-    constexpr int NTERM = NPL == 2 ? ESR_ABL_TERMS : 1;   // ablation build: wrong results, timing only
+    constexpr int NTERM_CAP = ESR_ABL_TERMS;   // ablation build: wrong results, timing only
 #else
-    constexpr int NTERM = NPL == 2 ? (NPW == 2 ? 3 : 2) : 1;
+    constexpr int NTERM_CAP = 3;
 #endif
-    constexpr int NM = MT * R * NTERM;
-    constexpr int NL = (MT + R) * NPL;
-    constexpr int NSLOT = NM > NL ? NM : NL;
+    constexpr int NOPS_HI = NACT / NPL + NWOP;       // DMA instructions of a hi-only chunk
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
+        const bool xlo0 = !PARTLO || 0 < a.lo_chunks;
 #pragma unroll
-        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave);
+        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave, xlo0);
     }
-    for (int cp = 0; cp < a.ncp; ++cp) {
+    // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
+    // plane.  The chunks with a lo plane come first, so the K loop is two loops over the same step with XLO = true / false: a run-time
+    // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
+    auto step = [&](auto XLO_T, const int cp) {
+        constexpr bool xlo = decltype(XLO_T)::value;
         const int st = NST == 2 ? (cp & 1) : 0;
         const unsigned char* const sb = sb0 + st * stage_bytes;
         const unsigned char* const sa = sa0 + st * stage_bytes;
@@ -304,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #ifdef ESR_ABL_NOADMA
                 if (op < NACT && cp > 0) continue;
 #endif
-                dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave);
+                dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave, xlo);
             }
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,10 +404,12 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
             // everything EXCEPT the NOPS copies just issued (every wave issues exactly NOPS per chunk, see dma_op / setup_tile)
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 1, fs.b, lane);
+            const bool xlo_next = !PARTLO || cp + 1 < a.lo_chunks;
 #pragma unroll
-            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave);
+            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave, xlo_next);
             ESR_TR();
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS) : "memory");
+            if (xlo_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS_HI) : "memory");
         } else {
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,65 +417,15 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         ESR_TR();
         __syncthreads();
         ESR_TR();
-        uint4 fa[2][MT][NPW], fb[2][R][NPL];
-        auto load_frag = [&](int t, int k, int buf) {
-            const int tapoff = ((t / 3) * P + (t % 3)) * 16;
-            const int grp = k / (MT + R), idx = k % (MT + R);
-            const int pl_a = NPW == 2 ? 1 - grp : 0, pl_b = grp;
-            if (idx < MT) { if (NPW == 2 || grp == 0) fa[buf][idx][pl_a] = *(const uint4*)(sa + ((t * MT + idx) * NPW + pl_a) * 1024); }
-            else fb[buf][idx - MT][pl_b] = *(const uint4*)(sb + (idx - MT) * NW * 512 + tapoff + pl_b * plane_bytes);
-        };
-#pragma unroll
-        for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int cb = t & 1;
-#pragma unroll
-            for (int i = 0; i < NSLOT; ++i) {
-                if (i < NM) {
-                    // terms, last to first: Whi*Xhi, Whi*Xlo, Wlo*Xhi — a mode with fewer terms drops from the front of that list
-                    const int term = i / (MT * R) + (NPL == 2 ? 3 - NTERM : 0), rem = i % (MT * R), r = rem % R, m = rem / R;
-                    const int pa = (NPL == 2 && term == 0) ? 1 : 0, pb = (NPL == 2 && term == 1) ? 1 : 0;
-                    acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
-                }
-#ifdef ESR_ABL_NOLDS
-                if (t < 8 && i < NL && cp == 0) load_frag(t + 1, i, cb ^ 1);
-#else
-                if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr ((EPI & EPI_RESIN) != 0) {
-            // groups 2cp, 2cp+1 of the input are in LDS right now: if they belong to the residual slice, add this lane's 4
-            // channels of the centre-tap pixel (exactly hi + lo, in fp32) to the matching accumulator rows
-#pragma unroll
-            for (int sgrp = 0; sgrp < 2; ++sgrp) {
-                const int og = 2 * cp + sgrp - a.resin_g0;              // output group fed by this input group (uniform)
-                if (og < 0 || og * 8 >= a.cout) continue;
-#pragma unroll
-                for (int mg = 0; mg < MT * 4; ++mg) {
-                    if (og != mg) continue;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const unsigned char* const pr = smem + st * stage_bytes + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
-                        const uint2 h = *(const uint2*)pr;
-                        float x0 = e2f<FMT>(h.x & 0xFFFF), x1 = e2f<FMT>(h.x >> 16), x2 = e2f<FMT>(h.y & 0xFFFF), x3 = e2f<FMT>(h.y >> 16);
-                        if (NPL == 2) {
-                            const uint2 l = *(const uint2*)(pr + plane_bytes);
-                            x0 += e2f<FMT>(l.x & 0xFFFF); x1 += e2f<FMT>(l.x >> 16); x2 += e2f<FMT>(l.y & 0xFFFF); x3 += e2f<FMT>(l.y >> 16);
-                        }
-                        acc[mg / 4][r][(mg % 4) * 4 + 0] = fmaf(a.resin_scale, x0, acc[mg / 4][r][(mg % 4) * 4 + 0]);
-                        acc[mg / 4][r][(mg % 4) * 4 + 1] = fmaf(a.resin_scale, x1, acc[mg / 4][r][(mg % 4) * 4 + 1]);
-                        acc[mg / 4][r][(mg % 4) * 4 + 2] = fmaf(a.resin_scale, x2, acc[mg / 4][r][(mg % 4) * 4 + 2]);
-                        acc[mg / 4][r][(mg % 4) * 4 + 3] = fmaf(a.resin_scale, x3, acc[mg / 4][r][(mg % 4) * 4 + 3]);
-                    }
-                }
-            }
-        }
+        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes);
+        if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
         ESR_TR();
         __syncthreads();
-    }
+    };
+    const int lo_end = PARTLO ? (a.lo_chunks < a.ncp ? a.lo_chunks : a.ncp) : a.ncp;
+    for (int cp = 0; cp < lo_end; ++cp) step(std::true_type{}, cp);
+    if constexpr (PARTLO)
+        for (int cp = lo_end; cp < a.ncp; ++cp) step(std::false_type{}, cp);
     ESR_TR();
     {
         // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
@@ -505,11 +549,11 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                         if (cgs < ncg_out) {
                             const long long o = b * a.out.bs + cgs * a.out.cs + pix;
                             ((uint4*)a.out.hi)[o] = hv;
-                            if (NPL == 2) ((uint4*)a.out.lo)[o] = lv;
+                            if (NPL == 2 && (!PARTLO || a.out.lo)) ((uint4*)a.out.lo)[o] = lv;
                             if (EPI & EPI_OUT2) {
                                 const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
                                 ((uint4*)a.out2.hi)[o2] = hv;
-                                if (NPL == 2) ((uint4*)a.out2.lo)[o2] = lv;
+                                if (NPL == 2 && (!PARTLO || a.out2.lo)) ((uint4*)a.out2.lo)[o2] = lv;
                             }
                         }
                     }
@@ -620,9 +664,9 @@ TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
     ESR_ALLOW_160K_LDS(k);
     const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
@@ -632,41 +676,41 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI, int FMT, int NPW>
+template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool two = force ? force == 2 : ntiles <= 320;
-    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW>(a, s);
+    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
-template <int NPL, int MT, int FMT, int NPW>
+template <int NPL, int MT, int FMT, int NPW, bool PARTLO = false>
 int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
     if (FMT == 1) {              // f16: the inference forward only (no data-gradient epilogues)
         switch (epi) {
-            case 0: return launch<NPL, MT, 0, FMT, NPW>(a, s);
-            case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW>(a, s);
-            case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW>(a, s);
-            case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW>(a, s);
-            case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW>(a, s);
-            case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW>(a, s);
-            case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW>(a, s);
+            case 0: return launch<NPL, MT, 0, FMT, NPW, PARTLO>(a, s);
+            case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW, PARTLO>(a, s);
+            case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW, PARTLO>(a, s);
+            case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW, PARTLO>(a, s);
+            case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW, PARTLO>(a, s);
+            case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW, PARTLO>(a, s);
+            case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW, PARTLO>(a, s);
             default: return ESR_E_UNSUPPORTED;
         }
     }
     switch (epi) {
-        case 0: return launch<NPL, MT, 0, FMT, NPW>(a, s);
-        case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW>(a, s);
-        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW>(a, s);
-        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW>(a, s);
-        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW>(a, s);
-        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW>(a, s);
-        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW>(a, s);
-        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT, NPW>(a, s);
-        case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW>(a, s);
+        case 0: return launch<NPL, MT, 0, FMT, NPW, PARTLO>(a, s);
+        case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW, PARTLO>(a, s);
+        case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW, PARTLO>(a, s);
+        case EPI_RESIN: return launch<NPL, MT, EPI_RESIN, FMT, NPW, PARTLO>(a, s);
+        case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW, PARTLO>(a, s);
+        case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW, PARTLO>(a, s);
+        case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW, PARTLO>(a, s);
+        case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT, NPW, PARTLO>(a, s);
+        case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW, PARTLO>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
 }
@@ -762,8 +806,9 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     const int mt = (d->cout + 31) / 32;
     if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches
     if (d->out.hi && d->out.ncg * 8 < d->cout) return ESR_E_ARG;
-    if (d->out.hi && ((d->out.lo != nullptr) != split)) return ESR_E_ARG;
-    if (d->out2.hi && (!d->out.hi || (d->out2.lo != nullptr) != split)) return ESR_E_ARG;
+    // a missing lo OUTPUT plane with hi+lo inputs is the single-plane-intermediate case (fp16 formats only, checked below)
+    if (d->out.hi && d->out.lo && !split) return ESR_E_ARG;
+    if (d->out2.hi && (!d->out.hi || (d->out2.lo != nullptr) != (d->out.lo != nullptr))) return ESR_E_ARG;
     if (d->act_slope <= 0.f || d->act_slope > 1.f) return ESR_E_ARG;
 
     ConvArgs a{};
@@ -824,6 +869,18 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     int wpl = d->weight_planes;
     if (wpl == 0) wpl = f16 ? 1 : npl;
     if (wpl < 1 || wpl > npl || (!f16 && wpl != npl)) return ESR_E_ARG;
+    // which leading chunks of the concatenated input carry a lo plane
+    a.lo_chunks = a.ncp;
+    bool partlo = false;
+    if (split && d->in1_lo_groups > 0 && d->in1_lo_groups < d->in1.ncg) {
+        a.lo_chunks = (a.in0.ncg + d->in1_lo_groups + 1) / 2;
+        partlo = true;
+    }
+    if (split && d->out.hi && !d->out.lo) partlo = true;
+    if (partlo && !f16) return ESR_E_UNSUPPORTED;                   // single-plane intermediates exist for the fp16 formats only
+    if (partlo && (epi & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && !d->out.lo && d->out.hi && (epi & EPI_MASK)) return ESR_E_UNSUPPORTED;
+    if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
+    if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
     if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);
     if (f16 && split) return mt == 1 ? launch_epi<2, 1, 1, 1>(a, epi, s) : launch_epi<2, 2, 1, 1>(a, epi, s);
     if (f16) return mt == 1 ? launch_epi<1, 1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1, 1>(a, epi, s);

@@ -24,7 +24,7 @@ class Conv3x3Desc(C.Structure):
                 ('res1', ActView), ('beta1', C.c_float), ('res2', ActView), ('beta2', C.c_float),
                 ('out', ActView), ('out2', ActView), ('out_nchw', C.c_void_p),
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
-                ('reverse_order', C.c_int32), ('weight_planes', C.c_int32)]
+                ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32)]
 
 
 class WgradDesc(C.Structure):

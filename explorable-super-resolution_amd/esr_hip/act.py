@@ -50,11 +50,12 @@ class ActBuf:
         self.cg_stride = (H + 2) * (W + 2)
         self.batch_stride = ncg * self.cg_stride
 
-    def view(self, cg0=0, ncg=None):
+    def view(self, cg0=0, ncg=None, with_lo=True):
+        """esr_act_view of groups [cg0, cg0+ncg).  with_lo=False: a producer shall write (a consumer shall see) the hi plane only."""
         ncg = self.ncg - cg0 if ncg is None else ncg
         assert 0 <= cg0 and cg0 + ncg <= self.ncg
         off = cg0 * self.cg_stride * 16
-        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if self.nplanes == 2 else None, ncg, self.H, self.W,
+        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if (self.nplanes == 2 and with_lo) else None, ncg, self.H, self.W,
                        self.batch_stride, self.cg_stride, self.fmt)
 
     def nbytes(self):
@@ -275,7 +276,7 @@ ALTERNATE_ORDER = os.environ.get('ESR_ALTERNATE_ORDER', '1') != '0'
 
 
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
-            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None):
+            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0):
     d = _lib.Conv3x3Desc()
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
@@ -302,6 +303,7 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
         _launch_parity += 1
     d.reverse_order = 1 if reverse else 0
     d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
+    d.in1_lo_groups = in1_lo_groups
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
 
 

@@ -99,6 +99,10 @@ typedef struct {
      * f16 hi+lo activations with 2 weight planes is the 3-MFMA fp16 form (2^-22 operands) used for the few layers whose weight
      * rounding dominates the output error; with 1 plane it is the 2-MFMA form. */
     int32_t weight_planes;
+    /* fp16 formats only: number of LEADING channel groups of in1 whose lo plane carries data (0 = all of them).  The groups behind
+     * them are single-plane intermediates (a dense block's conv outputs, consumed only inside the block, where 11 bits suffice): their
+     * lo plane is neither read nor multiplied.  Likewise `out.lo == NULL` with hi+lo inputs stores the result as one fp16 plane. */
+    int32_t in1_lo_groups;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
