@@ -14,6 +14,7 @@ Inference rotates three RDB buffers; a forward that must be differentiated keeps
 activations) and the backward re-uses the same conv kernel with transposed/flipped weight packs (data gradient), a
 pixel-contraction MFMA kernel (weight gradient) and the gradient buffers laid out exactly like the activations.
 """
+import os
 import weakref
 
 import torch
@@ -30,6 +31,8 @@ class RRDBEngine:
     def __init__(self, net):
         self.net = net
         self.split = True
+        if os.environ.get('ESR_DEFAULT_PRECISION'):        # experiments / whole-suite checks of a non-default mode
+            self.split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[os.environ['ESR_DEFAULT_PRECISION']]
         self._packed = None
         self._packed_t = None
         self._packed_rdb_t = None
