@@ -159,8 +159,9 @@ def main():
         # FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/
         import glob
         traffic = None
-        pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-        if pmc and BATCH == 32:
+        pmc = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))
+                     if ('mixed' in os.path.basename(f)) == (args.precision == 'mixed'))        # the PMC passes of THIS precision mode
+        if pmc and BATCH == 32 and args.precision in ('split', 'mixed'):
             traffic = json.load(open(pmc[-1]))['hbm_bytes_per_launch']
         conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
         t_launch = conv_ms * 1e-3 / N_CONV_LAUNCHES
