@@ -137,12 +137,16 @@ def _f4_input(nb, sf, lat):
     return x
 
 
+@pytest.mark.parametrize('precision', ['split', 'mixed'])
 @pytest.mark.parametrize('name,nb,sf,lat', F4_CASES, ids=[c[0] for c in F4_CASES])
-def test_rrdb_forward_matches_reference_golden(name, nb, sf, lat):
+def test_rrdb_forward_matches_reference_golden(name, nb, sf, lat, precision):
+    """Forward of 7 generator variants against outputs of the reference itself, in the fp32 path ('split') and in the 'mixed' fp16
+    inference mode — the same 1e-4 assertion for both (bar: 1e-3)."""
     g = load('rrdb_fwd_bwd.npz')
     net = _rrdb(nb, sf, lat)
     assert sum(p.numel() for p in net.parameters()) == int(g[name + '/nparams'][1])
     net = net.to(DEV)
+    net.set_precision(precision)
     x = _f4_input(nb, sf, lat)
     with torch.no_grad():
         y = net(x.to(DEV)).cpu().numpy()
