@@ -800,8 +800,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     const bool f16 = d->in1.fmt == ESR_FMT_F16;
     // one element format per launch
     if ((d->in0.hi && d->in0.fmt != d->in1.fmt) || (d->out.hi && d->out.fmt != d->in1.fmt) || (d->out2.hi && d->out2.fmt != d->in1.fmt) ||
-        (d->res1.hi && d->res1.fmt != d->in1.fmt) || (d->res2.hi && d->res2.fmt != d->in1.fmt) || (d->mask_src.hi && d->mask_src.fmt != d->in1.fmt))
-        return ESR_E_ARG;
+        (d->res1.hi && d->res1.fmt != d->in1.fmt) || (d->res2.hi && d->res2.fmt != d->in1.fmt))
+        return ESR_E_ARG;      // (mask_src may be in either format: only its sign and zero-ness are read, and those bits coincide)
     if (d->in0.hi && ((d->in0.lo != nullptr) != split)) return ESR_E_ARG;
     const int mt = (d->cout + 31) / 32;
     if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches

@@ -80,6 +80,12 @@ class RRDBEngine:
         if any(p.stale() for p in packs):
             self._pack_batch.run(packs)
 
+    @property
+    def _bwd_split(self):
+        """Operand format of the backward pass: gradients need bf16's exponent range, so 'mixed' back-propagates in the fp32-class
+        bf16 hi+lo format (data gradient only: the saved fp16 activations then serve as LeakyReLU' masks, nothing else)."""
+        return True if self.split == 'mixed' else self.split
+
     def _wfmt(self, name):
         """Weight format of one layer's forward pack."""
         if self.split != 'mixed':
@@ -102,9 +108,9 @@ class RRDBEngine:
                     continue                  # dense blocks: packed_rdb_t()
                 main = c.weight.shape[1] - lat
                 for j in range((main + 63) // 64):
-                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
+                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self._bwd_split, transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
                 if lat:
-                    d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self.split, transposed=True, m_slice='latent')
+                    d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_split, transposed=True, m_slice='latent')
             self._packed_t = d
         self._refresh_packs()
         return self._packed_t
@@ -127,10 +133,10 @@ class RRDBEngine:
                     pieces = [(ws[4], s4), (ws[3], 1.0), (ws[2], 1.0), (ws[1], 1.0), (ws[0], 1.0)]
                     for c in (3, 2, 1, 0):
                         rows = list(range(lat + 64 + 32 * c, lat + 96 + 32 * c))
-                        d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self.split)
-                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self.split)
+                        d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self._bwd_split)
+                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self._bwd_split)
                     if lat:
-                        d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self.split)
+                        d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_split)
             self._packed_rdb_t = d
         self._refresh_packs()
         return self._packed_rdb_t
@@ -282,10 +288,13 @@ class RRDBEngine:
     # ------------------------------------------------------------------ backward
     def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
-        if self.split in ('f16', 'f16x2', 'mixed'):
+        if self.split == 'mixed' and need_dw:
+            raise NotImplementedError("precision 'mixed' back-propagates to the INPUT only (Z optimisation): its saved activations are fp16, the "
+                                      "weight-gradient kernel wants them in the gradients' bf16 hi+lo format; train in 'split' or 'bf16'")
+        if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
-        net, sp = self.net, self.split
+        net, sp = self.net, self._bwd_split
         sf = net.upscale
         has_lat = net.latent_input is not None and net.num_latent_channels > 0
         lat1 = net.num_latent_channels if has_lat else 0

@@ -170,3 +170,33 @@ def test_z_optimizer_training_mode_leaves_a_differentiable_forward():
     assert all(p.requires_grad for n, p in m.netG.named_parameters() if 'Filter_OP' not in n)
     m.fake_H.mean().backward()
     assert m.netG.generated_image_model.model[0].weight.grad is not None
+
+
+def test_z_search_in_mixed_precision_follows_the_fp32_path():
+    """'mixed' (fp16 forward) supports the Z search: the data gradient runs in the bf16 hi+lo format with the saved fp16 activations as
+    LeakyReLU' masks.  The search must track the fp32-path search (same losses to 1e-3, same Z to Adam-step accuracy); weight gradients
+    are refused loudly."""
+    from Z_optimization import Z_optimizer
+    nb, lat, B, iters = 2, 3, 2, 4
+    res = []
+    for prec in ('split', 'mixed'):
+        m = _model(nb, lat, is_train=False)
+        m.netG.generated_image_model.set_precision(prec)
+        lr = seeded_uniform((1, 3, 10, 12), 241)
+        z0 = seeded_uniform((B, lat, 40, 48), 242, -0.5, 0.5)
+        dev = m.device
+        m.feed_data({'LR': lr.expand(B, -1, -1, -1).to(dev), 'Z': z0.to(dev)}, need_GT=False)
+        m.test()
+        zo = Z_optimizer(objective='max_STD', Z_size=[40, 48], model=m, Z_range=1, max_iters=iters, data={'LR': lr.to(dev)}, initial_LR=0.02,
+                         batch_size=B, initial_Z=z0.to(dev))
+        Z = zo.optimize()
+        res.append((Z.cpu().numpy(), np.array(zo.loss_values)))
+    (Zs, Ls), (Zm, Lm) = res
+    np.testing.assert_allclose(Lm, Ls, rtol=2e-3, atol=1e-6)
+    # Adam normalises every component's step to ~lr whatever the gradient's size, so 1e-4-level gradient differences (these are the
+    # high-gain formula weights, mixed's worst case) move individual Z entries by a fraction of a step: 4 steps of 0.02 -> median 5e-4
+    assert np.median(np.abs(Zm - Zs)) < 2e-3 and rel_l2(Zm, Zs) < 5e-2
+    net = m.netG.generated_image_model
+    x = torch.rand(1, 3 + lat * 16, 10, 12, device=m.device)
+    with pytest.raises(NotImplementedError):
+        net(x).sum().backward()                     # parameters require grad here -> weight gradients -> refused in 'mixed'
