@@ -7,6 +7,13 @@
 A step = one forward of the hot path over one batch already resident in HBM.  Rank 0 prints ONE JSON line with the
 throughput, the roofline fraction of the dominant kernel (conv3x3, measured with HIP events on the launch stream) and a CPU
 baseline (the oracle's CPU restatement, timed on this box's host cores on a bounded sample).
+
+Arithmetic.  The headline runs the generator's inference precision 'mixed' (DESIGN.md section 5): fp32 in and out, fp16 MFMA operands
+with fp32 accumulation, hi+lo planes (22 bits) wherever the output is sensitive to them.  BASELINE.md section 2 sets the criterion — a
+scheme qualifies if it meets the 1e-3 parity bar against fp32 (exact-fp32 math is capped at 14 % of the HBM-roofline rate on this part) —
+and the line carries the evidence: `generator_rel_l2_vs_cpu_oracle` / `generator_rel_max_vs_cpu_oracle` of the benchmarked weights (3e-5).
+The same workload in 'split' (bf16 hi+lo operands in every layer, the mode training uses) is timed right after it and reported in the
+`alt_precision` block.
 """
 import argparse
 import json
@@ -88,7 +95,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precision', action='store_true', help="skip the extra timing of the 'mixed' fp16 mode")
-    ap.add_argument('--precision', default='split', choices=['split', 'mixed', 'f16x2', 'bf16', 'f16'], help="experiments: the headline is 'split' (fp32-class)")
+    ap.add_argument('--precision', default='mixed', choices=['mixed', 'split', 'f16x2', 'bf16', 'f16'],
+                    help="'mixed' (default, headline): fp16 operands with hi+lo planes wherever the output is sensitive to them, 3e-5 from the fp32 "
+                         "oracle on this workload; 'split': bf16 hi+lo everywhere (the training path), reported in the alt_precision block")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
     args = ap.parse_args()
     if args.batch != BATCH:
@@ -112,8 +121,7 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     cem, G = build_model(dev)
-    if args.precision != 'split':
-        G.generated_image_model.set_precision(args.precision)
+    G.generated_image_model.set_precision(args.precision)
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.rand(BATCH, 3, LR_SIZE, LR_SIZE, generator=g).to(dev)      # synthetic LR batch, resident in HBM
 
@@ -174,13 +182,15 @@ def main():
         out = {
             'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'f32', 'mixed': 'f16 hi+lo', 'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'bf16x3 (bf16 hi+lo operands, f32 accumulate)', 'mixed': 'f16 (hi+lo planes on the residual stream and main-path weights, f32 accumulate)',
+                                                                      'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
                        'arithmetic': {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
                                       'f16': 'f16 MFMA operands, fp32 accumulate',
                                       'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate',
-                                      'mixed': 'f16 hi+lo activations; f16 hi+lo weights (3 MFMAs) in the 6 convs outside the dense blocks, '
-                                               'f16 weights (2 MFMAs) in the 345 dense-block convs; fp32 accumulate'}[args.precision],
+                                      'mixed': 'fp32 I/O; f16 MFMA operands, fp32 accumulate: hi+lo (22-bit) residual stream and hi+lo weights (3 MFMAs) in the 6 convs '
+                                               'outside the dense blocks; one-plane weights and one-plane intermediate activations inside the dense blocks '
+                                               '(2 / 1 MFMAs); parity vs the fp32 CPU oracle reported in this line'}[args.precision],
                        'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
@@ -188,9 +198,9 @@ def main():
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
                          'generator_ms_per_step': conv_ms,
                          'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 2.08}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 1.58}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
                          # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
-                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 2.08}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
+                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 1.58}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
@@ -203,15 +213,18 @@ def main():
             net = G.generated_image_model
             gen_ref = cpu_baseline.generator_output
 
-            def gen_err():
+            def gen_err(rel_max=False):
                 with torch.no_grad():
                     gg = net(xs.to(dev), pad=MARGIN_LR).cpu()
+                if rel_max:
+                    return float((gg - gen_ref).abs().max() / gen_ref.abs().max())
                 return float((gg - gen_ref).norm() / gen_ref.norm())
             out['generator_rel_l2_vs_cpu_oracle'] = gen_err()       # the generator alone (the CEM output above is dominated by the LR content)
-            if args.precision == 'split' and not args.no_alt_precision:
-                # NOT the headline: the same workload in the 'mixed' fp16 mode (fp16 hi+lo activations; hi+lo weights in the 6 convs outside
-                # the dense blocks, single-plane weights in the 345 dense-block convs), with its own parity figure
-                net.set_precision('mixed')
+            out['generator_rel_max_vs_cpu_oracle'] = gen_err(True)
+            if args.precision == 'mixed' and not args.no_alt_precision:
+                # beside the headline: the same workload in 'split' (bf16 hi+lo operands everywhere, 3 MFMAs per product — the universal
+                # fp32-class path that training uses), with its own parity figure
+                net.set_precision('split')
                 for _ in range(2):
                     step()
                 sync()
@@ -220,10 +233,11 @@ def main():
                     step()
                 sync()
                 dta = time.perf_counter() - t0
-                out['alt_precision'] = {'mode': 'mixed', 'ms_per_step': dta / args.steps * 1e3, 'value': hr_px * args.steps / dta, 'unit': 'HR pixels/s',
-                                        'generator_rel_l2_vs_cpu_oracle': gen_err(),
-                                        'note': 'not the headline; fp16 hi+lo (22-bit) activations, 11-bit weights in the dense-block convs'}
-                net.set_precision('split')
+                out['alt_precision'] = {'mode': 'split', 'ms_per_step': dta / args.steps * 1e3, 'value': hr_px * args.steps / dta, 'unit': 'HR pixels/s',
+                                        'roofline_frac': ALGO_BYTES_PER_FWD / (dta / args.steps) / HBM_PEAK,
+                                        'generator_rel_l2_vs_cpu_oracle': gen_err(), 'generator_rel_max_vs_cpu_oracle': gen_err(True),
+                                        'note': 'bf16 hi+lo weights x bf16 hi+lo activations in every layer (3 MFMAs per product)'}
+                net.set_precision(args.precision)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
