@@ -1,5 +1,5 @@
 import os, sys
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, os.path.join(ROOT,'explorable-super-resolution_amd')); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
 import torch, numpy as np
 from oracle.check_golden import load, rel_l2
