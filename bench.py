@@ -166,8 +166,10 @@ def main():
         # FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/
         import glob
         traffic = None
-        pmc = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))
-                     if ('mixed' in os.path.basename(f)) == (args.precision == 'mixed'))        # the PMC passes of THIS precision mode
+        import re
+        pmc = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))
+                      if ('mixed' in os.path.basename(f)) == (args.precision == 'mixed')),      # the PMC passes of THIS precision mode
+                     key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])    # r01_v9 < r01_v11
         if pmc and BATCH == 32 and args.precision in ('split', 'mixed'):
             traffic = json.load(open(pmc[-1]))['hbm_bytes_per_launch']
         conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
@@ -181,15 +183,15 @@ def main():
         out = {
             'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'bf16x3 (bf16 hi+lo operands, f32 accumulate)', 'mixed': 'f16 (hi+lo planes on the residual stream and main-path weights, f32 accumulate)',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'bf16x3 (bf16 hi+lo operands, f32 accumulate)', 'mixed': 'f16 (residual stream stored as hi+lo planes, hi+lo main-path weights, f32 accumulate)',
                                                                       'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
                        'arithmetic': {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
                                       'f16': 'f16 MFMA operands, fp32 accumulate',
                                       'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate',
-                                      'mixed': 'fp32 I/O; f16 MFMA operands, fp32 accumulate: hi+lo (22-bit) residual stream and hi+lo weights (3 MFMAs) in the 6 convs '
-                                               'outside the dense blocks; one-plane weights and one-plane intermediate activations inside the dense blocks '
-                                               '(2 / 1 MFMAs); parity vs the fp32 CPU oracle reported in this line'}[args.precision],
+                                      'mixed': 'fp32 I/O; f16 MFMA operands, fp32 accumulate: residual stream stored as hi+lo (22-bit) planes; hi+lo weights x hi+lo '
+                                               'activations (3 MFMAs) in the 6 convs outside the dense blocks; one-plane weights x hi planes (1 MFMA) and '
+                                               'one-plane intermediates inside the dense blocks; parity vs the fp32 CPU oracle reported in this line'}[args.precision],
                        'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
@@ -197,9 +199,9 @@ def main():
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
                          'generator_ms_per_step': conv_ms,
                          'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 1.58}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 1.16}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
                          # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
-                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 1.58}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
+                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 1.16}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
             'cem_consistency_rmse_interior': cons,
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only

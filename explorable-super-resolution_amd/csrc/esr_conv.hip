@@ -41,6 +41,9 @@ constexpr int NTHREADS = 64 * NW;
 constexpr int MAXS_BASE = ESR_MAXS;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
 // Measured on MI355X (RRDB-23 forward, ms): MT1/MT2 resident workgroups 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is
 // power-limited under this kernel: beyond the overlap that reaches the power cap, more resident waves cost clock.
+#ifndef ESR_EPI_AHEAD
+#define ESR_EPI_AHEAD 0
+#endif
 #ifndef ESR_WGS_MT1
 #define ESR_WGS_MT1 2
 #endif
@@ -281,6 +284,9 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
             const int pl = NPW == 2 ? 1 : 0;
             fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
         } else if (k < MT + R) {
+#ifdef ESR_ABL_BREUSE                      // ablation (timing only): one activation read per tap ROW, the other two taps copy registers
+            if (t % 3 != 0) { fb[buf][k - MT][0] = fb[buf ^ 1][k - MT][0]; return; }
+#endif
             fb[buf][k - MT][0] = *(const uint4*)(sb + (k - MT) * NW * 512 + tapoff);
         } else if (NPW == 2 && k < 2 * MT + R) {
             const int idx = k - MT - R;
@@ -440,25 +446,39 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         const int half = lane >> 5;
         const int Wp = a.W + 2;
         const int ncg_out = (a.cout + 7) >> 3;
+        // Residual / mask operands are 16-byte loads straight from global memory, issued ESR_EPI_AHEAD column tiles ahead of the math that
+        // uses them.  Measured: 0 (load, use, next tile) and R-1 (all loads first) run the C2 forward in the same time — the co-resident
+        // workgroup already covers the latency — and 0 keeps every instantiation free of register spills, so 0 it is.
+        constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
+        constexpr int AHEAD = ESR_EPI_AHEAD < R ? ESR_EPI_AHEAD : R - 1;
+        ResRaw q1[HAS_R1 ? R : 1][MT * 2], q2[HAS_R2 ? R : 1][MT * 2], qm[HAS_MK ? R : 1][MT * 2];
+        int Ys[R], Xs[R], pixs[R];
+        bool valids[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int q = (wave + r * NW) * 32 + (lane & 31);
             const int rr = q / P, cc = q - rr * P;
-            const int Y = y0 + rr, X = x0 + cc;
-            const bool valid = (rr < a.TH) && (cc < a.TW) && (Y < a.H) && (X < a.W);
-            const int pix = (Y + 1) * Wp + (X + 1);
-            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
-            if (any_valid && valid) {
-                // all residual / mask loads of this column tile first (independent 16-byte loads in flight together), then the math
-                constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
-                ResRaw q1[HAS_R1 ? MT * 2 : 1], q2[HAS_R2 ? MT * 2 : 1], qm[HAS_MK ? MT * 2 : 1];
+            Ys[r] = y0 + rr; Xs[r] = x0 + cc;
+            valids[r] = (rr < a.TH) && (cc < a.TW) && (Ys[r] < a.H) && (Xs[r] < a.W);
+            pixs[r] = (Ys[r] + 1) * Wp + (Xs[r] + 1);
+        }
+#pragma unroll
+        for (int st = 0; st < R + AHEAD; ++st) {                     // software pipeline: loads of column tile st, math of tile st - AHEAD
+            if (st < R && (HAS_R1 || HAS_R2 || HAS_MK)) {
 #pragma unroll
                 for (int mp = 0; mp < MT * 2; ++mp) {
-                    const int cgs = (mp * 2 + half) < ncg_out ? mp * 2 + half : -1;      // -1: no such output group, operand = 0
-                    if constexpr (HAS_R1) q1[mp] = res_issue(a.res1, b, cgs, pix, NPL == 2);
-                    if constexpr (HAS_R2) q2[mp] = res_issue(a.res2, b, cgs, pix, NPL == 2);
-                    if constexpr (HAS_MK) qm[mp] = res_issue(a.mask, b, (cgs >= a.mask_cg0 && cgs < a.mask_cg1) ? cgs - a.mask_cg0 : -1, pix, false);
+                    const int cgs = (valids[st] && (mp * 2 + half) < ncg_out) ? mp * 2 + half : -1;     // -1: no such output, operand = 0
+                    if constexpr (HAS_R1) q1[st][mp] = res_issue(a.res1, b, cgs, pixs[st], NPL == 2);
+                    if constexpr (HAS_R2) q2[st][mp] = res_issue(a.res2, b, cgs, pixs[st], NPL == 2);
+                    if constexpr (HAS_MK) qm[st][mp] = res_issue(a.mask, b, (cgs >= a.mask_cg0 && cgs < a.mask_cg1) ? cgs - a.mask_cg0 : -1, pixs[st], false);
                 }
+            }
+            if (st < AHEAD) continue;
+            const int r = st - AHEAD;
+            const bool valid = valids[r];
+            const int Y = Ys[r], X = Xs[r], pix = pixs[r];
+            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
+            if (any_valid && valid) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -477,7 +497,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                         }
                         if constexpr (HAS_R1) {
                             float rv[2][4];
-                            res_unpack<FMT>(q1[m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
+                            res_unpack<FMT>(q1[r][m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                         }
                         if constexpr (HAS_R2) {
                             float rv[2][4];
-                            res_unpack<FMT>(q2[m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
+                            res_unpack<FMT>(q2[r][m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                             // LeakyReLU' from the stored post-activation value: its sign is the pre-activation's (slope > 0);
                             // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
                             uint32_t d[2][2];
-                            swap_halves(qm[m * 2 + gp].h, d);
+                            swap_halves(qm[r][m * 2 + gp].h, d);
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 const int cg = cg0 + k;
@@ -850,7 +870,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->res1.hi) epi |= EPI_RES1;
     // residual 1 == a channel-group slice of this conv's own main input, linear epilogue: take it from the staged LDS tile
     if (d->res1.hi && d->act_slope == 1.f && d->alpha != 0.f && ups == 1 && !d->mask_src.hi && !d->out_nchw &&
-        d->res1.batch_stride == d->in1.batch_stride && d->res1.cg_stride == d->in1.cg_stride && ((d->res1.lo != nullptr) == split)) {
+        d->res1.batch_stride == d->in1.batch_stride && d->res1.cg_stride == d->in1.cg_stride && ((d->res1.lo != nullptr) == split) &&
+        d->in1_lo_groups >= 0) {
         const long long unit = (long long)d->in1.cg_stride * 16;
         const long long off = (const char*)d->res1.hi - (const char*)d->in1.hi;
         const bool lo_ok = !split || ((const char*)d->res1.lo - (const char*)d->in1.lo) == off;
@@ -874,6 +895,10 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     bool partlo = false;
     if (split && d->in1_lo_groups > 0 && d->in1_lo_groups < d->in1.ncg) {
         a.lo_chunks = (a.in0.ncg + d->in1_lo_groups + 1) / 2;
+        partlo = true;
+    }
+    if (split && d->in1_lo_groups < 0) {                             // the conv reads hi planes only (lo planes exist but are not operands)
+        a.lo_chunks = 0;
         partlo = true;
     }
     if (split && d->out.hi && !d->out.lo) partlo = true;

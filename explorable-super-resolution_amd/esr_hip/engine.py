@@ -254,20 +254,25 @@ class RRDBEngine:
         # the RDB input (groups 0:8, the residual stream) keeps hi+lo.  Their lo planes are never written (they stay zero).
         mixed = self.split == 'mixed'
         lo8 = dict(in1_lo_groups=8) if mixed else {}
+        xlo_mode = os.environ.get('ESR_MIXED_XLO', 'none')
+        lo_in = lo8 if xlo_mode == 'all' else dict(in1_lo_groups=-1)
+        lo_c4 = lo8 if xlo_mode in ('all', 'conv4') else dict(in1_lo_groups=-1)
+        if not mixed:
+            lo_in = lo_c4 = {}
         for r in range(net.nb):
             rrdb_in = buf_of(3 * r)
             for k in range(3):
                 buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
                 for i in range(4):
                     conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), **(lo8 if i > 0 else {}))
+                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), **(lo_in if (i > 0 or xlo_mode != 'all') else {}))
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
-                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), **lo8)
+                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), **lo_c4)
                 else:         # RRDB output: 0.2*(0.2*conv5 + x) + x_rrdb   (block.py:270); lands in the next RRDB's first buffer
                     # (inference: that is rrdb_in's own buffer when the three buffers rotate; the kernel's in-place residual is safe)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.04, res1=buf.view(0, 8), beta1=0.2,
-                         res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8), **lo8)
+                         res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8), **lo_c4)
         last = buf_of(nrdb).view(0, 8) if net.nb else bufs['fea'].view()
         # LR_conv + trunk shortcut (block.py:96)
         conv(pk['lr_conv'], last, B, h, w, 64, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view())

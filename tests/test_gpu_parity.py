@@ -309,7 +309,7 @@ def test_rrdb_first_layer_latent_matches_reference_golden(name, nb, sf, lat):
 def test_c2_rrdb23_probe_matches_reference_golden(precision, tol):
     """The full-depth generator of BASELINE configs[1] (RRDB-23 x4 + CEM, eval, one 128x128 image) against outputs of the REFERENCE itself
     (fixture F6: a 64x64 crop and a stride-8 sampling of the 512x512 result).  Bar: 1e-3.  Measured: split 3.9e-5 (asserted at 1e-4),
-    mixed 7.2e-5 (asserted at 3e-4), f16x2 7.5e-4 (asserted at the bar)."""
+    mixed 1.25e-4 (asserted at 3e-4), f16x2 7.5e-4 (asserted at the bar)."""
     g = load('c2_rrdb23_probe.npz')
     cem = _cem(4, None, None)
     G = cem.WrapArchitecture_PyTorch(_rrdb(23, 4, 0))
@@ -322,4 +322,5 @@ def test_c2_rrdb23_probe_matches_reference_golden(precision, tol):
         y = G(x).cpu().numpy()
     assert y.shape == (1, 3, 512, 512)
     e1, e2 = rel_l2(y[:, :, 200:264, 300:364], g['crop64']), rel_l2(y[:, :, 3::8, 5::8], g['stride8'])
+    print("F6 %s: crop %.2e stride8 %.2e" % (precision, e1, e2))
     assert e1 < tol and e2 < tol, (precision, e1, e2)

@@ -1,6 +1,8 @@
 import numpy as np, sys
 from collections import defaultdict
-for name,ncp in [('128_32',8),('192_64',12)]:
+cases = [a.split(':') for a in sys.argv[1:]] or [('128_32', 8), ('192_64', 12)]      # name:chunks
+for name,ncp in cases:
+    ncp = int(ncp)
     t=np.load('gpurun_out/trace_%s.npy'%name).astype(np.int64)
     t=t[t[:,2]!=0]; n=len(t)
     hw=t[:,0]; xcc=t[:,1]&0xf
