@@ -709,8 +709,9 @@ int launch(const ConvArgs& a, hipStream_t s) {
 // the epilogue combinations the RRDB forward / backward plans use
 template <int NPL, int MT, int FMT, int NPW, bool PARTLO = false>
 int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
-    if (FMT == 1) {              // f16: the inference forward only (no data-gradient epilogues)
+    if (FMT == 1) {              // f16: the inference forward and the data gradient of 'mixed' (EPI_MASK)
         switch (epi) {
+            case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW, PARTLO>(a, s);
             case 0: return launch<NPL, MT, 0, FMT, NPW, PARTLO>(a, s);
             case EPI_RES1: return launch<NPL, MT, EPI_RES1, FMT, NPW, PARTLO>(a, s);
             case EPI_RES1 | EPI_RES2: return launch<NPL, MT, EPI_RES1 | EPI_RES2, FMT, NPW, PARTLO>(a, s);
@@ -903,7 +904,6 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     }
     if (split && d->out.hi && !d->out.lo) partlo = true;
     if (partlo && !f16) return ESR_E_UNSUPPORTED;                   // single-plane intermediates exist for the fp16 formats only
-    if (partlo && (epi & (EPI_RES1 | EPI_RES2 | EPI_MASK | EPI_NCHW)) && !d->out.lo && d->out.hi && (epi & EPI_MASK)) return ESR_E_UNSUPPORTED;
     if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
     if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
     if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);

@@ -82,9 +82,19 @@ class RRDBEngine:
 
     @property
     def _bwd_split(self):
-        """Operand format of the backward pass: gradients need bf16's exponent range, so 'mixed' back-propagates in the fp32-class
-        bf16 hi+lo format (data gradient only: the saved fp16 activations then serve as LeakyReLU' masks, nothing else)."""
-        return True if self.split == 'mixed' else self.split
+        """Buffer format of the backward pass.  'mixed' back-propagates (to the input only) the way it runs forward: fp16 planes, the
+        gradient of the residual stream stored hi+lo, one-plane operands inside the dense blocks, with the incoming gradient scaled by a
+        power of two into fp16's range (run_backward).  ESR_MIXED_BWD=bf16 selects the earlier variant: bf16 hi+lo gradients (3 MFMAs
+        per product), the saved fp16 activations serving as LeakyReLU' masks only."""
+        if self.split == 'mixed':
+            return True if os.environ.get('ESR_MIXED_BWD', 'f16') == 'bf16' else 'mixed'
+        return self.split
+
+    def _bwd_wfmt(self, rdb):
+        """Weight format of a data-gradient pack (rdb: a dense-block pack)."""
+        if self._bwd_split != 'mixed':
+            return self._bwd_split
+        return 'f16x2' if rdb else 'f16x3'
 
     def _wfmt(self, name):
         """Weight format of one layer's forward pack."""
@@ -108,9 +118,9 @@ class RRDBEngine:
                     continue                  # dense blocks: packed_rdb_t()
                 main = c.weight.shape[1] - lat
                 for j in range((main + 63) // 64):
-                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self._bwd_split, transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
+                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
                 if lat:
-                    d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_split, transposed=True, m_slice='latent')
+                    d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice='latent')
             self._packed_t = d
         self._refresh_packs()
         return self._packed_t
@@ -133,10 +143,10 @@ class RRDBEngine:
                     pieces = [(ws[4], s4), (ws[3], 1.0), (ws[2], 1.0), (ws[1], 1.0), (ws[0], 1.0)]
                     for c in (3, 2, 1, 0):
                         rows = list(range(lat + 64 + 32 * c, lat + 96 + 32 * c))
-                        d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self._bwd_split)
-                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self._bwd_split)
+                        d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self._bwd_wfmt(True))
+                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self._bwd_wfmt(True))
                     if lat:
-                        d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_split)
+                        d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_wfmt(True))
             self._packed_rdb_t = d
         self._refresh_packs()
         return self._packed_rdb_t
@@ -312,6 +322,17 @@ class RRDBEngine:
         conv = A.conv3x3
         dg = dg.detach()
         dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
+        f16_bwd = sp == 'mixed'
+        unscale = None
+        if f16_bwd:
+            # fp16 gradients: scale the incoming gradient by a power of two so that its largest element is in [8, 16) — 12 binades of head
+            # room before fp16 overflows, 18 before the hi plane goes subnormal — and scale dx back at the end.  Computed on the device
+            # (no host synchronisation); an all-zero gradient keeps scale 1.
+            amax = dg.abs().amax()
+            scale = torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(16.0 / amax.clamp_min(1e-37)))), torch.ones_like(amax))
+            dg = dg * scale
+            unscale = 1.0 / scale
+        hi_only = dict(in1_lo_groups=-1) if f16_bwd else {}       # dense-block convs multiply hi planes only (see run_forward)
         wg = WGrad(self, need_dw, B)
         # gradient buffers come from a per-engine pool and go back to it when this pass is over: their zero borders (which the conv
         # kernels rely on and no producer ever writes) survive, so a steady-state step does no buffer memsets at all.  Everything
@@ -419,19 +440,19 @@ class RRDBEngine:
                 wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
                 for c in (3, 2, 1, 0):
                     g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
-                    conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4), use_bias=False,
-                         mask_src=X.view(8 + 4 * c, 4), mask_cg=(0, 4), mask_slope=0.2)
+                    conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
+                         mask_src=X.view(8 + 4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
                     wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if lat:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
-                    conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz)
+                    conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
                     zfirst = False
                 # d(RDB input) = s_out*dy_out + sum_i W_i^T dy_i  (+ d(out of the RRDB) for its first RDB: the RRDB skip connection),
                 # written where the next RDB in backward order expects its dy_out
                 n += 1
                 G_next = gbuf(n) if n < nseq else galloc(B, 8, h, w)
                 kw = dict(res2=G_rrdb.view(0, 8), beta2=1.0) if k == 0 else {}
-                conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw)
+                conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw, **hi_only)
                 G_cur = G_next
             dout = G_cur
         # d fea = d trunk (shortcut) + d(first RRDB input)
@@ -451,6 +472,8 @@ class RRDBEngine:
                 A.unpack_grad_nchw(GZ_lr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, down=sf, **kw)
                 if GZ_hr is not None:
                     A.unpack_grad_nchw(GZ_hr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, accumulate=True, **kw)
+        if dx is not None and unscale is not None:
+            dx.mul_(unscale)
         grads = wg.result()                   # the batched weight-gradient launch is enqueued here, before the buffers are recycled
         for buf in taken:
             self._gpool[buf.ncg, buf.H, buf.W].append(buf)

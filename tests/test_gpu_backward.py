@@ -115,6 +115,39 @@ def test_rrdb_input_gradient_matches_reference_golden(name, nb, sf, lat):
     assert_grad_close(dx, g[name + '/dx'], name)
 
 
+@pytest.mark.parametrize('bwd_fmt', ['f16', 'bf16'])
+def test_mixed_precision_input_gradient_against_oracle_autograd(bwd_fmt, monkeypatch):
+    """'mixed' back-propagates to the input (the Z search) in its own fp16 format: gradient of the residual stream stored hi+lo, hi-plane
+    operands inside the dense blocks, the incoming gradient scaled by a power of two into fp16's range.  Checked against autograd through
+    the fp32 CPU oracle at training-scale weights (kaiming x0.1, RRDB-6, latent 3) with a cotangent of size 1e-7 — a mean-reduced loss,
+    far below fp16's smallest subnormal without the scaling.  Measured (RRDB-23): relative L2 8.5e-6 (f16), 9.2e-6 (the bf16 hi+lo variant
+    ESR_MIXED_BWD=bf16), split 9.2e-5."""
+    import models.modules.architecture as arch
+    import models.networks as N
+    from oracle import rrdb_oracle as ro
+    monkeypatch.setenv('ESR_MIXED_BWD', bwd_fmt)
+    nb, lat = 6, 3
+    torch.manual_seed(5)
+    net = arch.RRDBNet(3, 3, 64, nb, gc=32, upscale=4, latent_input='all_layers_HR_downscaled', num_latent_channels=lat)
+    N.init_weights(net, 'kaiming', scale=0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x0 = seeded_uniform((2, 3 + 16 * lat, 14, 18), 301)
+    x0[:, :16 * lat] = x0[:, :16 * lat] * 2 - 1
+    cot = seeded_uniform((2, 3, 56, 72), 302, -1.0, 1.0) * 1e-7
+    xc = x0.clone().requires_grad_(True)
+    (ro.rrdb_forward(sd, xc, nb, 4, lat) * cot).sum().backward()
+    net = net.to(DEV)
+    net.set_precision('mixed')
+    for p in net.parameters():
+        p.requires_grad_(False)
+    xg = x0.clone().to(DEV).requires_grad_(True)
+    (net(xg) * cot.to(DEV)).sum().backward()
+    dx = xg.grad.cpu().numpy()
+    assert np.isfinite(dx).all()
+    assert_grad_close(dx, xc.grad.numpy(), 'mixed/' + bwd_fmt)
+    assert rel_l2(dx, xc.grad.numpy()) < 1e-3
+
+
 def test_cem_wrapped_generator_z_gradient_eval_mode():
     """Gradient w.r.t. Z through CEM (eval: replicate padding folded into the packing) vs autograd through the CPU oracle."""
     import CEM.CEMnet as C

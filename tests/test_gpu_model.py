@@ -173,8 +173,8 @@ def test_z_optimizer_training_mode_leaves_a_differentiable_forward():
 
 
 def test_z_search_in_mixed_precision_follows_the_fp32_path():
-    """'mixed' (fp16 forward) supports the Z search: the data gradient runs in the bf16 hi+lo format with the saved fp16 activations as
-    LeakyReLU' masks.  The search must track the fp32-path search (same losses to 1e-3, same Z to Adam-step accuracy); weight gradients
+    """'mixed' (fp16 forward) supports the Z search: the data gradient runs in the same fp16 format (power-of-two scaled, gradient of the
+    residual stream stored hi+lo), the saved fp16 activations serve as LeakyReLU' masks.  The search must track the fp32-path search (same losses to 1e-3, same Z to Adam-step accuracy); weight gradients
     are refused loudly."""
     from Z_optimization import Z_optimizer
     nb, lat, B, iters = 2, 3, 2, 4
