@@ -240,11 +240,18 @@ __device__ __forceinline__ uint4 frag_tr(const unsigned char* p) {
     return make_uint4(u0.x, u0.y, u1.x, u1.y);
 }
 
-__device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+// FMT: element format of both operands (ESR_FMT_BF16 / ESR_FMT_F16) — only the MFMA instruction and the constant 1.0 differ
+template <int FMT>
+__device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
+    if constexpr (FMT == ESR_FMT_F16) {
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
 }
 
-template <int NPL, int NST>
+template <int NPL, int NST, int FMT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -264,7 +271,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const bool do_bias = (cit == 0) && a.db;                     // uniform: the first input tile's workgroups also reduce dY itself
-    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
+    constexpr uint32_t ONE2 = FMT == ESR_FMT_F16 ? 0x3C003C00u : 0x3F803F80u;
+    const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);   // 1.0 x 8 in the operand format
 
     // this lane's source address inside a fragment's 16-lane group (see frag_tr)
     const int li = lane & 15, grp16 = lane >> 4;
@@ -346,8 +354,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
                 if (do_bias) {                                    // dY x ones: every column of the tile holds sum_k dY[row][k]
-                    accb = mfma_bf16(fa[0], ones, accb);
-                    if (NPL == 2) accb = mfma_bf16(fa[NPL - 1], ones, accb);
+                    accb = mfma_e<FMT>(fa[0], ones, accb);
+                    if (NPL == 2) accb = mfma_e<FMT>(fa[NPL - 1], ones, accb);
                 }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -356,10 +364,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                     for (int pl = 0; pl < NPL; ++pl)
                         fb[pl] = frag_tr(sx + pl * WG_X_BYTES + ((rr + t / 3) * (WG_TW + 2) + ks * 16 + t % 3) * 16);
                     if (NPL == 2) {
-                        acc[t] = mfma_bf16(fa[1], fb[0], acc[t]);
-                        acc[t] = mfma_bf16(fa[0], fb[NPL - 1], acc[t]);
+                        acc[t] = mfma_e<FMT>(fa[1], fb[0], acc[t]);
+                        acc[t] = mfma_e<FMT>(fa[0], fb[NPL - 1], acc[t]);
                     }
-                    acc[t] = mfma_bf16(fa[0], fb[0], acc[t]);
+                    acc[t] = mfma_e<FMT>(fa[0], fb[0], acc[t]);
                 }
             }
         }
@@ -414,22 +422,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 
 #undef ESR_WG_ISSUE
 
-template <int NPL, int NST>
+template <int NPL, int NST, int FMT>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    wgrad_body<NPL, NST>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
+    wgrad_body<NPL, NST, FMT>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
 }
 
 // Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
 // slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
-template <int NPL, int NST>
+template <int NPL, int NST, int FMT>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
-    wgrad_body<NPL, NST>(a, group, slice, smem);
+    wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
 }
 
 // dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
@@ -492,6 +500,8 @@ static int wgrad_validate(const esr_wgrad_desc* d) {
     const bool split = d->dy.lo != nullptr;
     if ((d->x.lo != nullptr) != split) return ESR_E_ARG;
     if (d->xlat.hi && ((d->xlat.lo != nullptr) != split)) return ESR_E_ARG;
+    if (d->x.fmt != d->dy.fmt || (d->xlat.hi && d->xlat.fmt != d->dy.fmt)) return ESR_E_ARG;      // one element format per contraction
+    if (d->dy.fmt == ESR_FMT_F16 && split) return ESR_E_UNSUPPORTED;   // fp16 operands: the hi planes only (one MFMA per product)
     return ESR_OK;
 }
 
@@ -582,8 +592,10 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const WgradArgs a = wgrad_args(d, p, d->workspace);
     const bool split = d->dy.lo != nullptr;
     const int nst = wgrad_stages();
-    void (*k)(const WgradArgs) = split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2> : conv3x3_wgrad_kernel<2, 1>)
-                                       : (nst == 2 ? conv3x3_wgrad_kernel<1, 2> : conv3x3_wgrad_kernel<1, 1>);
+    const bool f16 = d->dy.fmt == ESR_FMT_F16;                    // fp16 operands: single plane only (wgrad_validate)
+    void (*k)(const WgradArgs) = f16 ? (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 1> : conv3x3_wgrad_kernel<1, 1, 1>)
+                               : split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0> : conv3x3_wgrad_kernel<2, 1, 0>)
+                                       : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0> : conv3x3_wgrad_kernel<1, 1, 0>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1, nst), (hipStream_t)stream, a);
@@ -610,7 +622,7 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
     for (int i = 0; i < n; ++i) {
         const int rc = wgrad_validate(&descs[i]);
         if (rc != ESR_OK) return rc;
-        if ((descs[i].dy.lo != nullptr) != split) return ESR_E_ARG;      // one operand format per batch
+        if ((descs[i].dy.lo != nullptr) != split || descs[i].dy.fmt != descs[0].dy.fmt) return ESR_E_ARG;      // one operand format per batch
     }
     if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
     const BatchPlan b = batch_plan(descs, n);
@@ -634,8 +646,10 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
     if (hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), (size_t)b.nwg * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
         return ESR_E_LAUNCH;
     const int nst = wgrad_stages();
-    void (*k)(const WgradArgs*, const int4*) = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2> : conv3x3_wgrad_batch_kernel<2, 1>)
-                                                     : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2> : conv3x3_wgrad_batch_kernel<1, 1>);
+    const bool f16 = descs[0].dy.fmt == ESR_FMT_F16;
+    void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
+                                             : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
+                                                     : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,

@@ -1,7 +1,9 @@
 """Device-side containers used by the launch planner: activation buffers in the kernels' channel-group layout
 and packed conv weights.  PyTorch is only the allocator / stream provider here."""
 import ctypes as C
+import functools
 import os
+import threading
 
 import torch
 
@@ -14,8 +16,29 @@ def require_gpu(t, what='tensor'):
         raise EsrError('%s must live on an AMD GPU: the RRDB/CEM kernels have no CPU fallback' % what)
 
 
+_tls = threading.local()
+
+
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream as the C-ABI's stream argument (inside a one_stream scope: the stream that was current at its start)."""
+    s = getattr(_tls, 'stream', None)
+    return s if s is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def one_stream(fn):
+    """Decorator for a launch plan (hundreds of kernels, no stream switch inside): look torch's current stream up once instead of per
+    launch (torch.cuda.current_stream() costs a few microseconds, comparable to a small kernel).  Per thread: autograd runs backward
+    passes on its own thread."""
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        if getattr(_tls, 'stream', None) is not None:
+            return fn(*a, **kw)
+        _tls.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        try:
+            return fn(*a, **kw)
+        finally:
+            _tls.stream = None
+    return wrapped
 
 
 # operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 'f16' = one fp16 plane,
@@ -38,6 +61,13 @@ def act_planes(split):
     return (2, 0) if split else (1, 0)
 
 
+def hi_plane(v):
+    """The same view without its lo plane (None stays None)."""
+    if v is None:
+        return None
+    return ActView(v.hi, None, v.ncg, v.H, v.W, v.batch_stride, v.cg_stride, v.fmt)
+
+
 class ActBuf:
     """[B][CG][H+2][W+2][8] bf16 `hi` (+ `lo`) planes.  Allocated zeroed, so the 1-pixel border the conv kernels
     rely on is zero from the start; producers never write it."""
@@ -49,14 +79,20 @@ class ActBuf:
         self.lo = torch.zeros_like(self.hi) if self.nplanes == 2 else None
         self.cg_stride = (H + 2) * (W + 2)
         self.batch_stride = ncg * self.cg_stride
+        self._views = {}
 
     def view(self, cg0=0, ncg=None, with_lo=True):
-        """esr_act_view of groups [cg0, cg0+ncg).  with_lo=False: a producer shall write (a consumer shall see) the hi plane only."""
-        ncg = self.ncg - cg0 if ncg is None else ncg
-        assert 0 <= cg0 and cg0 + ncg <= self.ncg
-        off = cg0 * self.cg_stride * 16
-        return ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if (self.nplanes == 2 and with_lo) else None, ncg, self.H, self.W,
-                       self.batch_stride, self.cg_stride, self.fmt)
+        """esr_act_view of groups [cg0, cg0+ncg).  with_lo=False: a producer shall write (a consumer shall see) the hi plane only.
+        Memoised per buffer (treat views as immutable): a pass over the generator asks for the same few thousand views every step."""
+        key = (cg0, ncg, with_lo)
+        v = self._views.get(key)
+        if v is None:
+            n = self.ncg - cg0 if ncg is None else ncg
+            assert 0 <= cg0 and cg0 + n <= self.ncg
+            off = cg0 * self.cg_stride * 16
+            v = self._views[key] = ActView(self.hi.data_ptr() + off, (self.lo.data_ptr() + off) if (self.nplanes == 2 and with_lo) else None,
+                                           n, self.H, self.W, self.batch_stride, self.cg_stride, self.fmt)
+        return v
 
     def nbytes(self):
         return self.hi.numel() * 2 * self.nplanes

@@ -30,7 +30,7 @@ class _RRDBFunction(torch.autograd.Function):
 
 
 def rrdb_forward_with_grad(engine, x, pad):
-    params = [p for p in engine.net.parameters()]
+    params = engine.parameters()
     return _RRDBFunction.apply(engine, pad, x, *params)
 
 

@@ -33,6 +33,7 @@ class RRDBEngine:
         self.split = True
         if os.environ.get('ESR_DEFAULT_PRECISION'):        # experiments / whole-suite checks of a non-default mode
             self.split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[os.environ['ESR_DEFAULT_PRECISION']]
+        self._convs_cache = None
         self._packed = None
         self._packed_t = None
         self._packed_rdb_t = None
@@ -55,7 +56,16 @@ class RRDBEngine:
 
     # ------------------------------------------------------------------ weights
     def _convs(self):
-        """(name, conv module, n_latent) in execution order, following the reference's module tree."""
+        """(name, conv module, n_latent) in execution order, following the reference's module tree (walked once: the tree is static)."""
+        if self._convs_cache is None:
+            self._convs_cache = self._walk_convs()
+        return self._convs_cache
+
+    def parameters(self):
+        """The generator's parameters in execution order, without walking the module tree (700 of them, every forward)."""
+        return [p for _, c, _ in self._convs() for p in (c.weight, c.bias) if p is not None]
+
+    def _walk_convs(self):
         net = self.net
         m = net.model
         lat_first, lat = net.num_latent_channels if net.latent_input is not None else 0, net._lat_all_layers
@@ -204,7 +214,7 @@ class RRDBEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x, pad=0):
         A.require_gpu(x, 'generator input')
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.net.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from . import autograd as AG
             return AG.rrdb_forward_with_grad(self, x, pad)
         return self.run_forward(x, pad, keep=False)[0]
@@ -221,6 +231,7 @@ class RRDBEngine:
             raise EsrError('expected %d input channels (latent %d x sf^2 + 3), got %d' % (lat1 * sf * sf + 3, lat1, x.shape[1]))
         return sf, has_lat, lat1
 
+    @A.one_stream
     def run_forward(self, x, pad=0, keep=False):
         """Returns (g, bufs).  keep=True keeps one buffer per RDB so that `bufs` holds every activation the backward needs."""
         net = self.net
@@ -301,11 +312,12 @@ class RRDBEngine:
         return g, bufs
 
     # ------------------------------------------------------------------ backward
+    @A.one_stream
     def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
-        if self.split == 'mixed' and need_dw:
-            raise NotImplementedError("precision 'mixed' back-propagates to the INPUT only (Z optimisation): its saved activations are fp16, the "
-                                      "weight-gradient kernel wants them in the gradients' bf16 hi+lo format; train in 'split' or 'bf16'")
+        if self.split == 'mixed' and need_dw and self._bwd_split != 'mixed':
+            raise NotImplementedError("precision 'mixed' with ESR_MIXED_BWD=bf16 back-propagates to the INPUT only (Z optimisation): its saved "
+                                      "activations are fp16, the gradients bf16 — the weight-gradient kernel contracts one element format")
         if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
@@ -323,17 +335,17 @@ class RRDBEngine:
         dg = dg.detach()
         dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
         f16_bwd = sp == 'mixed'
-        unscale = None
+        gscale = None                 # device scalar: the power of two the gradients in flight are currently scaled by
         if f16_bwd:
-            # fp16 gradients: scale the incoming gradient by a power of two so that its largest element is in [8, 16) — 12 binades of head
-            # room before fp16 overflows, 18 before the hi plane goes subnormal — and scale dx back at the end.  Computed on the device
-            # (no host synchronisation); an all-zero gradient keeps scale 1.
-            amax = dg.abs().amax()
-            scale = torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(16.0 / amax.clamp_min(1e-37)))), torch.ones_like(amax))
-            dg = dg * scale
-            unscale = 1.0 / scale
+            # fp16 gradients need their magnitude managed: the incoming gradient is scaled by a power of two (largest element into
+            # [128, 256)) and the gradient of the trunk, which the HR stages of a freshly initialised generator attenuate ~1000x, is
+            # scaled again (largest element into [512, 1024)) before it enters the dense blocks, whose intermediate gradients are another
+            # ~60x smaller and stored in one fp16 plane.  dx and dW are scaled back at the end.  All on the device, no host synchronisation.
+            gscale = _pow2_scale(dg.abs().amax(), 256.0)
+            dg = dg * gscale
         hi_only = dict(in1_lo_groups=-1) if f16_bwd else {}       # dense-block convs multiply hi planes only (see run_forward)
-        wg = WGrad(self, need_dw, B)
+        wg = WGrad(self, need_dw, B, hi_only=f16_bwd)
+        wg.gscale = gscale
         # gradient buffers come from a per-engine pool and go back to it when this pass is over: their zero borders (which the conv
         # kernels rely on and no producer ever writes) survive, so a steady-state step does no buffer memsets at all.  Everything
         # runs on one stream, so the next pass may reuse them as soon as its kernels are enqueued behind this one's.
@@ -409,6 +421,12 @@ class RRDBEngine:
             cur_g = nxt_g
             del tmp
         G_trunk = cur_g
+        if f16_bwd:
+            s2 = _pow2_scale(G_trunk.hi.view(torch.float16).abs().amax().float(), 1024.0)
+            for pl in (G_trunk.hi, G_trunk.lo):
+                pl.view(torch.float16).mul_(s2)          # exact: a power of two
+            gscale_hr, gscale = gscale, gscale * s2      # the HR-resolution latent gradient (GZ_hr) stays at the first scale
+            wg.gscale = gscale
         # ---- trunk: trunk = fea + LR_conv(last)
         last_act = bufs['last'] if net.nb else bufs['fea']
         pr = self.packed_rdb_t() if net.nb else {}
@@ -470,14 +488,24 @@ class RRDBEngine:
                 # the latent's gradient goes back through the raw [lat][sf*h0][sf*w0] view of the first lat*sf^2 channels
                 kw = dict(batch_stride=Ct * h0 * w0)
                 A.unpack_grad_nchw(GZ_lr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, down=sf, **kw)
-                if GZ_hr is not None:
+                if GZ_hr is not None and not f16_bwd:
                     A.unpack_grad_nchw(GZ_hr.view(), dx, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad, accumulate=True, **kw)
-        if dx is not None and unscale is not None:
-            dx.mul_(unscale)
+        if dx is not None and gscale is not None:
+            dx.div_(gscale)
+            if GZ_hr is not None:     # scaled differently from the trunk's gradients: unpacked on its own, added in fp32
+                dz = torch.zeros(B, lat1 * sf * sf, h0, w0, dtype=torch.float32, device=dev)
+                A.unpack_grad_nchw(GZ_hr.view(), dz, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad)
+                dx[:, :lat1 * sf * sf].add_(dz.div_(gscale_hr))
         grads = wg.result()                   # the batched weight-gradient launch is enqueued here, before the buffers are recycled
         for buf in taken:
             self._gpool[buf.ncg, buf.H, buf.W].append(buf)
         return dx, grads
+
+
+def _pow2_scale(amax, target):
+    """Device scalar 2^k with amax * 2^k in [target/2, target); 1 for amax == 0."""
+    amax = amax.float()
+    return torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(target / amax.clamp_min(1e-37)))), torch.ones_like(amax))
 
 
 class WGrad:
@@ -485,8 +513,13 @@ class WGrad:
     them all in one batched launch (esr_conv3x3_wgrad_batch), which is why every gradient / activation buffer a record refers to
     is kept alive here until then."""
 
-    def __init__(self, engine, enabled, B):
+    def __init__(self, engine, enabled, B, hi_only=False):
         self.engine, self.enabled, self.B = engine, enabled, B
+        # hi_only ('mixed'): gradients and activations are fp16 planes and the contraction uses their hi planes (one MFMA per product, fp32
+        # accumulate).  gscale: device scalar (or None), the power of two the dy recorded from now on are scaled by; result() divides
+        # each layer's gradients by the value that was current when the layer was recorded.
+        self.hi_only, self.gscale = hi_only, None
+        self.scaled = []              # (flat offset, length, gscale)
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
@@ -503,8 +536,12 @@ class WGrad:
         if not self.enabled:
             return
         c = self.mods[name]
+        if self.hi_only:
+            dy, x_main, x_lat = A.hi_plane(dy), A.hi_plane(x_main), A.hi_plane(x_lat)
         o, nw = self.offsets[name], c.weight.numel()
         out = (self.flat[o:o + nw].view(c.weight.shape), self.flat[o + nw:o + nw + c.weight.shape[0]])
+        if self.gscale is not None:
+            self.scaled.append((o, nw + c.weight.shape[0], self.gscale))
         d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device, out=out)
         self.descs.append(d)
         self.keep.extend(keep)
@@ -517,5 +554,14 @@ class WGrad:
     def result(self):
         if self.enabled and self.descs:
             A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device)
+            # undo the gradient scaling: consecutive layers recorded under the same scale are contiguous in `flat` more often than not
+            runs = []
+            for o, n, g in sorted(self.scaled, key=lambda t: t[0]):
+                if runs and runs[-1][2] is g and runs[-1][0] + runs[-1][1] == o:
+                    runs[-1][1] += n
+                else:
+                    runs.append([o, n, g])
+            for o, n, g in runs:
+                self.flat[o:o + n].div_(g)
             self.descs, self.keep = [], []
         return self.grads

@@ -186,12 +186,15 @@ class SRRaGANModel(BaseModel):
         if self.cri_pix is not None:
             l_g_pix = self.cri_pix(fake_H, var_H)
             l_g_total = l_g_total + self.l_pix_w * l_g_pix / self.grad_accumulation_steps_G
-            self.l_g_pix_grad_step.append(l_g_pix.item())
         if self.cri_range is not None:
             l_g_range = self.cri_range(fake_H)
             l_g_total = l_g_total + self.l_range_w * l_g_range / self.grad_accumulation_steps_G
-            self.l_g_range_grad_step.append(l_g_range.item())
         l_g_total.backward()
+        # the loss values are read (a host synchronisation) only after the backward pass is enqueued, as in the reference (:483-493)
+        if self.cri_pix is not None:
+            self.l_g_pix_grad_step.append(l_g_pix.item())
+        if self.cri_range is not None:
+            self.l_g_range_grad_step.append(l_g_range.item())
         if last_grad_accumulation_step_G:
             self.grad_reducer()                               # RCCL all-reduce (mean) of the G gradients: the one exchange step
             self.optimizer_G.step()

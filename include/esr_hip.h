@@ -49,13 +49,13 @@ typedef void* esr_stream_t;   /* hipStream_t */
 
 /* A view of `ncg` consecutive channel groups inside an activation buffer. */
 typedef struct {
-    void* hi;                /* bf16 planes, NULL = view absent */
-    void* lo;                /* bf16 residual planes or NULL (plain-bf16 mode) */
+    void* hi;                /* 16-bit planes (bf16 or fp16, see fmt), NULL = view absent */
+    void* lo;                /* residual planes (value = hi + lo) or NULL: single-plane view */
     int32_t ncg;             /* number of 8-channel groups in this view */
     int32_t H, W;            /* interior size; the buffer holds (H+2) x (W+2) pixels per group */
     int64_t batch_stride;    /* in 16-byte pixel vectors */
     int64_t cg_stride;       /* in 16-byte pixel vectors (normally (H+2)*(W+2)) */
-    int32_t fmt;             /* element format of the planes: ESR_FMT_BF16 (default; hi [+ lo]) or ESR_FMT_F16 (hi only) */
+    int32_t fmt;             /* element format of the planes: ESR_FMT_BF16 (default) or ESR_FMT_F16; both as hi [+ lo] */
 } esr_act_view;
 
 /* ---- conv3x3 (+bias, +LeakyReLU, +scaled residuals, + fused nearest upsample of the input) ----
