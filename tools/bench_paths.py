@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--nb', type=int, default=23)
-    ap.add_argument('--precision', default='split', choices=['split', 'mixed', 'f16x2', 'f16', 'bf16'], help="'bf16': single-MFMA operands (C3 names bf16); the fp16 modes are inference-only (c5)")
+    ap.add_argument('--precision', default='split', choices=['split', 'mixed', 'f16x2', 'f16', 'bf16'], help="'mixed': fp16 planes, fp32-class forward (inference, Z search, training); 'bf16': single-MFMA operands (C3 names bf16); 'f16x2' / 'f16' are inference-only (c5)")
     a = ap.parse_args()
     from esr_hip import dist as D
     D.init_from_env()
