@@ -55,6 +55,8 @@ _SIGS = {
     'esr_zero': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     'esr_act_combine': (C.c_int, [C.POINTER(ActView), C.c_float, C.POINTER(ActView), C.c_float, C.c_int, C.POINTER(ActView), C.c_float,
                                   C.POINTER(ActView), C.c_int, C.c_void_p]),
+    'esr_grad_absmax': (C.c_int, [C.POINTER(ActView), C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_grad_scale': (C.c_int, [C.POINTER(ActView), C.POINTER(ActView), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'esr_unpack_grad_nchw': (C.c_int, [C.POINTER(ActView), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p]),
     'esr_cem_adjoint': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

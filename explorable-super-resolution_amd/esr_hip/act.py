@@ -349,6 +349,40 @@ def act_combine(out, B, A_=None, alpha=1.0, Bv=None, beta=1.0, s=1, mask=None, m
     check(_lib.lib.esr_act_combine(ref(A_), alpha, ref(Bv), beta, s, ref(mask), mask_slope, C.byref(out), B, stream_ptr()), 'esr_act_combine')
 
 
+class GradScaler:
+    """Running power-of-two scale of the fp16 gradients of one backward pass, kept on the device (esr_grad_absmax / esr_grad_scale).
+    `current` is a 0-dim fp32 tensor (a slice of one small buffer): the scale the gradients in flight carry right now; every rescale()
+    moves to the next slice, so tensors handed out earlier keep the value that was in force then."""
+
+    def __init__(self, device, first):
+        self.slots = torch.zeros(64, dtype=torch.int32, device=device)
+        self.scales = torch.ones(65, dtype=torch.float32, device=device)
+        self.scales[0:1].copy_(first.reshape(1))
+        self.i = 0
+
+    @property
+    def current(self):
+        return self.scales[self.i]
+
+    def _ptr(self, t, i):
+        return t.data_ptr() + 4 * i
+
+    def rescale(self, B, views, exp):
+        """Bring max|hi| of views[0] into [2^(exp-1), 2^exp), scale the other views by the same factor, advance `current`."""
+        assert self.i < 64
+        slot = self._ptr(self.slots, self.i)
+        check(_lib.lib.esr_grad_absmax(C.byref(views[0]), B, slot, stream_ptr()), 'esr_grad_absmax')
+        for j, v in enumerate(views):
+            check(_lib.lib.esr_grad_scale(C.byref(v), C.byref(v), B, slot, exp, self._ptr(self.scales, self.i), None,
+                                          self._ptr(self.scales, self.i + 1) if j == 0 else None, stream_ptr()), 'esr_grad_scale')
+        self.i += 1
+
+    def rescaled_copy(self, B, src, dst, scale_then):
+        """dst = src * (current / scale_then): bring a buffer produced under an earlier scale to the current one."""
+        check(_lib.lib.esr_grad_scale(C.byref(src), C.byref(dst), B, None, 0, self._ptr(self.scales, self.i), scale_then.data_ptr(), None,
+                                      stream_ptr()), 'esr_grad_scale')
+
+
 def unpack_grad_nchw(G, dst, C_, h, w, c0, nc, pad=0, down=1, accumulate=False, batch_stride=0):
     """Adjoint of pack_nchw: act-layout gradient G -> channels [c0, c0+nc) of the fp32 gradient `dst` of an un-padded source
     laid out [B][C_][h][w] (image b at dst + b*batch_stride floats; 0 = C_*h*w)."""

@@ -44,8 +44,8 @@ class RRDBEngine:
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
-        # 'mixed': fp16 hi+lo activations everywhere; hi+lo weights (3 MFMAs) in the few layers outside the dense blocks, whose weight
-        # rounding would dominate the output error, single-plane weights (2 MFMAs) in the dense-block convs
+        # 'mixed': fp16; residual stream stored hi+lo; hi+lo weights x hi+lo activations (3 MFMAs) in the few layers outside the dense blocks,
+        # whose rounding would dominate the output error; one-plane weights x hi planes (1 MFMA) in the dense-block convs
         split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[precision]
         if split != self.split:
             self.split = split
@@ -337,11 +337,16 @@ class RRDBEngine:
         f16_bwd = sp == 'mixed'
         gscale = None                 # device scalar: the power of two the gradients in flight are currently scaled by
         if f16_bwd:
-            # fp16 gradients need their magnitude managed: the incoming gradient is scaled by a power of two (largest element into
-            # [128, 256)) and the gradient of the trunk, which the HR stages of a freshly initialised generator attenuate ~1000x, is
-            # scaled again (largest element into [512, 1024)) before it enters the dense blocks, whose intermediate gradients are another
-            # ~60x smaller and stored in one fp16 plane.  dx and dW are scaled back at the end.  All on the device, no host synchronisation.
-            gscale = _pow2_scale(dg.abs().amax(), 256.0)
+            # fp16 gradients need their magnitude managed, on the device (no host synchronisation), by powers of two (exact):
+            #   * the incoming gradient is scaled so that its largest element lies in [8, 16): 12 binades of head room for the HR stages,
+            #     whose gradients are hi+lo pairs (22 bits as long as they stay above fp16's subnormals);
+            #   * the gradient of the trunk — which the HR stages of a freshly initialised generator attenuate ~1000x — and then the
+            #     gradient of every RRDB's input are brought into [512, 1024): the dense blocks' one-plane intermediate gradients are
+            #     ~60x smaller than the stream's and must stay in fp16's normal range, while a trained network may amplify the stream
+            #     gradient by an order of magnitude per RRDB;
+            #   * dx and every layer's dW are divided by the scale that was in force where they were produced.
+            scaler = A.GradScaler(dev, _pow2_scale(dg, 4))
+            gscale = scaler.current
             dg = dg * gscale
         hi_only = dict(in1_lo_groups=-1) if f16_bwd else {}       # dense-block convs multiply hi planes only (see run_forward)
         wg = WGrad(self, need_dw, B, hi_only=f16_bwd)
@@ -422,10 +427,9 @@ class RRDBEngine:
             del tmp
         G_trunk = cur_g
         if f16_bwd:
-            s2 = _pow2_scale(G_trunk.hi.view(torch.float16).abs().amax().float(), 1024.0)
-            for pl in (G_trunk.hi, G_trunk.lo):
-                pl.view(torch.float16).mul_(s2)          # exact: a power of two
-            gscale_hr, gscale = gscale, gscale * s2      # the HR-resolution latent gradient (GZ_hr) stays at the first scale
+            scaler.rescale(B, [G_trunk.view()], 10)
+            gscale_hr, gscale = gscale, scaler.current   # the HR-resolution latent gradient (GZ_hr) stays at the first scale
+            gscale_trunk = gscale                        # ... and G_trunk, needed again for the trunk's shortcut, at this one
             wg.gscale = gscale
         # ---- trunk: trunk = fea + LR_conv(last)
         last_act = bufs['last'] if net.nb else bufs['fea']
@@ -472,10 +476,19 @@ class RRDBEngine:
                 kw = dict(res2=G_rrdb.view(0, 8), beta2=1.0) if k == 0 else {}
                 conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw, **hi_only)
                 G_cur = G_next
+            if f16_bwd and os.environ.get('ESR_GRAD_RENORM', '1') != '0':
+                # d(input of RRDB r) is complete and not yet recorded anywhere: renormalise it (and the latent gradient accumulated so far)
+                scaler.rescale(B, [G_cur.view(0, 8)] + ([GZ_lr.view()] if lat and not zfirst else []), 10)
+                gscale = scaler.current
+                wg.gscale = gscale
             dout = G_cur
         # d fea = d trunk (shortcut) + d(first RRDB input)
         G_fea = galloc(B, 8, h, w)
-        A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_trunk.view(), beta=1.0, s=1)
+        G_short = G_trunk
+        if f16_bwd and net.nb:        # the shortcut's gradient at the current scale (a copy: the weight-gradient launch still reads G_trunk)
+            G_short = galloc(B, 8, h, w)
+            scaler.rescaled_copy(B, G_trunk.view(), G_short.view(), gscale_trunk)
+        A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_short.view(), beta=1.0, s=1)
         wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w, keep=(G_fea,))
         dx = None
         if need_dx:
@@ -502,10 +515,10 @@ class RRDBEngine:
         return dx, grads
 
 
-def _pow2_scale(amax, target):
-    """Device scalar 2^k with amax * 2^k in [target/2, target); 1 for amax == 0."""
-    amax = amax.float()
-    return torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(target / amax.clamp_min(1e-37)))), torch.ones_like(amax))
+def _pow2_scale(t, exp):
+    """Device scalar 2^k such that max|t| * 2^k lies in [2^(exp-1), 2^exp)  (k = exp for an all-zero t)."""
+    _, e = torch.frexp(torch.linalg.vector_norm(t, ord=float('inf')).float())          # max|t| = m * 2^e, m in [0.5, 1)
+    return torch.ldexp(torch.ones((), dtype=torch.float32, device=t.device), exp - e)
 
 
 class WGrad:

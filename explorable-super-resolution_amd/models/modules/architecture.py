@@ -78,9 +78,13 @@ class RRDBNet(nn.Module):
         return self._engine
 
     def set_precision(self, precision):
-        """'split' (default; bf16 hi+lo operands, 3 MFMAs per product, fp32-class accuracy), 'f16x2' (fp16 weights x fp16 hi+lo activations, 2 MFMAs,
-        ~5e-4 on RRDB-23, inference-only), 'bf16' or 'f16' (single-MFMA modes with fp32 accumulation; 'f16' is ~8x more accurate than
-        'bf16' and inference-only)."""
+        """Operand scheme of the MFMA kernels (fp32 accumulate and fp32 I/O in all of them):
+        'split'  default: bf16 hi+lo weights x bf16 hi+lo activations, 3 MFMAs per product, fp32-class forward AND gradients;
+        'mixed'  fp16: residual stream stored hi+lo, hi+lo operands in the six convs outside the dense blocks, one-plane operands inside
+                 them; forward within 3e-5..3e-4 of fp32 at 0.55x the time of split; back-propagates with power-of-two gradient scaling
+                 (input gradient ~1e-5, weight gradients ~3e-3 of fp32): inference, Z search, optionally training;
+        'f16x2'  fp16 weights x fp16 hi+lo activations, 2 MFMAs, ~5e-4 on RRDB-23, inference only;
+        'f16' / 'bf16'  one plane, one MFMA; 'f16' (1.6e-3) is inference only, 'bf16' (1.3e-2) also trains."""
         assert precision in ('split', 'mixed', 'f16x2', 'f16', 'bf16')
         self.engine.set_precision(precision)
 

@@ -186,6 +186,16 @@ int esr_act_combine(const esr_act_view* A, float alpha, const esr_act_view* Bv, 
  * act-layout gradient -> fp32 NCHW gradient of channels [c0, c0+nc) of the un-padded source. */
 int esr_unpack_grad_nchw(const esr_act_view* G, float* dst, int64_t dst_batch_stride, int B, int C, int h, int w, int c0, int nc,
                          int pad, int down, int accumulate, esr_stream_t stream);
+/* Magnitude management of fp16 gradients (the 'mixed' precision's backward; no counterpart in the reference, whose gradients are fp32):
+ * esr_grad_absmax: *slot = max(*slot, bit pattern of max|hi|) over the view's groups (fp16 planes; the caller zeroes the slot once).
+ * esr_grad_scale : dst = src * f (hi and lo planes; dst may be src), f a power of two taken from device memory:
+ *   slot != NULL : f = 2^k with max|hi| * 2^k in [2^(exp-1), 2^exp)  (k = 0 when the view is all zero); scale_out, if given, receives
+ *                  scale_in[0] * f — the running scale of the gradients in flight;
+ *   slot == NULL : f = scale_in[0] / scale_den[0].
+ * Nothing is read back by the host. */
+int esr_grad_absmax(const esr_act_view* v, int B, uint32_t* slot, esr_stream_t stream);
+int esr_grad_scale(const esr_act_view* src, const esr_act_view* dst, int B, const uint32_t* slot, int exp, const float* scale_in,
+                   const float* scale_den, float* scale_out, esr_stream_t stream);
 /* Adjoint of a CEM filter (see csrc/esr_cem.hip): y[q] = sum taps * frame[clamp(q*sq+oq + a - p)], unknowns at n*sn+on.
  * tabs: device fp32 [3][3][k][k] prefix/plain/suffix tap tables (esr_hip/cem_ops.py builds them). */
 int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
