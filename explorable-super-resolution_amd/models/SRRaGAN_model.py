@@ -76,7 +76,8 @@ class SRRaGANModel(BaseModel):
         self.netG.to(self.device)
         esr_dist.broadcast_parameters(self.netG)          # every rank starts from rank 0's weights
         logs_2_keep = ['l_g_pix', 'l_g_range', 'psnr_val', 'LR_decrease']
-        self.log_dict = OrderedDict(zip(logs_2_keep, [[] for _ in logs_2_keep]))
+        self._log_dict = OrderedDict(zip(logs_2_keep, [[] for _ in logs_2_keep]))
+        self._pending_logs = []          # (key, step, [loss tensors of the accumulation steps]): read back lazily, see log_dict
         self.D_exists = False
         self.generator_changed = True
         if self.is_train:
@@ -173,6 +174,7 @@ class SRRaGANModel(BaseModel):
         first_grad_accumulation_step_G = self.step % self.grad_accumulation_steps_G == 0
         last_grad_accumulation_step_G = self.step % self.grad_accumulation_steps_G == (self.grad_accumulation_steps_G - 1)
         if first_grad_accumulation_step_G:
+            self.log_dict                                   # read back the previous step's loss values (already computed: no stall)
             self.optimizer_G.zero_grad()
             self.l_g_pix_grad_step, self.l_g_range_grad_step = [], []
         var_H = self.var_H
@@ -190,22 +192,32 @@ class SRRaGANModel(BaseModel):
             l_g_range = self.cri_range(fake_H)
             l_g_total = l_g_total + self.l_range_w * l_g_range / self.grad_accumulation_steps_G
         l_g_total.backward()
-        # the loss values are read (a host synchronisation) only after the backward pass is enqueued, as in the reference (:483-493)
+        # The reference reads the loss values back right here (.item(), :483-493): a host synchronisation per step, during which the GPU
+        # drains and then idles while the host prepares the next step.  Here they stay on the device and are read when somebody looks at
+        # the log (log_dict / get_current_log) or when the next step starts — by then the kernels that produced them finished long ago.
         if self.cri_pix is not None:
-            self.l_g_pix_grad_step.append(l_g_pix.item())
+            self.l_g_pix_grad_step.append(l_g_pix.detach())
         if self.cri_range is not None:
-            self.l_g_range_grad_step.append(l_g_range.item())
+            self.l_g_range_grad_step.append(l_g_range.detach())
         if last_grad_accumulation_step_G:
             self.grad_reducer()                               # RCCL all-reduce (mean) of the G gradients: the one exchange step
             self.optimizer_G.step()
             self.generator_changed = True
             if self.cri_pix is not None:
-                self.log_dict['l_g_pix'].append((self.gradient_step_num, float(np.mean(self.l_g_pix_grad_step))))
+                self._pending_logs.append(('l_g_pix', self.gradient_step_num, self.l_g_pix_grad_step))
             if self.cri_range is not None:
-                self.log_dict['l_g_range'].append((self.gradient_step_num, float(np.mean(self.l_g_range_grad_step))))
+                self._pending_logs.append(('l_g_range', self.gradient_step_num, self.l_g_range_grad_step))
         self.step += 1
 
     # ------------------------------------------------------------------ bookkeeping
+    @property
+    def log_dict(self):
+        """{name: [(gradient step, value), ...]} as in the reference; pending device-side loss values are read back first."""
+        pending, self._pending_logs = self._pending_logs, []
+        for key, step, vals in pending:
+            self._log_dict[key].append((step, float(np.mean([float(v) for v in vals]))))
+        return self._log_dict
+
     def get_current_log(self):
         return OrderedDict((k, v[-1][1]) for k, v in self.log_dict.items() if len(v) > 0)
 
