@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates the measurements committed under profiles/ for the current kernel set, on a machine with one MI355X:
+#   the bench line, the rocprofv3 kernel summary of the same command, and the HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
+#   SEPARATE passes, never combined with a trace domain), then condenses them with tools/summarise_profiles.py.
+# usage: tools/reproduce_profiles.sh <tag> [precision]       e.g.  tools/reproduce_profiles.sh r02_v1_mixed mixed
+set -e
+TAG=${1:?tag}; PREC=${2:-mixed}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --precision $PREC"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $B > /dev/null 2>&1
+python tools/summarise_profiles.py --tag "$TAG" --stats "$(dirname "$(find "$OUT/stats" -name '*_kernel_stats.csv' | head -1)")" \
+    --fetch "$(dirname "$(find "$OUT/fetch" -name '*_counter_collection.csv' | head -1)")" \
+    --write "$(dirname "$(find "$OUT/write" -name '*_counter_collection.csv' | head -1)")"
+python bench.py --steps 10 --warmup 3 --precision "$PREC" | tee "profiles/${TAG}_bench.json.log"
