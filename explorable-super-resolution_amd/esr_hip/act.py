@@ -354,9 +354,10 @@ class GradScaler:
     `current` is a 0-dim fp32 tensor (a slice of one small buffer): the scale the gradients in flight carry right now; every rescale()
     moves to the next slice, so tensors handed out earlier keep the value that was in force then."""
 
-    def __init__(self, device, first):
-        self.slots = torch.zeros(64, dtype=torch.int32, device=device)
-        self.scales = torch.ones(65, dtype=torch.float32, device=device)
+    def __init__(self, device, first, max_rescales=64):
+        self.n = max_rescales
+        self.slots = torch.zeros(self.n, dtype=torch.int32, device=device)
+        self.scales = torch.ones(self.n + 1, dtype=torch.float32, device=device)
         self.scales[0:1].copy_(first.reshape(1))
         self.i = 0
 
@@ -369,7 +370,7 @@ class GradScaler:
 
     def rescale(self, B, views, exp):
         """Bring max|hi| of views[0] into [2^(exp-1), 2^exp), scale the other views by the same factor, advance `current`."""
-        assert self.i < 64
+        assert self.i < self.n
         slot = self._ptr(self.slots, self.i)
         check(_lib.lib.esr_grad_absmax(C.byref(views[0]), B, slot, stream_ptr()), 'esr_grad_absmax')
         for j, v in enumerate(views):

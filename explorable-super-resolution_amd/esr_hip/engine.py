@@ -345,7 +345,7 @@ class RRDBEngine:
             #     ~60x smaller than the stream's and must stay in fp16's normal range, while a trained network may amplify the stream
             #     gradient by an order of magnitude per RRDB;
             #   * dx and every layer's dW are divided by the scale that was in force where they were produced.
-            scaler = A.GradScaler(dev, _pow2_scale(dg, 4))
+            scaler = A.GradScaler(dev, _pow2_scale(dg, 4), max_rescales=net.nb + 2)
             gscale = scaler.current
             dg = dg * gscale
         hi_only = dict(in1_lo_groups=-1) if f16_bwd else {}       # dense-block convs multiply hi planes only (see run_forward)
