@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd'))
 import numpy as np, torch
 from esr_hip import _lib, act
 dev = 'cuda'
-B, H, W = 32, 148, 148
+B, H, W = [int(v) for v in os.environ.get("SHAPE", "32,148,148").split(",")]
 cin, cout = int(sys.argv[1]) if len(sys.argv) > 1 else 128, int(sys.argv[2]) if len(sys.argv) > 2 else 32
 torch.manual_seed(0)
 buf = act.ActBuf(B, 24, H, W, dev, split='mixed')
