@@ -2,30 +2,33 @@
 """Headline benchmark: HR pixels / second of the RRDB-23 x4 generator + CEM (eval mode) forward on synthetic
 32 x 3 x 128 x 128 fp32 batches per GPU (BASELINE.json configs[1]), weak scaling over N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
 
-A step = one forward of the hot path over one batch already resident in HBM.  Rank 0 prints ONE JSON line with the
-throughput, the roofline fraction of the dominant kernel (conv3x3, measured with HIP events on the launch stream) and a CPU
-baseline (the oracle's CPU restatement, timed on this box's host cores on a bounded sample).
+`--gpus N` with N > 1 launches its own ranks (python -m torch.distributed.run, one process per GPU, RCCL) unless it already runs
+under a launcher (WORLD_SIZE set).  A step = one pass of the hot path over one batch already resident in HBM.  Rank 0 prints ONE
+JSON line with the throughput, the roofline fraction of the dominant kernel (conv3x3, measured with HIP events on the launch
+stream) and a CPU baseline (the oracle's CPU restatement, timed on this box's host cores on a bounded sample).
 
-Arithmetic.  The headline runs the generator's inference precision 'mixed' (DESIGN.md section 5): fp32 in and out, fp16 MFMA operands
-with fp32 accumulation, hi+lo planes (22 bits) wherever the output is sensitive to them.  BASELINE.md section 2 sets the criterion — a
-scheme qualifies if it meets the 1e-3 parity bar against fp32 (exact-fp32 math is capped at 14 % of the HBM-roofline rate on this part) —
-and the line carries the evidence: `generator_rel_l2_vs_cpu_oracle` / `generator_rel_max_vs_cpu_oracle` of the benchmarked weights (3e-5).
-The same workload in 'split' (bf16 hi+lo operands in every layer, the mode training uses) is timed right after it and reported in the
-`alt_precision` block.
+Arithmetic.  The headline runs the fp32-class precision 'split' (bf16x3): every product of every layer is evaluated from 16-bit
+operands (bf16 hi + bf16 lo, three MFMAs, fp32 accumulate) — the scheme SURVEY.md section 7.4 sanctions for the fp32 configs.
+'mixed' (fp16 operands, one MFMA per product inside the dense blocks: narrower than fp32-class arithmetic by the letter, 3e-5
+from the fp32 oracle on this workload) is timed right after it and reported in the `alt_precision` block with BOTH of its
+roofline fractions: against the fp32-equivalent algorithmic bytes and against the bytes it physically moves.
+
+`--workload c3` times the generator + discriminator training step of configs[2] at its per-GPU shape (32 crops of 52x52, latent 3)
+with the gradient all-reduce over RCCL when N > 1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd'))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 # SURVEY.md §8(d): RRDB-23 x4, batch 32, eval-padded 148^2 LR frames
 NB, SF, BATCH, LR_SIZE = 23, 4, 32, 128
@@ -37,9 +40,40 @@ FLOP_PER_LR_PX = 2 * 17926848
 FLOP_PER_FWD = LR_PX_THROUGH_G * FLOP_PER_LR_PX                    # 25.13 TFLOP
 HBM_PEAK = 8.0e12
 N_CONV_LAUNCHES = 3 + NB * 15 + 2 + 1                              # 351
+MFMA_TERMS = {'split': 3, 'f16x2': 2, 'mixed': 1.16}              # bf16/f16 MFMA instructions issued per product, network average
+
+DTYPE = {'split': 'bf16x3 (bf16 hi+lo operands = 16 significand bits per operand in every product, three MFMAs, f32 accumulate)',
+         'mixed': 'f16 (residual stream stored as hi+lo planes, hi+lo main-path weights, one-plane dense-block products, f32 accumulate)',
+         'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}
+ARITHMETIC = {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate, fp32 I/O', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
+              'f16': 'f16 MFMA operands, fp32 accumulate', 'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate',
+              'mixed': 'fp32 I/O; f16 MFMA operands, fp32 accumulate: residual stream stored as hi+lo (22-bit) planes; hi+lo weights x hi+lo '
+                       'activations (3 MFMAs) in the 6 convs outside the dense blocks; one-plane weights x hi planes (1 MFMA) and '
+                       'one-plane intermediates inside the dense blocks'}
 
 
+# ---------------------------------------------------------------------------------------------------------------- self-launch
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(gpus, argv, port=None, script=None):
+    """The command `bench.py --gpus N` re-executes itself with when it was started as a plain process: one rank per GPU on this node."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port or free_port()), script or os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(gpus, environ):
+    return gpus > 1 and 'WORLD_SIZE' not in environ
+
+
+# ---------------------------------------------------------------------------------------------------------------- workload pieces
 def build_model(device, nb=NB):
+    import torch
     import CEM.CEMnet as CEMnet
     import models.modules.architecture as arch
     import models.networks as networks
@@ -51,22 +85,21 @@ def build_model(device, nb=NB):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         networks.init_weights(G, init_type='kaiming', scale=0.1)      # the reference's training init (networks.py:119)
-    # kaiming x0.1 leaves the output ~1e-2; scale the last conv so that the SR image is O(1) like a trained generator's
     return cem, G.to(device).eval()
 
 
 def cpu_baseline(G, cem):
     """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on ONE 128x128 image of the same
-    workload: RRDB-23 x4 + CEM eval = 1/32 of a step.  ~1-3 s per run; 1 warm-up + 3 timed."""
+    workload: RRDB-23 x4 + CEM eval = 1/32 of a step.  Thread counts 8/16/32/64 (capped by the cores this process may use) are each
+    timed (1 warm-up + 2 runs) and the best is reported with its thread count: oversubscribed torch CPU convolutions are slower."""
+    import torch
     from oracle import cem_oracle as co
     from oracle import rrdb_oracle as ro
-    ncores = min(len(os.sched_getaffinity(0)), 64)     # cores this process may actually use (cgroup/affinity aware)
-    torch.set_num_threads(ncores)
+    avail = len(os.sched_getaffinity(0))     # cores this process may actually use (cgroup/affinity aware)
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
     taps = co.CEMTaps(SF)
     g = torch.Generator().manual_seed(1)
     x = torch.rand(1, 3, LR_SIZE, LR_SIZE, generator=g)
-
     keep = {}
 
     def run():
@@ -75,30 +108,69 @@ def cpu_baseline(G, cem):
             gen = ro.rrdb_forward(sd, xp, NB, SF, 0, prefix='generated_image_model.model')
             keep['gen'] = gen
             return co.cem_combine(xp, gen, taps, crop=True)
-    run()
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        y = run()
-        ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[1]
-    return {'value': (SF * LR_SIZE) ** 2 / t, 'unit': 'HR pixels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval), median of 3 runs, %.2f s each' % t}, x, y, keep['gen']
+    sweep = {}
+    y = None
+    for nt in sorted({min(n, avail) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        run()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            y = run()
+            ts.append(time.perf_counter() - t0)
+        sweep[nt] = min(ts)
+    best = min(sweep, key=sweep.get)
+    t = sweep[best]
+    return {'value': (SF * LR_SIZE) ** 2 / t, 'unit': 'HR pixels/s', 'cores': best, 'kind': 'port',
+            'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval), best of 2 runs at the best thread count, %.2f s each' % t,
+            'thread_sweep_s': {str(k): round(v, 3) for k, v in sweep.items()}, 'cores_available': avail}, x, y, keep['gen']
 
 
-def main():
-    global BATCH, LR_PX_THROUGH_G, ALGO_BYTES_PER_FWD, FLOP_PER_FWD
+def newest_pmc(precision):
+    """HBM bytes per conv launch measured with rocprofv3 PMC passes of this same command on an earlier run (FETCH_SIZE / WRITE_SIZE, separate
+    --pmc runs, FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/ for this precision."""
+    import glob
+    import re
+    pmc = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))
+                  if ('mixed' in os.path.basename(f)) == (precision == 'mixed')),
+                 key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])    # r01_v9 < r01_v11 < r02_v1
+    if not pmc or precision not in ('split', 'mixed'):
+        return None, None
+    return json.load(open(pmc[-1]))['hbm_bytes_per_launch'], os.path.basename(pmc[-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3'],
+                    help="c2 (default, the headline): configs[1] forward; c3: configs[2] G+D training step at its per-GPU shape, gradients all-reduced over RCCL")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precision', action='store_true', help="skip the extra timing of the 'mixed' fp16 mode")
-    ap.add_argument('--precision', default='mixed', choices=['mixed', 'split', 'f16x2', 'bf16', 'f16'],
-                    help="'mixed' (default, headline): fp16 operands with hi+lo planes wherever the output is sensitive to them, 3e-5 from the fp32 "
-                         "oracle on this workload; 'split': bf16 hi+lo everywhere (the training path), reported in the alt_precision block")
+    ap.add_argument('--precision', default=None, choices=['mixed', 'split', 'f16x2', 'bf16', 'f16'],
+                    help="c2 default 'split' (headline): bf16 hi+lo operands in every product; 'mixed': fp16 one-MFMA dense blocks, reported in the "
+                         "alt_precision block.  c3 default 'bf16' (configs[2] names bf16)")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    global BATCH, LR_PX_THROUGH_G, ALGO_BYTES_PER_FWD, FLOP_PER_FWD
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if needs_self_launch(args.gpus, os.environ):
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit('bench.py --gpus %d: this node exposes %d GPU(s)' % (args.gpus, have))
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # RCCL needs dmabuf IPC on this driver
+        env.setdefault('OMP_NUM_THREADS', '8')
+        sys.exit(subprocess.call(launch_command(args.gpus, argv), env=env))
+
+    import torch
     if args.batch != BATCH:
         BATCH = args.batch
         LR_PX_THROUGH_G = BATCH * (LR_SIZE + 2 * MARGIN_LR) ** 2
@@ -110,6 +182,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d: pass --gpus %d (or start it as a plain '
+                         'process, it launches its own ranks)' % (args.gpus, world, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -117,14 +192,43 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=dev)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        """(max over ranks, per-rank list) of a duration in seconds"""
+        if dist is None:
+            return dt, [dt]
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per = [float(a.item()) for a in allt]
+        return max(per), per
+
+    if args.workload == 'c3':
+        out = run_c3(args, dev, rank, world, dist, sync, max_over_ranks)
+    else:
+        out = run_c2(args, dev, rank, world, dist, sync, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
+    import torch
+    precision = args.precision or 'split'
     cem, G = build_model(dev)
-    G.generated_image_model.set_precision(args.precision)
+    net = G.generated_image_model
+    net.set_precision(precision)
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.rand(BATCH, 3, LR_SIZE, LR_SIZE, generator=g).to(dev)      # synthetic LR batch, resident in HBM
 
-    eng = G.generated_image_model.engine
+    eng = net.engine
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -138,109 +242,143 @@ def main():
             eng._ev = None
             return y
 
+    def timed(with_events):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            y = step(i if with_events else None)
+        sync()
+        return max_over_ranks(time.perf_counter() - t0) + (y,)
+
     for _ in range(args.warmup):
-        y = step()
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        y = step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+        step()
+    dt, per_rank, y = timed(True)
     ms_per_step = dt / args.steps * 1e3
     hr_px = BATCH * (SF * LR_SIZE) ** 2
     value = world * hr_px * args.steps / dt
+    if rank != 0:
+        if precision == 'split' and not args.no_alt_precision:      # every rank takes part in the alt timing's barriers
+            net.set_precision('mixed')
+            for _ in range(2):
+                step()
+            timed(False)
+        return None
 
-    if rank == 0:
-        # HBM bytes per conv launch from the PMC passes of this same command (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
-        # FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/
-        import glob
-        traffic = None
-        import re
-        pmc = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))
-                      if ('mixed' in os.path.basename(f)) == (args.precision == 'mixed')),      # the PMC passes of THIS precision mode
-                     key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])    # r01_v9 < r01_v11
-        if pmc and BATCH == 32 and args.precision in ('split', 'mixed'):
-            traffic = json.load(open(pmc[-1]))['hbm_bytes_per_launch']
-        conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
-        t_launch = conv_ms * 1e-3 / N_CONV_LAUNCHES
-        achieved = (ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES) / t_launch
-        # CEM downsample-consistency of the timed output (interior) with the HIP downsampler
+    traffic, traffic_src = newest_pmc(precision) if BATCH == 32 else (None, None)
+    conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]      # generator span per step (ms)
+    t_launch = conv_ms * 1e-3 / N_CONV_LAUNCHES
+    achieved = (ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES) / t_launch
+    # CEM downsample-consistency of the timed output (interior) with the HIP downsampler
+    with torch.no_grad():
+        d = G.DownscaleOP(y)
+    m = int(cem.invalidity_margins_LR)
+    cons = float(((d - x)[:, :, m:-m, m:-m] ** 2).mean().sqrt())
+    terms = MFMA_TERMS.get(precision, 1)
+    out = {
+        'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[precision], 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
+                   'arithmetic': ARITHMETIC[precision], 'global_batch': BATCH * world,
+                   'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
+        'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],
+        'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
+                     # PMC traffic is NOT re-measured by this run (counters need rocprofv3): it is the committed summary of the same command
+                     'traffic': traffic, 'traffic_static': True, 'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
+                     'generator_ms_per_step': conv_ms,
+                     'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
+                     'mfma_bf16_issue_frac': terms * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
+                     # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
+                     'mfma_bf16_issue_frac_of_measured_1.79PF': terms * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
+        'cem_consistency_rmse_interior': cons,
+    }
+    if traffic:
+        out['roofline']['frac_physical_static'] = traffic / t_launch / HBM_PEAK      # bytes the mode really moves (static PMC figure) / measured time
+    gen_err = None
+    if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
+        cb, xs, ys, gen_ref = cpu_baseline(G, cem)      # gen_ref: the oracle's generator output on the padded frame
+        out['cpu_baseline'] = cb
         with torch.no_grad():
-            d = G.DownscaleOP(y)
-        m = int(cem.invalidity_margins_LR)
-        cons = float(((d - x)[:, :, m:-m, m:-m] ** 2).mean().sqrt())
-        out = {
-            'metric': 'HR pixels/sec (RRDB-23 x4, 128->512, bs32 per GPU, fwd + CEM)', 'value': value, 'unit': 'HR pixels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'split': 'bf16x3 (bf16 hi+lo operands, f32 accumulate)', 'mixed': 'f16 (residual stream stored as hi+lo planes, hi+lo main-path weights, f32 accumulate)',
-                                                                      'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: RRDB-23 x4 SR forward, batch 32 of 128x128 per GPU, fp32 I/O, CEM wrap (eval: G runs on 148x148)',
-                       'arithmetic': {'split': 'split-bf16 (bf16x3) MFMA operands, fp32 accumulate', 'bf16': 'bf16 MFMA operands, fp32 accumulate',
-                                      'f16': 'f16 MFMA operands, fp32 accumulate',
-                                      'f16x2': 'f16 weights x f16 hi+lo activations (2 MFMAs per product), fp32 accumulate',
-                                      'mixed': 'fp32 I/O; f16 MFMA operands, fp32 accumulate: residual stream stored as hi+lo (22-bit) planes; hi+lo weights x hi+lo '
-                                               'activations (3 MFMAs) in the 6 convs outside the dense blocks; one-plane weights x hi planes (1 MFMA) and '
-                                               'one-plane intermediates inside the dense blocks; parity vs the fp32 CPU oracle reported in this line'}[args.precision],
-                       'global_batch': BATCH * world, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (351 launches per forward, all instantiations)', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK, 'traffic': traffic,
-                         'traffic_source': os.path.basename(pmc[-1]) if traffic else None,
-                         'algorithmic_bytes_per_launch': ALGO_BYTES_PER_FWD / N_CONV_LAUNCHES, 'avg_launch_ms': t_launch * 1e3,
-                         'generator_ms_per_step': conv_ms,
-                         'mfma_fp32_equiv_tflops': FLOP_PER_FWD / (conv_ms * 1e-3) / 1e12,
-                         'mfma_bf16_issue_frac': {'split': 3, 'f16x2': 2, 'mixed': 1.16}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 2.5e15,
-                         # sustained dense bf16 MFMA rate measured on this part with random operands (power-limited clock, profiles/microbench/mfma_peak.hip)
-                         'mfma_bf16_issue_frac_of_measured_1.79PF': {'split': 3, 'f16x2': 2, 'mixed': 1.16}.get(args.precision, 1) * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
-            'cem_consistency_rmse_interior': cons,
-        }
-        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
-            cb, xs, ys, gen_ref = cpu_baseline(G, cem)      # gen_ref: the oracle's generator output on the padded frame
-            out['cpu_baseline'] = cb
-            with torch.no_grad():
-                yg = G(xs.to(dev)).cpu()
-            out['rel_l2_vs_cpu_oracle'] = float((yg - ys).norm() / ys.norm())
-            out['rel_max_vs_cpu_oracle'] = float((yg - ys).abs().max() / ys.abs().max())
-            net = G.generated_image_model
+            yg = G(xs.to(dev)).cpu()
+        out['rel_l2_vs_cpu_oracle'] = float((yg - ys).norm() / ys.norm())
+        out['rel_max_vs_cpu_oracle'] = float((yg - ys).abs().max() / ys.abs().max())
 
-            def gen_err(rel_max=False):
-                with torch.no_grad():
-                    gg = net(xs.to(dev), pad=MARGIN_LR).cpu()
-                if rel_max:
-                    return float((gg - gen_ref).abs().max() / gen_ref.abs().max())
-                return float((gg - gen_ref).norm() / gen_ref.norm())
-            out['generator_rel_l2_vs_cpu_oracle'] = gen_err()       # the generator alone (the CEM output above is dominated by the LR content)
-            out['generator_rel_max_vs_cpu_oracle'] = gen_err(True)
-            if args.precision == 'mixed' and not args.no_alt_precision:
-                # beside the headline: the same workload in 'split' (bf16 hi+lo operands everywhere, 3 MFMAs per product — the universal
-                # fp32-class path that training uses), with its own parity figure
-                net.set_precision('split')
-                for _ in range(2):
-                    step()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                sync()
-                dta = time.perf_counter() - t0
-                out['alt_precision'] = {'mode': 'split', 'ms_per_step': dta / args.steps * 1e3, 'value': hr_px * args.steps / dta, 'unit': 'HR pixels/s',
-                                        'roofline_frac': ALGO_BYTES_PER_FWD / (dta / args.steps) / HBM_PEAK,
-                                        'generator_rel_l2_vs_cpu_oracle': gen_err(), 'generator_rel_max_vs_cpu_oracle': gen_err(True),
-                                        'note': 'bf16 hi+lo weights x bf16 hi+lo activations in every layer (3 MFMAs per product)'}
-                net.set_precision(args.precision)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        def gen_err(rel_max=False):
+            with torch.no_grad():
+                gg = net(xs.to(dev), pad=MARGIN_LR).cpu()
+            if rel_max:
+                return float((gg - gen_ref).abs().max() / gen_ref.abs().max())
+            return float((gg - gen_ref).norm() / gen_ref.norm())
+        out['generator_rel_l2_vs_cpu_oracle'] = gen_err()       # the generator alone (the CEM output above is dominated by the LR content)
+        out['generator_rel_max_vs_cpu_oracle'] = gen_err(True)
+    if precision == 'split' and not args.no_alt_precision:
+        # beside the headline: the same workload in 'mixed' (fp16, one MFMA per product inside the dense blocks — narrower than fp32-class
+        # by the letter), with its own parity figure and BOTH roofline fractions
+        net.set_precision('mixed')
+        for _ in range(2):
+            step()
+        dta, _, _ = timed(False)
+        tm, tm_src = newest_pmc('mixed') if BATCH == 32 else (None, None)
+        alt = {'mode': 'mixed', 'dtype': DTYPE['mixed'], 'ms_per_step': dta / args.steps * 1e3, 'value': world * hr_px * args.steps / dta, 'unit': 'HR pixels/s',
+               'roofline_frac_fp32_equiv_bytes': ALGO_BYTES_PER_FWD / (dta / args.steps) / HBM_PEAK,
+               'roofline_frac_physical_static': (tm * N_CONV_LAUNCHES / (dta / args.steps) / HBM_PEAK) if tm else None,
+               'physical_bytes_per_forward_static': tm * N_CONV_LAUNCHES if tm else None, 'traffic_source': tm_src,
+               'note': ARITHMETIC['mixed'] + '; whole-step time (the headline roofline uses the generator span)'}
+        if gen_err is not None:
+            alt['generator_rel_l2_vs_cpu_oracle'] = gen_err()
+            alt['generator_rel_max_vs_cpu_oracle'] = gen_err(True)
+        out['alt_precision'] = alt
+        net.set_precision(precision)
+    return out
+
+
+def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
+    """configs[2] at its per-GPU shape: SRRaGANModel.optimize_parameters() (G forward/backward through the HIP path, discriminator
+    + WGAN-GP on stock MIOpen kernels, two Adam steps) on 32 crops of 52x52 (HR 208x208, latent 3) per GPU; G and D gradients are
+    all-reduced over RCCL when N > 1."""
+    import contextlib
+    import io
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_paths
+    import models
+    from esr_hip import dist as D
+    precision = args.precision or 'bf16'
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.create_model(bench_paths.make_opt(True, with_D=True))
+    if precision != 'split':
+        model.netG.generated_image_model.set_precision(precision)
+    B = 32 if args.batch == BATCH else args.batch
+    g = torch.Generator().manual_seed(2000 + rank)
+    data = {'LR': torch.rand(B, 3, 52, 52, generator=g).to(dev), 'HR': torch.rand(B, 3, 208, 208, generator=g).to(dev),
+            'Z': (torch.rand(B, 3, 208, 208, generator=g) * 2 - 1).to(dev)}
+    for _ in range(args.warmup):
+        model.feed_data(data); model.optimize_parameters()
+    model.timing = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.feed_data(data); model.optimize_parameters()
+    sync()
+    dt, per_rank = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return None
+    log = model.get_current_log()
+    split_ms = {k: v / args.steps for k, v in getattr(model, 'timing', {}).items()}
+    flop_g = 3 * 32 * 52 * 52 * 2 * 18316944 * (B / 32)        # fwd + dgrad + wgrad of G (lat 3), SURVEY §8(d)
+    return {'metric': 'LR crops/sec (RRDB-23 x4 lat 3 G + Discriminator_VGG_128 WGAN-GP step, 32 x 52x52 per GPU)', 'value': world * B * args.steps / dt, 'unit': 'LR crops/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator fp32 on MIOpen', 'data': 'synthetic',
+            'config': {'workload': 'configs[2] per-GPU shape: SRRaGANModel.optimize_parameters(), G+D step, %d crops of 52x52 (HR 208x208, latent 3) per GPU' % B,
+                       'global_batch': B * world, 'parallelism': 'dp%d (G and D gradients all-reduced over RCCL)' % world},
+            'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],
+            'phases_ms': split_ms, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
+            'roofline': {'bound': 'mfma', 'kernel': 'generator convs (forward + data gradient + weight gradient)', 'achieved': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 1e12,
+                         'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 2.5e15, 'traffic': None,
+                         'note': 'MFMA issue rate of the generator over the WHOLE step time (D, optimizers and all-reduce included in the denominator)'}}
 
 
 if __name__ == '__main__':

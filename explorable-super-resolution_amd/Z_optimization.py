@@ -94,8 +94,9 @@ class Z_optimizer():
         self.image_mask = None
         if not self.model_training and 'fake_H' in model.__dict__:
             self.initial_output = model.Output_Batch(within_0_1=True).detach()
-            # the reference point is the GLOBAL batch's first image: rank 0's value is shared with every shard
-            self.initial_STD = esr_dist.broadcast_tensor(self.Masked_STD(first_image_only=True).detach())
+            # every sample's own initial STD (the reference's first_image_only flag is honoured by its 'local' objectives only,
+            # Z_optimization.py:617-627): per-sample reference points, so sharding the batch over ranks needs no exchange
+            self.initial_STD = self.Masked_STD(first_image_only=True).detach()
         if 'STD' in objective and any(p in objective for p in ['increase', 'decrease']):
             STD_CHANGE_FACTOR = 1.05
             self.desired_STD = 1 * self.initial_STD
@@ -112,13 +113,11 @@ class Z_optimizer():
         self.max_iters = max_iters
         self.random_Z_inits = 'all' if (random_Z_inits or self.model_training) else False
         self.HR_unpadder = HR_unpadder
-        self.STD_PRESERVING_WEIGHT = 20
+        self.STD_PRESERVING_WEIGHT = 100 if 'TV' in objective else 20      # reference Z_optimization.py:508-509 (TV), :471 (others)
 
     def Masked_STD(self, first_image_only=False):
-        out = self.model.Output_Batch(within_0_1=True)
-        if first_image_only:
-            out = out[:1]
-        return torch.std(out, dim=(1, 2, 3)).view(1, -1)
+        # whole-image objectives: the STD of EVERY sample, [1, B], whatever the flag says (as the reference, see __init__)
+        return torch.std(self.model.Output_Batch(within_0_1=True), dim=(1, 2, 3)).view(1, -1)
 
     def feed_data(self, data):
         self.data = data

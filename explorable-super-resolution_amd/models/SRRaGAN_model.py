@@ -1,14 +1,16 @@
-"""SRRaGANModel — the generator-side counterpart of the reference's model wrapper (codes/models/SRRaGAN_model.py): the calls the
-drivers (train.py / test.py / GUI.py) and Z_optimizer make around the RRDB+CEM hot path, with the same method names, attributes and
-input packing.  What is reproduced:
+"""SRRaGANModel — counterpart of the reference's live model wrapper (codes/models/SRRaGAN_model.py): the calls the drivers
+(train.py / test.py / GUI.py) and Z_optimizer make around the RRDB+CEM hot path, with the same method names, attributes and input
+packing.  What is reproduced:
   * Prepare_Input: [Z viewed as B x (lat*sf^2) x h x w | LR] (raw view, :230-236); GetLatent; feed_data's Z sampling (:244-278)
   * test(): eval mode (CEM pre-padding) with or without autograd (:523-531); Output_Batch
-  * optimize_parameters(): the GENERATOR step — forward in train mode (no pre-pad), HR_unpadder crop of targets, pixel (L1/L2),
-    range and latent-consistency-free losses, gradient accumulation, Adam — with the gradients all-reduced over RCCL when
-    several ranks run (one process per GPU) instead of nn.DataParallel
-  * save / load through BaseModel (positional checkpoint loading)
-Out of scope for the hot path and therefore refused loudly: discriminator / GAN / VGG-feature losses (define_D / define_F),
-the D-verification and LR-rollback heuristics, validation image dumps.
+  * optimize_parameters() (:280-521): gradient accumulation, the D / G step gating (D_init_iters, D_update_ratio, D_verification
+    'current' / 'past'), the discriminator step (relativistic or plain; vanilla / lsgan / wgan-gp with the gradient penalty's double
+    backward through D), the generator step (pixel, range, GAN and optimal-Z reference losses; the optimal-Z dual step runs
+    Z_optimizer through the frozen generator), Adam for both — with G's and D's gradients all-reduced over RCCL when several ranks
+    run (one process per GPU) instead of nn.DataParallel
+  * perform_validation / save_log / save / load (G, D, optimizers, logs.npz) through BaseModel (positional checkpoint loading)
+Not reproduced, and refused loudly: the VGG-feature loss (define_F needs torchvision), FilterLoss (train.latent_weight), the
+'convergence' D-verification and the LR-rollback heuristics (:592-632), D_update_ratio given as a controller range.
 """
 import os
 from collections import OrderedDict
@@ -20,29 +22,8 @@ import torch.nn as nn
 import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
+from models.modules.loss import CreateRangeLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
-
-
-def Latent_channels_desc_2_num_channels(latent_channels_desc):
-    """Number of Z channels for a `latent_channels` option (reference models/modules/loss.py:16-25)."""
-    if latent_channels_desc is None or latent_channels_desc == 0:
-        return 0
-    if isinstance(latent_channels_desc, int):
-        return latent_channels_desc
-    if 'structure_tensor' in latent_channels_desc:
-        return 3
-    if latent_channels_desc in ('STD_1dir', 'STD_directional'):
-        return 2
-    raise NotImplementedError('Unknown latent channel setting %s' % latent_channels_desc)
-
-
-def CreateRangeLoss(legit_range):
-    """Penalty on values outside the legit range (reference models/modules/loss.py:248-258)."""
-    lo, hi = float(legit_range[0]), float(legit_range[1])
-
-    def RangeLoss(x):
-        return torch.max(torch.max(x - hi, lo - x), torch.zeros_like(x)).mean()
-    return RangeLoss
 
 
 class SRRaGANModel(BaseModel):
@@ -75,19 +56,44 @@ class SRRaGANModel(BaseModel):
         self.netG = networks.define_G(opt, CEM=self.CEM_net, num_latent_channels=self.num_latent_channels)
         self.netG.to(self.device)
         esr_dist.broadcast_parameters(self.netG)          # every rank starts from rank 0's weights
-        logs_2_keep = ['l_g_pix', 'l_g_range', 'psnr_val', 'LR_decrease']
+        logs_2_keep = ['l_g_pix', 'l_g_fea', 'l_g_range', 'l_g_gan', 'l_d_real', 'l_d_fake', 'D_loss_STD', 'l_d_real_fake', 'D_real', 'D_fake',
+                       'D_logits_diff', 'psnr_val', 'D_update_ratio', 'LR_decrease', 'Correctly_distinguished', 'l_d_gp', 'per_pix_STD_val',
+                       'l_g_optimalZ', 'Z_effect']
         self._log_dict = OrderedDict(zip(logs_2_keep, [[] for _ in logs_2_keep]))
-        self._pending_logs = []          # (key, step, [loss tensors of the accumulation steps]): read back lazily, see log_dict
+        self._pending_logs = []          # (key, step, [device scalars of the accumulation steps]): read back lazily, see log_dict
         self.D_exists = False
         self.generator_changed = True
+        self.generator_started_learning = False
+        self.optimalZ_loss_type = None
+        self.timing = None               # set to {} to accumulate per-phase GPU milliseconds of optimize_parameters (bench.py --workload c3)
         if self.is_train:
-            if train_opt['gan_weight'] is not None or train_opt['feature_weight'] is not None:
-                raise NotImplementedError('GAN / VGG-feature losses need define_D / define_F, which are outside the RRDB+CEM hot path '
-                                          '(SURVEY.md §8(f)); set train.gan_weight and train.feature_weight to null')
+            if train_opt['feature_weight'] is not None:
+                raise NotImplementedError('The VGG-feature loss needs define_F (torchvision), which is outside this build; set train.feature_weight to null')
+            if self.latent_input is not None and train_opt['latent_weight'] is not None:
+                raise NotImplementedError('FilterLoss (train.latent_weight) is not part of this build; set it to null')
+            if self.latent_input is not None and train_opt['optimalZ_loss_type'] is not None and train_opt['optimalZ_loss_weight'] is not None:
+                self.optimalZ_loss_type = train_opt['optimalZ_loss_type']
+            self.D_verification = train_opt['D_verification']
+            if self.D_verification not in ['current', 'past', None]:
+                raise NotImplementedError("train.D_verification = %r: 'current', 'past' or null" % (self.D_verification,))
+            self.D_verified = self.verified_D_saved = self.D_verification is None
+            net_D = opt['network_D'] or {}
+            self.relativistic_D = net_D.get('relativistic') is None or bool(net_D.get('relativistic'))
+            self.add_quantization_noise = bool(net_D.get('add_quantization_noise'))
             self.grad_accumulation_steps_G = train_opt['grad_accumulation_steps_G'] or 1
+            self.grad_accumulation_steps_D = train_opt['grad_accumulation_steps_D'] or self.grad_accumulation_steps_G
+            self.min_accumulation_steps = min(self.grad_accumulation_steps_G, self.grad_accumulation_steps_D)
             self.max_accumulation_steps = accumulation_steps_per_batch
-            self.decomposed_output = False
+            self.decomposed_output = bool(self.CEM_arch and net_D.get('decomposed_input'))
+            if self.decomposed_output:
+                raise NotImplementedError('network_D.decomposed_input: the reference supports it for PatchGAN only, which is outside this build')
             self.netG.train()
+            self.l_gan_w = train_opt['gan_weight']
+            self.D_exists = self.l_gan_w is not None
+            if self.D_exists:
+                self.netD = networks.define_D(opt, CEM=self.CEM_net).to(self.device)
+                esr_dist.broadcast_parameters(self.netD)
+                self.netD.train()
             self.cri_pix = None
             if train_opt['pixel_weight'] is not None:
                 l_pix_type = train_opt['pixel_criterion']
@@ -98,20 +104,57 @@ class SRRaGANModel(BaseModel):
                 else:
                     raise NotImplementedError('Loss type [{:s}] not recognized.'.format(l_pix_type))
                 self.l_pix_w = train_opt['pixel_weight']
+            self.cri_optimalZ = None
+            if self.optimalZ_loss_type is not None:
+                from Z_optimization import Z_optimizer
+                if self.optimalZ_loss_type not in ('l1', 'l2'):
+                    raise NotImplementedError("train.optimalZ_loss_type = %r: 'l1' or 'l2' ('hist' needs SoftHistogramLoss)" % self.optimalZ_loss_type)
+                self.l_g_optimalZ_w = train_opt['optimalZ_loss_weight']
+                z_side = int(opt['datasets']['train']['patch_size'] / (opt['scale'] / self.Z_size_factor))
+                self.Z_optimizer = Z_optimizer(objective=self.optimalZ_loss_type, Z_size=2 * [z_side], model=self, Z_range=1, max_iters=10, initial_LR=1,
+                                               batch_size=opt['datasets']['train']['batch_size'], HR_unpadder=self.CEM_net.HR_unpadder)
+                self.cri_optimalZ = (nn.MSELoss() if self.optimalZ_loss_type == 'l2' else nn.L1Loss()).to(self.device)
+            self.cri_fea = None
             self.cri_range = None
-            if train_opt['range_weight'] is not None and train_opt['range_weight'] > 0:
+            if train_opt['range_weight'] is not None:
                 self.cri_range = CreateRangeLoss(opt['range'])
                 self.l_range_w = train_opt['range_weight']
+            self.GD_update_controller = None
+            self.cri_gan, self.D_init_iters, self.global_D_update_ratio = None, 0, 1
+            if self.D_exists:
+                self.cri_gan = GANLoss(train_opt['gan_type'], 1.0, 0.0).to(self.device)
+                self.global_D_update_ratio = train_opt['D_update_ratio'] if train_opt['D_update_ratio'] is not None else 1
+                if isinstance(self.global_D_update_ratio, list):
+                    raise NotImplementedError('train.D_update_ratio as a controller range (utils.util.G_D_updates_controller) is not part of this build; pass a number')
+                self.D_init_iters = train_opt['D_init_iters'] if train_opt['D_init_iters'] else 0
+                if train_opt['gan_type'] == 'wgan-gp':
+                    self.cri_gp = GradientPenaltyLoss(device=self.device).to(self.device)
+                    self.l_gp_w = train_opt['gp_weight']
             wd_G = train_opt['weight_decay_G'] if train_opt['weight_decay_G'] else 0
             optim_params = [v for k, v in self.netG.named_parameters() if v.requires_grad]
-            self.optimizer_G = torch.optim.Adam(optim_params, lr=train_opt['lr_G'], weight_decay=wd_G, betas=(train_opt['beta1_G'] or 0.9, 0.999))
+            self.lr_G, self.lr_D = train_opt['lr_G'], train_opt['lr_D']
+            self.optimizer_G = torch.optim.Adam(optim_params, lr=self.lr_G, weight_decay=wd_G,
+                                                betas=(train_opt['beta1_G'] or 0.9, train_opt['beta2_G'] if train_opt['beta2_G'] is not None else 0.999))
             self.optimizers.append(self.optimizer_G)
-            self.lr_G = train_opt['lr_G']
+            self.grad_reducer = esr_dist.GradBucketAllReducer(optim_params)
+            if self.D_exists:
+                wd_D = train_opt['weight_decay_D'] if train_opt['weight_decay_D'] else 0
+                self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=self.lr_D, weight_decay=wd_D,
+                                                    betas=(train_opt['beta1_D'] or 0.9, train_opt['beta2_D'] if train_opt['beta2_D'] is not None else 0.999))
+                self.optimizers.append(self.optimizer_D)
+                self.grad_reducer_D = esr_dist.GradBucketAllReducer(list(self.netD.parameters()))
             if train_opt['lr_scheme'] == 'MultiStepLR':
                 for optimizer in self.optimizers:
                     self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(optimizer, train_opt['lr_steps'], train_opt['lr_gamma']))
-            self.grad_reducer = esr_dist.GradBucketAllReducer(optim_params)
+            elif train_opt['lr_scheme'] is not None:
+                raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
+            self.generator_step = False
             self.gradient_step_num = 0
+        elif init_Dnet:
+            self.netD = networks.define_D(opt, CEM=self.CEM_net).to(self.device)
+            self.netD.eval()
+        if init_Fnet:
+            raise NotImplementedError('init_Fnet: the VGG feature extractor needs torchvision')
         self.load()
         print('---------- Model initialized ------------------')
 
@@ -168,46 +211,168 @@ class SRRaGANModel(BaseModel):
         self.output_image = 1 * self.fake_H
         self.netG.train()
 
-    # ------------------------------------------------------------------ generator step (reference :280-333,418-499, G side)
+    # ------------------------------------------------------------------ training step (reference :280-521)
+    def _draw_interp_points(self, batch_size):
+        """Interpolation points of the WGAN-GP penalty, one per image, U[0,1) (reference :364-367).  A method so that parity tests can
+        replay the reference's draws."""
+        return torch.rand(batch_size, 1, 1, 1, device=self.device)
+
+    def _tick(self, name):
+        """Phase timer (only when self.timing is a dict): GPU time since the previous tick is charged to `name`."""
+        if self.timing is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if self._last_ev is not None:
+            self._phase_evs.append((name, self._last_ev, ev))
+        self._last_ev = ev
+
     def optimize_parameters(self):
+        train_opt = self.opt['train']
+        acc_G, acc_D = self.grad_accumulation_steps_G, self.grad_accumulation_steps_D
         self.gradient_step_num = self.step // max(self.max_accumulation_steps, 1)
-        first_grad_accumulation_step_G = self.step % self.grad_accumulation_steps_G == 0
-        last_grad_accumulation_step_G = self.step % self.grad_accumulation_steps_G == (self.grad_accumulation_steps_G - 1)
-        if first_grad_accumulation_step_G:
-            self.log_dict                                   # read back the previous step's loss values (already computed: no stall)
-            self.optimizer_G.zero_grad()
-            self.l_g_pix_grad_step, self.l_g_range_grad_step = [], []
-        var_H = self.var_H
-        if self.CEM_net is not None and self.CEM_arch and var_H.size(2) > 2 * int(self.CEM_net.invalidity_margins_HR):
-            var_H = self.CEM_net.HR_unpadder(self.var_H)     # losses ignore the frame the CEM cannot constrain (reference :319-320)
-        self.fake_H = self.netG(self.model_input)            # train mode: no pre-padding
-        fake_H = self.fake_H
-        if self.CEM_net is not None and self.CEM_arch and fake_H.size(2) > 2 * int(self.CEM_net.invalidity_margins_HR):
-            fake_H = self.CEM_net.HR_unpadder(fake_H)
-        l_g_total = 0
-        if self.cri_pix is not None:
-            l_g_pix = self.cri_pix(fake_H, var_H)
-            l_g_total = l_g_total + self.l_pix_w * l_g_pix / self.grad_accumulation_steps_G
-        if self.cri_range is not None:
-            l_g_range = self.cri_range(fake_H)
-            l_g_total = l_g_total + self.l_range_w * l_g_range / self.grad_accumulation_steps_G
-        l_g_total.backward()
-        # The reference reads the loss values back right here (.item(), :483-493): a host synchronisation per step, during which the GPU
-        # drains and then idles while the host prepares the next step.  Here they stay on the device and are read when somebody looks at
-        # the log (log_dict / get_current_log) or when the next step starts — by then the kernels that produced them finished long ago.
-        if self.cri_pix is not None:
-            self.l_g_pix_grad_step.append(l_g_pix.detach())
-        if self.cri_range is not None:
-            self.l_g_range_grad_step.append(l_g_range.detach())
-        if last_grad_accumulation_step_G:
-            self.grad_reducer()                               # RCCL all-reduce (mean) of the G gradients: the one exchange step
-            self.optimizer_G.step()
-            self.generator_changed = True
-            if self.cri_pix is not None:
-                self._pending_logs.append(('l_g_pix', self.gradient_step_num, self.l_g_pix_grad_step))
-            if self.cri_range is not None:
-                self._pending_logs.append(('l_g_range', self.gradient_step_num, self.l_g_range_grad_step))
+        first_acc_G, last_acc_G = self.step % acc_G == 0, self.step % acc_G == acc_G - 1
+        first_acc_D, last_acc_D = self.step % acc_D == 0, self.step % acc_D == acc_D - 1
+        self._last_ev, self._phase_evs = None, []
+        self._tick('start')
+        # ---- which networks step this time (:287-306)
+        if first_acc_G:
+            self.generator_step = self.gradient_step_num > self.D_init_iters
+            if self.generator_step:
+                self.generator_step = self.gradient_step_num % max(1, self.global_D_update_ratio) == 0
+                # with a larger D batch, G steps on the last accumulation steps of D only
+                self.generator_step = self.generator_step and self.step % acc_D >= acc_D - acc_G
+        if self.D_exists and first_acc_D:
+            self.discriminator_step = self.gradient_step_num >= -self.D_init_iters
+            if self.discriminator_step and self.verified_D_saved:
+                self.discriminator_step = self.gradient_step_num % max(1, np.ceil(1 / self.global_D_update_ratio)) == 0
+        G_grads_retained = first_acc_D or self.generator_step
+        self.Set_Require_Grad_Status(self.netG, bool(G_grads_retained))
+        dual_steps = int(self.optimalZ_loss_type is not None and self.generator_started_learning) + 1
+        for dual in range(dual_steps):
+            optimized_Z_step = dual == dual_steps - 2     # first the optimised-Z pass (its Z search needs no G gradients), then the assigned Z
+            first_dual, last_dual = dual == 0, dual == dual_steps - 1
+            if self.CEM_net is not None and first_dual:
+                # the losses and the critic ignore the frame the CEM cannot constrain (:319-320)
+                self.var_H, self.var_ref = self.CEM_net.HR_unpadder(self.var_H), self.CEM_net.HR_unpadder(self.var_ref)
+            if first_dual:
+                static_Z = self.GetLatent() if self.latent_input is not None else None
+            if optimized_Z_step:
+                self.Z_optimizer.feed_data({'LR': self.var_L, 'desired': self.var_H})
+                self.Z_optimizer.optimize()               # leaves self.fake_H = G(optimal Z) with G's graph
+            else:
+                self.Prepare_Input(LR_image=self.var_L, latent_input=static_Z)
+                self.fake_H = self.netG(self.model_input)     # train mode: no pre-padding
+            if self.CEM_net is not None:
+                self.fake_H = self.CEM_net.HR_unpadder(self.fake_H)
+            self._tick('G_forward')
+            # ---- D step (:340-414)
+            if not self.D_exists:
+                self.generator_step = self.gradient_step_num > 0       # one idle first iteration, as the reference (initial validation)
+            elif self.discriminator_step:
+                self.Set_Require_Grad_Status(self.netD, True)
+                self.Set_Require_Grad_Status(self.netG, False)
+                if first_acc_D and first_dual:
+                    self.optimizer_D.zero_grad()
+                    self._d_acc = {k: [] for k in ('l_d_real', 'l_d_fake', 'D_real', 'D_fake', 'D_logits_diff')}
+                if first_dual:
+                    pred_d_real = self.netD(self.var_ref)
+                pred_d_fake = self.netD(self.fake_H.detach())
+                if self.relativistic_D:
+                    assert train_opt['hinge_threshold'] is None, 'Unsupported yet, should think whether it reuires special adaptation of hinge loss'
+                    l_d_real = self.cri_gan(pred_d_real - torch.mean(pred_d_fake), True)
+                    l_d_fake = self.cri_gan(pred_d_fake - torch.mean(pred_d_real), False)
+                else:
+                    if first_dual:
+                        l_d_real = 2 * self.cri_gan(pred_d_real, True, train_opt['hinge_threshold'])
+                    l_d_fake = 2 * self.cri_gan(pred_d_fake, False, train_opt['hinge_threshold'])
+                l_d_total = (l_d_real + l_d_fake) / 2
+                if train_opt['gan_type'] == 'wgan-gp':
+                    pt = self._draw_interp_points(self.var_ref.size(0))
+                    interp = (pt * self.fake_H.detach() + (1 - pt) * self.var_ref).requires_grad_(True)
+                    l_d_gp = self.l_gp_w * self.cri_gp(interp, self.netD(interp))
+                    l_d_total = l_d_total + l_d_gp
+                logits_diff = torch.mean(pred_d_real.detach() - pred_d_fake.detach(), dim=list(range(1, pred_d_real.dim())))
+                self._d_acc['l_d_real'].append(l_d_real.detach()); self._d_acc['l_d_fake'].append(l_d_fake.detach())
+                self._d_acc['D_real'].append(pred_d_real.detach().mean()); self._d_acc['D_fake'].append(pred_d_fake.detach().mean())
+                self._d_acc['D_logits_diff'].append(logits_diff)
+                if first_acc_D and first_dual and self.generator_step and self.D_verification == 'past' and (train_opt['D_valid_Steps_4_G_update'] or 0) > 0:
+                    n = train_opt['D_valid_Steps_4_G_update']
+                    log = self.log_dict
+                    self.generator_step = len(log['D_logits_diff']) >= n and \
+                        all(v[1] > np.log(train_opt['min_D_prob_ratio_4_G']) for v in log['D_logits_diff'][-n:]) and \
+                        all(v[1] > train_opt['min_mean_D_correct'] for v in log['Correctly_distinguished'][-n:])
+                if self.D_verification == 'current' and self.generator_step:
+                    cur = logits_diff.cpu().numpy()         # a host read, as in the reference: this mode gates G on the current batch
+                    self.generator_step = bool(np.all(cur > 0) and np.mean(cur) > np.log(train_opt['min_D_prob_ratio_4_G']))
+                if G_grads_retained and not self.generator_step:
+                    self.fake_H = self.fake_H.detach()     # nobody will back-propagate into G this time
+                (l_d_total / (acc_D * dual_steps)).backward()
+                if last_acc_D and last_dual:
+                    self.grad_reducer_D()                  # RCCL all-reduce (mean) of the D gradients
+                    self.optimizer_D.step()
+                    st = self.gradient_step_num
+                    for k in ('l_d_real', 'l_d_fake', 'D_real', 'D_fake'):
+                        self._pending_logs.append((k, st, self._d_acc[k]))
+                    self._pending_logs.append(('l_d_real_fake', st, [torch.stack(self._d_acc['l_d_real']).mean() + torch.stack(self._d_acc['l_d_fake']).mean()]))
+                    if train_opt['gan_type'] == 'wgan-gp':
+                        self._pending_logs.append(('l_d_gp', st, [l_d_gp.detach()]))
+                    diffs = torch.cat([d.reshape(-1) for d in self._d_acc['D_logits_diff']])
+                    self._pending_logs.append(('D_logits_diff', st, [diffs.mean()]))
+                    self._pending_logs.append(('Correctly_distinguished', st, [(diffs > 0).float().mean()]))
+                self._tick('D_step')
+            # ---- G step (:418-499)
+            if self.generator_step:
+                self.generator_started_learning = True
+                if self.D_exists:
+                    self.Set_Require_Grad_Status(self.netD, False)
+                self.Set_Require_Grad_Status(self.netG, True)
+                if first_acc_G and first_dual:
+                    self.optimizer_G.zero_grad()
+                    self._g_acc = {k: [] for k in ('l_g_pix', 'l_g_range', 'l_g_gan', 'l_g_optimalZ')}
+                scale = acc_G * dual_steps
+                l_g_total = 0
+                if self.cri_pix is not None:
+                    if train_opt['pixel_domain'] == 'LR':
+                        raise NotImplementedError("train.pixel_domain = 'LR'")
+                    l_g_pix = self.cri_pix(self.fake_H, self.var_H)
+                    l_g_total = l_g_total + self.l_pix_w * l_g_pix / scale
+                    self._g_acc['l_g_pix'].append(l_g_pix.detach())
+                if self.cri_range is not None:
+                    l_g_range = self.cri_range(self.fake_H)
+                    l_g_total = l_g_total + self.l_range_w * l_g_range / scale
+                    self._g_acc['l_g_range'].append(l_g_range.detach())
+                if self.cri_optimalZ is not None and first_dual:
+                    l_g_optimalZ = self.cri_optimalZ(self.fake_H, self.var_H)
+                    l_g_total = l_g_total + self.l_g_optimalZ_w * l_g_optimalZ / acc_G
+                    self._g_acc['l_g_optimalZ'].append(l_g_optimalZ.detach())
+                if self.D_exists:
+                    pred_g_fake = self.netD(self.fake_H)
+                    if self.relativistic_D:
+                        pred_d_real = self.netD(self.var_ref).detach()
+                        l_g_gan = self.l_gan_w * (self.cri_gan(pred_d_real - torch.mean(pred_g_fake), False) +
+                                                  self.cri_gan(pred_g_fake - torch.mean(pred_d_real), True)) / 2 / scale
+                    else:
+                        l_g_gan = self.l_gan_w * self.cri_gan(pred_g_fake, True) / scale
+                    l_g_total = l_g_total + l_g_gan
+                    self._g_acc['l_g_gan'].append(l_g_gan.detach())
+                l_g_total.backward()
+                self._tick('G_losses_and_backward')
+                # The reference reads every loss value back right here (.item(), :483-493): a host synchronisation per step.  Here they
+                # stay on the device and are read when somebody looks at the log (log_dict / get_current_log).
+                if last_acc_G and last_dual:
+                    self.grad_reducer()                    # RCCL all-reduce (mean) of the G gradients: the one exchange step
+                    self.optimizer_G.step()
+                    self.generator_changed = True
+                    for k, v in self._g_acc.items():
+                        if v:
+                            self._pending_logs.append((k, self.gradient_step_num, v))
+                    self._tick('G_allreduce_and_Adam')
         self.step += 1
+        if self.timing is not None:
+            torch.cuda.synchronize()
+            for name, e0, e1 in self._phase_evs:
+                self.timing[name] = self.timing.get(name, 0.0) + e0.elapsed_time(e1)
 
     # ------------------------------------------------------------------ bookkeeping
     @property
@@ -234,23 +399,114 @@ class SRRaGANModel(BaseModel):
     def print_network(self):
         s, n = self.get_network_description(self.netG)
         print('Number of parameters in G: {:,d}'.format(n))
+        if self.is_train and self.D_exists:
+            s, n = self.get_network_description(self.netD)
+            print('Number of parameters in D: {:,d}'.format(n))
 
-    def load(self, max_step=None, resume_train=None):
-        load_path_G = self.opt['path']['pretrain_model_G'] if self.opt['path'] else None
-        if resume_train is None:
-            resume_train = self.is_train and self.opt['train']['resume']
-        if resume_train and os.path.isdir(self.save_dir):
-            steps = [int(f.split('_')[0]) for f in os.listdir(self.save_dir) if f.endswith('_G.pth') and f.split('_')[0].isdigit()]
+    # ------------------------------------------------------------------ validation (reference :533-590)
+    def perform_validation(self, data_loader, cur_Z, print_rlt, first_eval, save_images):
+        """PSNR of the validation set for the latent value `cur_Z` (reference :533-590); print_rlt['psnr'] is incremented by the
+        average.  Returns the SR images as float32 HWC arrays in [0, 255].  The reference also writes image collages through OpenCV
+        when save_images is set; here the collage is kept in self.im_collages and written as .npy (no image codec in this build)."""
+        psnrs, sr_images, rows = [], [], []
+        for val_data in data_loader:
+            val_data = dict(val_data)
+            val_data['Z'] = cur_Z
+            self.feed_data(val_data)
+            self.test()
+            visuals = self.get_current_visuals()
+            sr = 255 * np.clip(visuals['SR'].numpy(), 0, 1).transpose(1, 2, 0).astype(np.float32)
+            gt = 255 * np.clip(visuals['HR'].numpy(), 0, 1).transpose(1, 2, 0).astype(np.float32)
+            sr_images.append(sr)
+            mse = float(np.mean((sr.astype(np.float64) - gt.astype(np.float64)) ** 2))
+            psnrs.append(float('inf') if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse)))
+            if save_images:
+                rows.append(np.clip(sr, 0, 255).astype(np.uint8))
+        avg_psnr = float(np.mean(psnrs))
+        if save_images:
+            self.generator_changed = False
+            side = min(min(r.shape[:2]) for r in rows)
+            collage = np.concatenate([r[:side, :side] for r in rows], 1)
+            if not hasattr(self, 'im_collages'):
+                self.im_collages = []
+            self.im_collages.append(collage)
+            val_dir = self.opt['path']['val_images']
+            if val_dir and esr_dist.rank() == 0:
+                os.makedirs(val_dir, exist_ok=True)
+                np.save(os.path.join(val_dir, '{:d}_{}PSNR{:.3f}.npy'.format(self.gradient_step_num, ('Z' + str(cur_Z)) if self.latent_input else '', avg_psnr)), collage)
+        print_rlt['psnr'] += avg_psnr
+        return sr_images
+
+    # ------------------------------------------------------------------ logs.npz (reference :644-675)
+    ADDITIONALLY_SAVED_ATTRIBUTES = ['D_verified', 'verified_D_saved', 'lr_G', 'lr_D']
+
+    def save_log(self):
+        if esr_dist.rank() != 0:
+            return
+        to_save = {k: np.array(v, dtype=np.float64).reshape(-1, 2) for k, v in self.log_dict.items()}
+        for attr in self.ADDITIONALLY_SAVED_ATTRIBUTES:
+            if attr in self.__dict__ and getattr(self, attr) is not None:
+                to_save[attr] = getattr(self, attr)
+        os.makedirs(self.log_path, exist_ok=True)
+        np.savez(os.path.join(self.log_path, 'logs.npz'), **to_save)
+
+    def load_log(self, max_step=None):
+        loaded = np.load(os.path.join(self.log_path, 'logs.npz'))
+        self.log_dict                                     # flush pending values before replacing the history
+        for key in list(self._log_dict):
+            self._log_dict[key] = []
+        for key in loaded.files:
+            if key in self.ADDITIONALLY_SAVED_ATTRIBUTES:
+                v = loaded[key]
+                setattr(self, key, v.item() if v.ndim == 0 else v)
+                continue
+            pairs = [(int(p[0]), float(p[1])) for p in loaded[key]]
             if max_step is not None:
-                steps = [s for s in steps if s <= max_step]
-            if steps:
-                load_path_G = os.path.join(self.save_dir, '%d_G.pth' % max(steps))
-                self.step = max(steps) * max(getattr(self, 'max_accumulation_steps', 1), 1)
+                pairs = [p for p in pairs if p[0] <= max_step]
+            self._log_dict[key] = pairs
+
+    # ------------------------------------------------------------------ checkpoints (reference :732-776)
+    def load(self, max_step=None, resume_train=None):
+        path_opt = self.opt['path'] or {}
+        resume = resume_train if resume_train is not None else (self.is_train and bool(self.opt['train']['resume']))
+        own = sorted(int(f.split('_')[0]) for f in (os.listdir(self.save_dir) if os.path.isdir(self.save_dir) else [])
+                     if f.endswith('_G.pth') and f.split('_')[0].isdigit())
+        if max_step is not None:
+            own = [st for st in own if st <= max_step]
+        load_own = bool(own) and (max_step is not None or resume or not self.is_train)
+        if load_own:
+            st = own[-1]
+            path_G = os.path.join(self.save_dir, '%d_G.pth' % st)
+            path_D = os.path.join(self.save_dir, '%d_D.pth' % st)
+            if self.is_train:
+                self.step = (st + 1) * max(self.max_accumulation_steps, 1)
+                print('Resuming training with model for G [{:s}] ...'.format(path_G))
+                self.load_network(path_G, self.netG, optimizer=self.optimizer_G)
+                if os.path.exists(os.path.join(self.log_path or '', 'logs.npz')):
+                    self.load_log(max_step=st)
+                if self.D_exists:
+                    print('Resuming training with model for D [{:s}] ...'.format(path_D))
+                    self.load_network(path_D, self.netD, optimizer=self.optimizer_D)
+            else:
+                print('Testing model for G [{:s}] ...'.format(path_G))
+                self.load_network(path_G, self.netG)
+                if 'netD' in self.__dict__ and os.path.exists(path_D):
+                    self.load_network(path_D, self.netD)
+                self.gradient_step_num = st
+            return
+        load_path_G = path_opt.get('pretrained_model_G') or path_opt.get('pretrain_model_G')      # the reference reads 'pretrained_model_G'
         if load_path_G is not None:
             print('loading model for G [{:s}] ...'.format(load_path_G))
-            self.load_network(load_path_G, self.netG, optimizer=self.optimizer_G if (self.is_train and resume_train) else None)
+            self.load_network(load_path_G, self.netG)
+        load_path_D = path_opt.get('pretrained_model_D') or path_opt.get('pretrain_model_D')
+        if self.is_train and self.D_exists and load_path_D is not None:
+            print('loading model for D [{:s}] ...'.format(load_path_D))
+            self.load_network(load_path_D, self.netD, optimizer=self.optimizer_D)
 
     def save(self, iter_label):
         if esr_dist.rank() != 0:
             return None
-        return self.save_network(self.save_dir, self.netG, 'G', iter_label, self.optimizer_G)
+        path = self.save_network(self.save_dir, self.netG, 'G', iter_label, self.optimizer_G)
+        if self.D_exists:
+            self.save_network(self.save_dir, self.netD, 'D', iter_label, self.optimizer_D)
+        return path

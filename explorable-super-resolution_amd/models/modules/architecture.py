@@ -1,11 +1,13 @@
 """RRDBNet — the ESRGAN-style generator of the reference (codes/models/modules/architecture.py:228-302) with the
 same constructor, attributes, module tree and state_dict keys, executed by the gfx950 engine (esr_hip/engine.py).
 
-Only the generator lives here; discriminators / feature extractors of the reference's architecture.py are outside the
-RRDB+CEM hot path.
+Discriminator_VGG_128 (architecture.py:446-508), the other half of the configs[2] training step, is a stock-PyTorch module (MIOpen
+convolutions, BatchNorm, Linear): the WGAN-GP penalty differentiates it twice, which autograd does for stock ops.  The other
+discriminators / feature extractors of the reference's architecture.py are outside this build.
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -97,3 +99,50 @@ class RRDBNet(nn.Module):
                 raise Exception('Unsupported yet')          # same behaviour as architecture.py:295
             raise NotImplementedError("latent_input '%s': only '<all_layers|first_layer>_HR_downscaled' is implemented" % self.latent_input)
         return self.engine.forward(x, pad=pad)
+
+
+class Discriminator_VGG_128(nn.Module):
+    """VGG-style critic (reference architecture.py:446-508): 3x3 stride-1 convs alternating with 4x4 stride-2 convs, widths
+    nf, nf, 2nf, 2nf, 4nf, 4nf, 8nf x4, BatchNorm + LeakyReLU(0.2) after every conv but the first (no norm there); the first `nb` of the
+    ten conv blocks are kept; `num_2_strides` of the five 4x4 convs stride (the rest run at stride 1).  With all five strides the
+    classifier is Linear(8nf * s^2, 100) -> LeakyReLU -> Linear(100, 1) on the s x s feature map (s = 4 for 128x128 inputs); with fewer
+    it is a "patch" critic: conv 8x8 (no padding) -> LeakyReLU -> conv 1x1.  `features` is ONE flat nn.Sequential and `classifier` a
+    3-element one, so state_dict keys and their order are the reference's (features.0.weight, features.2.weight, features.3.weight ...)."""
+
+    def __init__(self, in_nc, base_nf, norm_type='batch', act_type='leakyrelu', mode='CNA', input_patch_size=128, num_2_strides=5, nb=10):
+        super(Discriminator_VGG_128, self).__init__()
+        assert num_2_strides <= 5, 'Can be modified by adding more stridable layers, if needed.'
+        if mode != 'CNA' or act_type != 'leakyrelu' or norm_type not in ('batch', 'instance', None):
+            raise NotImplementedError('Discriminator_VGG_128(norm_type=%r, act_type=%r, mode=%r)' % (norm_type, act_type, mode))
+        self.num_2_strides = 1 * num_2_strides
+        widths = [base_nf, base_nf, 2 * base_nf, 2 * base_nf, 4 * base_nf, 4 * base_nf, 8 * base_nf, 8 * base_nf, 8 * base_nf, 8 * base_nf]
+        layers, cin, size, strides_left = [], in_nc, float(input_patch_size), num_2_strides
+        for i, cout in enumerate(widths):
+            k, stride = 3, 1
+            if i % 2 == 1:                     # the down-sampling slots: 4x4, stride 2 while strides remain
+                k, stride = 4, (2 if strides_left > 0 else 1)
+                size = np.ceil((size - 1) / stride)
+                strides_left -= 1
+            block = [nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2)]
+            if i > 0 and norm_type is not None:
+                block.append(B.norm(norm_type, cout))
+            block.append(nn.LeakyReLU(0.2, True))
+            layers.append(block)
+            cin = cout
+        layers = layers[:nb]
+        self.features = nn.Sequential(*[m for block in layers for m in block])
+        self.last_FC_layers = self.num_2_strides == 5
+        if self.last_FC_layers:
+            self.classifier = nn.Sequential(nn.Linear(base_nf * 8 * int(size) ** 2, 100), nn.LeakyReLU(0.2, True), nn.Linear(100, 1))
+        else:
+            feat = widths[len(layers) - 1]
+            hidden = min(100, feat)
+            c0 = [nn.Conv2d(feat, hidden, kernel_size=8, stride=1, padding=0)] + ([B.norm(norm_type, hidden)] if norm_type else []) + [nn.LeakyReLU(0.2, True)]
+            c1 = [nn.Conv2d(hidden, 1, kernel_size=1, stride=1, padding=0)] + ([B.norm(norm_type, 1)] if norm_type else []) + [nn.LeakyReLU(0.2, True)]
+            self.classifier = nn.Sequential(nn.Sequential(*c0), nn.LeakyReLU(0.2, False), nn.Sequential(*c1))
+
+    def forward(self, x):
+        x = self.features(x)
+        if self.last_FC_layers:
+            x = x.view(x.size(0), -1)
+        return self.classifier(x)

@@ -3,7 +3,9 @@
 Differences that follow from the MI355X design (one process per GPU, RCCL data parallelism):
   * define_G never wraps the generator in nn.DataParallel; callers that reach through `.module` (GUI.py:1687) still work
     because the CEM wrapper and RRDBNet expose `.module` as themselves.
-  * discriminators / feature extractors (define_D / define_F) are not part of the RRDB+CEM path.
+  * define_D builds the reference's default critic (Discriminator_VGG_128) from stock PyTorch modules (MIOpen kernels): it is the other
+    half of the configs[2] training step, not part of the RRDB+CEM kernel path.  The VGG feature extractor (define_F) needs
+    torchvision and stays out.
 """
 import functools
 
@@ -92,7 +94,25 @@ def define_G(opt, CEM=None, num_latent_channels=None, **kwargs):
 
 
 def define_D(opt, CEM=None, **kwargs):
-    raise NotImplementedError('define_D: discriminators are outside the RRDB+CEM hot path (SURVEY.md §8(f) "next")')
+    """Critic factory (reference networks.py:126-182).  The critic sees the generator's output with the CEM's invalidity frame cropped
+    (patch_size - 2*margins_HR, :133-135)."""
+    opt_net = opt['network_D']
+    which_model = opt_net['which_model_D']
+    input_patch_size = opt['datasets']['train']['patch_size']
+    assert not ((opt_net['pre_clipping'] or opt_net['decomposed_input']) and which_model != 'PatchGAN'), 'Unsupported yet'
+    if CEM is not None:
+        input_patch_size -= 2 * CEM.invalidity_margins_HR
+    if which_model == 'discriminator_vgg_128':
+        kw = {'num_2_strides': opt_net['num_2_strides']} if opt_net['num_2_strides'] is not None else {}
+        netD = arch.Discriminator_VGG_128(in_nc=opt_net['in_nc'], base_nf=opt_net['nf'], nb=opt_net['n_layers'] or 10, norm_type=opt_net['norm_type'],
+                                          mode=opt_net['mode'], act_type=opt_net['act_type'], input_patch_size=int(input_patch_size), **kw)
+    elif which_model in ('discriminator_vgg_128_nonModified', 'dis_acd', 'PatchGAN', 'discriminator_vgg_96', 'discriminator_vgg_192',
+                         'discriminator_vgg_128_SN') or 'DnCNN_D' in which_model:
+        raise NotImplementedError('Discriminator model [{:s}] is outside this build (the explorable-SR configuration uses discriminator_vgg_128)'.format(which_model))
+    else:
+        raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(which_model))
+    init_weights(netD, init_type='kaiming', scale=1)
+    return netD          # no nn.DataParallel: one process per GPU, D gradients all-reduced over RCCL (esr_hip.dist)
 
 
 def define_F(opt, use_bn=False, **kwargs):

@@ -27,7 +27,9 @@ REFERENCE_ROOT = '/root/reference/codes'
 
 
 def _stub(name, **attrs):
+    import importlib.machinery
     m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)     # torch._dynamo probes find_spec() of well-known module names
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
@@ -53,7 +55,7 @@ def install():
     import torch
     from oracle import cv2_cubic
     _stub('cv2', resize=cv2_cubic.resize, INTER_CUBIC=cv2_cubic.INTER_CUBIC,
-          INTER_LINEAR=1, INTER_NEAREST=0, IMREAD_UNCHANGED=-1)
+          INTER_LINEAR=1, INTER_NEAREST=0, IMREAD_UNCHANGED=-1, dilate=None, Sobel=None, CV_64F=6)
     tv = _stub('torchvision')
     tv.utils = _stub('torchvision.utils', make_grid=lambda *a, **k: None)
     tv.models = _stub('torchvision.models')
@@ -70,14 +72,44 @@ def install():
     _stub('imageio')
     _stub('tensorboardX')
     _stub('tensorboard_logger')
-    _stub('tqdm', tqdm=lambda x, *a, **k: x)
+    try:
+        import tqdm  # noqa: F401  (installed here; stubbed only where it is missing)
+    except ImportError:
+        _stub('tqdm', tqdm=lambda x, *a, **k: x)
+    import scipy.ndimage
+    if 'scipy.ndimage.morphology' not in sys.modules:      # Z_optimization.py:7 imports binary_opening from the removed sub-module
+        _stub('scipy.ndimage.morphology', binary_opening=scipy.ndimage.binary_opening)
 
     if not torch.cuda.is_available():
         torch.cuda.FloatTensor = torch.FloatTensor
         torch.cuda.DoubleTensor = torch.DoubleTensor
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
+        _map_cuda_device_to_cpu(torch)
     return True
+
+
+def _map_cuda_device_to_cpu(torch):
+    """The reference hard-codes torch.device('cuda') in places (Z_optimization.py:369, loss.py): on this CPU-only container every
+    `.to(<cuda device>)` of a tensor or module becomes `.to('cpu')`."""
+    if getattr(torch.Tensor.to, '_esr_shim', False):
+        return
+
+    def fix(a):
+        if isinstance(a, torch.device) and a.type == 'cuda':
+            return torch.device('cpu')
+        if isinstance(a, str) and a.startswith('cuda'):
+            return 'cpu'
+        return a
+    t_to, m_to = torch.Tensor.to, torch.nn.Module.to
+
+    def tensor_to(self, *a, **k):
+        return t_to(self, *[fix(x) for x in a], **{kk: fix(v) for kk, v in k.items()})
+
+    def module_to(self, *a, **k):
+        return m_to(self, *[fix(x) for x in a], **{kk: fix(v) for kk, v in k.items()})
+    tensor_to._esr_shim = True
+    torch.Tensor.to, torch.nn.Module.to = tensor_to, module_to
 
 
 def ref_import(name):

@@ -176,7 +176,7 @@ def gen_F4():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_fwd_bwd.npz'), **out)
 
 
-def gen_F7():
+def gen_F8():
     """RRDBNet with the latent fed to the FIRST layer only ('first_layer_HR_downscaled', architecture.py:245-246,288-299): forward,
     input gradient and weight-gradient digests.  A separate fixture file so that F4's stays byte-identical."""
     import models.modules.architecture as arch
@@ -261,7 +261,115 @@ def gen_F6():
     np.savez_compressed(os.path.join(GOLDEN, 'c2_rrdb23_probe.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7}
+def _ref_opt(is_train, nb=1, lat=3, gan=False, batch=2, root='/tmp/esr_ref_f7'):
+    """Options of the reference's model wrapper (codes/options/train/train_explorable_SR.json, reduced to what SRRaGANModel reads)."""
+    from options.options import dict_to_nonedict
+    os.makedirs(os.path.join(root, 'models'), exist_ok=True)
+    train = {'resume': 0, 'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'lr_scheme': 'MultiStepLR',
+             'lr_steps': [100000], 'lr_gamma': 0.5, 'pixel_domain': 'HR', 'pixel_criterion': 'l1', 'pixel_weight': 1, 'range_weight': 5000, 'CEM_exp': 1,
+             'grad_accumulation_steps_G': 1, 'grad_accumulation_steps_D': 1, 'D_verification': None, 'D_update_ratio': 1, 'D_init_iters': 0}
+    if gan:
+        train.update({'gan_type': 'wgan-gp', 'gan_weight': 1, 'gp_weight': 10})
+    return dict_to_nonedict({
+        'name': 'f7', 'model': 'srragan', 'scale': 4, 'gpu_ids': None, 'range': [0, 1], 'is_train': is_train,
+        'path': {'root': root, 'models': os.path.join(root, 'models'), 'log': root, 'experiments_root': root, 'val_images': root},
+        'network_G': {'which_model_G': 'RRDB_net', 'CEM_arch': 1, 'sigmoid_range_limit': 0, 'latent_input': 'all_layers' if lat else 'None',
+                      'latent_input_domain': 'HR_downscaled', 'latent_channels': lat, 'norm_type': None, 'mode': 'CNA', 'nf': 64, 'nb': nb,
+                      'in_nc': 3, 'out_nc': 3, 'gc': 32, 'group': 1, 'scale': 4},
+        'network_D': {'which_model_D': 'discriminator_vgg_128', 'relativistic': 0, 'decomposed_input': 0, 'pre_clipping': 0, 'add_quantization_noise': 0,
+                      'norm_type': 'batch', 'act_type': 'leakyrelu', 'mode': 'CNA', 'n_layers': 10, 'nf': 64, 'in_nc': 3},
+        'datasets': {'train': {'patch_size': 208, 'batch_size': batch}}, 'train': train if is_train else None, 'test': {'kernel': None}})
+
+
+def _norms(params):
+    return np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in params])
+
+
+def _train_batch(batch=2, seed=900):
+    return {'LR': seeded_uniform((batch, 3, 52, 52), seed), 'HR': seeded_uniform((batch, 3, 208, 208), seed + 1),
+            'Z': seeded_uniform((batch, 3, 208, 208), seed + 2, -1.0, 1.0)}
+
+
+def gen_F7():
+    """The callers, pinned by the reference itself:
+      g_only/*  SRRaGANModel.optimize_parameters() without a discriminator (RRDB-1, lat 3, batch 2, patch 208): the reference idles on its
+                first call and steps G on the second: l_g_pix / l_g_range, per-parameter gradient norms, weight deltas of the Adam step
+      gd/*      the same with Discriminator_VGG_128 + WGAN-GP (D_verification off, D_update_ratio 1): call 1 = D step only, call 2 = D and G
+                steps: D losses, penalty, interpolation points drawn, D / G gradient norms, l_g_gan, D logits, BatchNorm running means
+      z_<obj>/* Z_optimizer.optimize() on the eval-mode model (RRDB-1, lat 3, B=3, 4 iterations, lr 0.1): loss trajectory, final Z digest"""
+    import contextlib
+    import io
+    import models
+    out = {}
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    # ---- (i) generator-only step
+    with quiet:
+        m = models.create_model(_ref_opt(True))
+    fill_formula_weights(m.netG, gain=0.5)
+    data = _train_batch()
+    gp = [p for n, p in m.netG.named_parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in gp]
+    for _ in range(2):
+        m.feed_data({k: v.clone() for k, v in data.items()})
+        m.optimize_parameters()
+    log = m.get_current_log()
+    out['g_only/l_g_pix'], out['g_only/l_g_range'] = np.array(log['l_g_pix']), np.array(log['l_g_range'])
+    out['g_only/grad_norms'] = _norms(gp)
+    out['g_only/delta_norms'] = np.array([float((p.detach() - b).double().norm()) for p, b in zip(gp, before)])
+    out['g_only/fea_weight_after'] = _param_digest(gp[0])
+    out['g_only/fake_H_digest'] = _param_digest(m.fake_H)
+    print('g_only', log)
+    # ---- (ii) G + D step
+    with quiet:
+        m = models.create_model(_ref_opt(True, gan=True))
+    fill_formula_weights(m.netG, gain=0.5)
+    fill_formula_weights(m.netD, gain=1.0)
+    out['gd/D_keys'] = np.array(list(m.netD.state_dict().keys()))
+    out['gd/D_key_shapes'] = np.array([str(tuple(v.shape)) for v in m.netD.state_dict().values()])
+    m.netD.eval()
+    with torch.no_grad():
+        out['gd/D_eval_out'] = m.netD(seeded_uniform((2, 3, 128, 128), 910)).numpy()
+    m.netD.train()
+    gp = [p for n, p in m.netG.named_parameters() if p.requires_grad]
+    dp = list(m.netD.parameters())
+    for call in range(2):
+        torch.manual_seed(1234 + call)
+        m.feed_data({k: v.clone() for k, v in data.items()})
+        m.optimize_parameters()
+        out['gd/call%d/random_pt' % call] = m.random_pt.detach().numpy().copy()
+        out['gd/call%d/D_grad_norms' % call] = _norms(dp)
+        log = m.get_current_log()
+        for k in ('l_d_real', 'l_d_fake', 'l_d_gp', 'D_real', 'D_fake', 'D_logits_diff', 'Correctly_distinguished'):
+            out['gd/call%d/%s' % (call, k)] = np.array(log[k])
+        print('gd call', call, {k: v for k, v in log.items()})
+    for k in ('l_g_gan', 'l_g_pix', 'l_g_range'):
+        out['gd/call1/' + k] = np.array(log[k])
+    out['gd/call1/G_grad_norms'] = _norms(gp)
+    out['gd/bn_running_mean_first'] = m.netD.state_dict()['features.3.running_mean'].numpy().copy()
+    # ---- (iii) latent search
+    from Z_optimization import Z_optimizer
+    with quiet:
+        m = models.create_model(_ref_opt(False))
+    fill_formula_weights(m.netG, gain=0.5)
+    lr = seeded_uniform((1, 3, 24, 28), 920)
+    B = 3
+    for obj in ('STD_increase', 'max_STD', 'TV'):
+        z0 = seeded_uniform((B, 3, 96, 112), 921, -0.3, 0.3)
+        m.feed_data({'LR': lr.expand(B, -1, -1, -1).clone(), 'Z': z0.clone()}, need_GT=False)
+        m.test()
+        with quiet:
+            zo = Z_optimizer(objective=obj, Z_size=[96, 112], model=m, Z_range=1, max_iters=4, data={'LR': lr.expand(B, -1, -1, -1).clone(), 'STD_increment': 0.01}, initial_Z=z0.clone(),
+                             initial_LR=0.1, batch_size=B)
+            z = zo.optimize()
+        out['z_%s/loss' % obj] = np.array(zo.loss_values, dtype=np.float64)
+        out['z_%s/final_Z_digest' % obj] = _param_digest(z)
+        out['z_%s/final_Z_sub' % obj] = z[:, :, ::16, ::16].numpy().copy()
+        out['z_%s/initial_STD' % obj] = zo.initial_STD.detach().numpy().copy()
+        print(obj, zo.loss_values)
+    np.savez_compressed(os.path.join(GOLDEN, 'callers_f7.npz'), **out)
+
+
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8}
 
 if __name__ == '__main__':
     _refshim.install()

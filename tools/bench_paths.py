@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def make_opt(is_train, lat=3, nb=23):
+def make_opt(is_train, lat=3, nb=23, with_D=False):
     from options.options import dict_to_nonedict
     return dict_to_nonedict({
         'model': 'srragan', 'scale': 4, 'gpu_ids': [0], 'range': [0, 1], 'is_train': is_train,
@@ -26,9 +26,14 @@ def make_opt(is_train, lat=3, nb=23):
         'network_G': {'which_model_G': 'RRDB_net', 'CEM_arch': 1, 'sigmoid_range_limit': 0, 'latent_input': 'all_layers',
                       'latent_input_domain': 'HR_downscaled', 'latent_channels': lat, 'norm_type': None, 'mode': 'CNA', 'nf': 64, 'nb': nb,
                       'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
-        'network_D': None, 'test': {'kernel': None}, 'datasets': {'train': {'patch_size': 208}},
-        'train': {'pixel_weight': 1, 'pixel_criterion': 'l1', 'lr_G': 1e-4, 'pixel_domain': 'HR', 'grad_accumulation_steps_G': 1,
-                  'lr_scheme': 'MultiStepLR', 'lr_steps': [100000], 'lr_gamma': 0.5}})
+        # with_D: the discriminator half of configs[2] as codes/options/train/train_explorable_SR.json sets it (Discriminator_VGG_128, n_layers 10,
+        # BatchNorm, WGAN-GP with gp_weight 10, non-relativistic), D-verification off and one G step per D step so that every step does both
+        'network_D': {'which_model_D': 'discriminator_vgg_128', 'relativistic': 0, 'decomposed_input': 0, 'pre_clipping': 0, 'add_quantization_noise': 0,
+                      'norm_type': 'batch', 'act_type': 'leakyrelu', 'mode': 'CNA', 'n_layers': 10, 'nf': 64, 'in_nc': 3} if with_D else None,
+        'test': {'kernel': None}, 'datasets': {'train': {'patch_size': 208, 'batch_size': 32}},
+        'train': dict({'pixel_weight': 1, 'pixel_criterion': 'l1', 'lr_G': 1e-5, 'lr_D': 1e-5, 'pixel_domain': 'HR', 'grad_accumulation_steps_G': 1,
+                       'grad_accumulation_steps_D': 1, 'range_weight': 5000, 'CEM_exp': 1, 'lr_scheme': 'MultiStepLR', 'lr_steps': [100000], 'lr_gamma': 0.5},
+                      **({'gan_type': 'wgan-gp', 'gan_weight': 1, 'gp_weight': 10, 'D_update_ratio': 1, 'D_init_iters': 0, 'D_verification': None} if with_D else {}))})
 
 
 def c5(a, D):
@@ -71,6 +76,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--nb', type=int, default=23)
+    ap.add_argument('--with-D', dest='with_D', action='store_true', help='c3: add Discriminator_VGG_128 + WGAN-GP (the full configs[2] step)')
     ap.add_argument('--precision', default='split', choices=['split', 'mixed', 'f16x2', 'f16', 'bf16'], help="'mixed': fp16 planes, fp32-class forward (inference, Z search, training); 'bf16': single-MFMA operands (C3 names bf16); 'f16x2' / 'f16' are inference-only (c5)")
     a = ap.parse_args()
     from esr_hip import dist as D
@@ -83,7 +89,7 @@ def main():
     torch.manual_seed(0)
     dev = torch.device('cuda', torch.cuda.current_device())
     with contextlib.redirect_stdout(io.StringIO()):
-        model = models.create_model(make_opt(a.which == 'c3', nb=a.nb))
+        model = models.create_model(make_opt(a.which == 'c3', nb=a.nb, with_D=a.with_D))
     if a.precision != 'split':
         model.netG.generated_image_model.set_precision(a.precision)
     sync = torch.cuda.synchronize
@@ -91,8 +97,9 @@ def main():
         B = a.batch or 32
         data = {'LR': torch.rand(B, 3, 52, 52, device=dev), 'HR': torch.rand(B, 3, 208, 208, device=dev),
                 'Z': torch.rand(B, 3, 208, 208, device=dev) * 2 - 1}
-        for _ in range(2):
+        for _ in range(3):
             model.feed_data(data); model.optimize_parameters()
+        model.timing = {}
         sync(); t0 = time.perf_counter()
         for _ in range(a.steps):
             model.feed_data(data); model.optimize_parameters()
@@ -100,6 +107,7 @@ def main():
         if D.rank() == 0:
             print('c3 generator step [' + a.precision + '] (RRDB-%d x4 + CEM, lat 3, %d x 52x52 per GPU, %d GPU(s)): %.1f ms/step, %.0f LR crops/s, l_g_pix %.4f, peak %.1f GB'
                   % (a.nb, B, D.world_size(), dt * 1e3, B * D.world_size() / dt, model.get_current_log()['l_g_pix'], torch.cuda.max_memory_allocated() / 2 ** 30))
+            print('   phases (GPU ms per step, step synchronised for the timers): ' + ', '.join('%s %.1f' % (k, v / a.steps) for k, v in model.timing.items()))
     else:
         from Z_optimization import Z_optimizer
         B = a.batch or 64
