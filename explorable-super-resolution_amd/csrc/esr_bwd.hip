@@ -80,6 +80,23 @@ __global__ void act_combine_kernel(DView A, float alpha, DView Bv, float beta, i
     pack8((uint4*)out.hi, (uint4*)out.lo, b * out.bs + cg * out.cs + pix, v, out.fmt);
 }
 
+// Adjoint of the conv kernel's pixel-shuffle store (esr_hip.h): dst[g*r^2 + s][y][x] = src[g][r*y + s/r][r*x + s%r]; one 16-byte vector per thread
+__global__ void pixel_unshuffle_kernel(DView src, int r, DView dst, int H, int W, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, dst group, y, x) over dst's interior
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    long long t = idx / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int cg = (int)(t % dst.ncg);
+    const int b = (int)(t / dst.ncg);
+    const int g = cg / (r * r), sp = cg % (r * r);
+    const long long so = b * src.bs + g * src.cs + (long long)(r * y + sp / r + 1) * (r * W + 2) + (r * x + sp % r + 1);
+    const long long d_o = b * dst.bs + cg * dst.cs + (long long)(y + 1) * (W + 2) + (x + 1);
+    ((uint4*)dst.hi)[d_o] = src.hi[so];
+    if (dst.lo) ((uint4*)dst.lo)[d_o] = src.lo ? src.lo[so] : make_uint4(0, 0, 0, 0);
+}
+
 // Adjoint of esr_pack_nchw: act-layout gradient (interior (h+2pad)/down x (w+2pad)/down) -> fp32 NCHW gradient of the
 // un-padded source, dst[b][c0+c][y][x] (+)= sum over padded positions that the replicate padding maps onto (y,x) of
 //   down == 1 : g[pos]
@@ -263,6 +280,17 @@ extern "C" int esr_act_combine(const esr_act_view* A, float alpha, const esr_act
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(act_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, to_dview(a), alpha, to_dview(bv),
                        beta, s, to_dview(m), mask_slope, to_dview(*out), out->H, out->W, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+extern "C" int esr_pixel_unshuffle(const esr_act_view* src, int r, const esr_act_view* dst, int B, esr_stream_t stream) {
+    if (!src || !src->hi || !dst || !dst->hi || B <= 0 || r < 2) return ESR_E_ARG;
+    if (dst->ncg != src->ncg * r * r || src->H != r * dst->H || src->W != r * dst->W || src->fmt != dst->fmt) return ESR_E_ARG;
+    const long long total = (long long)B * dst->ncg * dst->H * dst->W;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, to_dview(*src), r, to_dview(*dst),
+                       dst->H, dst->W, total);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -710,8 +738,9 @@ extern "C" int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc*
     return b.table_bytes + b.map_bytes + (b.partial_floats + 1) * 4;
 }
 
-extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
-    if (!descs || n <= 0 || !workspace) return ESR_E_ARG;
+extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
+                                              esr_stream_t stream) {
+    if (!descs || n <= 0 || !workspace || !plan) return ESR_E_ARG;
     const bool split = descs[0].dy.lo != nullptr;
     for (int i = 0; i < n; ++i) {
         const int rc = wgrad_validate(&descs[i]);
@@ -735,24 +764,43 @@ extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void*
         if (p.nslices > 1 && p.ngroups * 9 * 1024 + p.mt * 32 > max_red) max_red = p.ngroups * 9 * 1024 + p.mt * 32;
     }
     hipStream_t s = (hipStream_t)stream;
-    // pageable host memory: the runtime stages it before returning, the vectors may go out of scope
+    // pageable host memory: the runtime stages it before returning (the vectors go out of scope); a host-blocking copy, not graph-capturable —
+    // which is why it is its own entry point: callers upload once per descriptor set and replay esr_conv3x3_wgrad_batch_run
     if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(WgradArgs), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
     if (hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), (size_t)b.nwg * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
         return ESR_E_LAUNCH;
+    plan->nwg = b.nwg;
+    plan->table_bytes = b.table_bytes;
+    plan->n = n;
+    plan->max_red = max_red;
+    plan->split = split ? 1 : 0;
+    plan->f16 = descs[0].dy.fmt == ESR_FMT_F16 ? 1 : 0;
+    return ESR_OK;
+}
+
+extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
+    if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
     const int nst = wgrad_stages();
-    const bool f16 = descs[0].dy.fmt == ESR_FMT_F16;
+    const bool f16 = plan->f16 != 0, split = plan->split != 0;
     void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
                                              : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
                                                      : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3((unsigned)b.nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
-                       (const int4*)((char*)workspace + b.table_bytes));
+    hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
+                       (const int4*)((const char*)workspace + plan->table_bytes));
     ESR_CHECK_LAUNCH();
-    if (max_red > 0) {
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((max_red + 255) / 256), (unsigned)n), dim3(256), 0, s,
+    if (plan->max_red > 0) {
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((plan->max_red + 255) / 256), (unsigned)plan->n), dim3(256), 0, s,
                            (const WgradArgs*)workspace);
         ESR_CHECK_LAUNCH();
     }
     return ESR_OK;
+}
+
+extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
+    esr_wgrad_batch_plan plan;
+    const int rc = esr_conv3x3_wgrad_batch_upload(descs, n, workspace, workspace_bytes, &plan, stream);
+    return rc != ESR_OK ? rc : esr_conv3x3_wgrad_batch_run(workspace, &plan, stream);
 }

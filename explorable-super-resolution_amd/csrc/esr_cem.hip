@@ -290,6 +290,179 @@ __global__ __launch_bounds__(256) void cem_upscale_tiled_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Separable fast path.  The bicubic ds_kernel and its inv_hTh are rank one (sigma_2 / sigma_1 ~ 1e-16), taps[a][b] = tv[a]*th[b]:
+// every filter is a horizontal pass followed by a vertical one (or the reverse) on the tile a workgroup holds in LDS — 2k instead of k^2 MACs
+// per output (k = 17..45).  Same windows, same clamping / zero-stuffing index rules as the 2-D kernels above; the host selects this path at
+// construction when the kernel passes the rank test and keeps the 2-D path for anisotropic (estimated) kernels.
+
+__global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __restrict__ x, int h, int w, const float* __restrict__ tv, const float* __restrict__ th,
+                                                             int k, float* __restrict__ out, int pitch) {
+    extern __shared__ float tile[];          // window (LT_TY + k - 1) x pitch | horizontal pass (LT_TY + k - 1) x (LT_TX + 1)
+    const int p = k / 2;
+    const int x0 = blockIdx.x * LT_TX, y0 = blockIdx.y * LT_TY;
+    const long long bc = blockIdx.z;
+    const float* src = x + bc * h * (long long)w;
+    const int rows = LT_TY + k - 1, cols = LT_TX + k - 1;
+    float* const hp = tile + rows * pitch;
+    for (int e = threadIdx.x; e < rows * cols; e += 256) {
+        const int r = e / cols, c = e - r * cols;
+        tile[r * pitch + c] = src[(long long)clampi(y0 + r - p, 0, h - 1) * w + clampi(x0 + c - p, 0, w - 1)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int r = threadIdx.x >> 6; r < rows; r += 4) {        // a wave per window row: 64 consecutive outputs, conflict-free reads
+        const float* row = tile + r * pitch + lx;
+        float a0 = 0.f, a1 = 0.f;
+        int c = 0;
+        for (; c + 1 < k; c += 2) { a0 = fmaf(th[c], row[c], a0); a1 = fmaf(th[c + 1], row[c + 1], a1); }
+        if (c < k) a0 = fmaf(th[c], row[c], a0);
+        hp[r * (LT_TX + 1) + lx] = a0 + a1;
+    }
+    __syncthreads();
+    for (int ty = threadIdx.x >> 6; ty < LT_TY; ty += 4) {
+        const float* col = hp + ty * (LT_TX + 1) + lx;
+        float a0 = 0.f, a1 = 0.f;
+        int a = 0;
+        for (; a + 1 < k; a += 2) { a0 = fmaf(tv[a], col[a * (LT_TX + 1)], a0); a1 = fmaf(tv[a + 1], col[(a + 1) * (LT_TX + 1)], a1); }
+        if (a < k) a0 = fmaf(tv[a], col[a * (LT_TX + 1)], a0);
+        const int Y = y0 + ty, X = x0 + lx;
+        if (Y < h && X < w) out[(bc * h + Y) * (long long)w + X] = a0 + a1;
+    }
+}
+
+__global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __restrict__ y, int h, int w, int sf, int pre, const float* __restrict__ tv,
+                                                              const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
+                                                              float* __restrict__ d, int qpitch, int rows) {
+    extern __shared__ float tile[];          // [sf][rows][qpitch] de-interleaved window (as cem_downscale_tiled_kernel) | horizontal pass [rows][DT + 1]
+    const int p = k / 2, Hh = h * sf, Wh = w * sf;
+    const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
+    const long long bc = blockIdx.z;
+    const float* src = y + bc * Hh * (long long)Wh;
+    const int Yb = sf * i0 + pre - p, Xb = sf * j0 + pre - p;
+    const int cols = (DT - 1) * sf + k;
+    const int lg = (sf & (sf - 1)) == 0 ? __builtin_ctz(sf) : -1;
+    float* const hp = tile + sf * rows * qpitch;
+    for (int r = threadIdx.x >> 6; r < rows; r += 4) {
+        const float* grow = src + (long long)clampi(Yb + r, 0, Hh - 1) * Wh;
+        for (int c = threadIdx.x & 63; c < cols; c += 64) {
+            const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+            tile[(ph * rows + r) * qpitch + q] = grow[clampi(Xb + c, 0, Wh - 1)];
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15;
+    for (int r = threadIdx.x >> 4; r < rows; r += 16) {       // horizontal (strided) pass: 16 kept columns of every window row
+        float a0 = 0.f, a1 = 0.f;
+        for (int ph = 0; ph < sf; ++ph) {
+            const float* pl = tile + (ph * rows + r) * qpitch + tx;
+            int c = ph, q = 0;
+            for (; c + sf < k; c += 2 * sf, q += 2) { a0 = fmaf(th[c], pl[q], a0); a1 = fmaf(th[c + sf], pl[q + 1], a1); }
+            if (c < k) a0 = fmaf(th[c], pl[q], a0);
+        }
+        hp[r * (DT + 1) + tx] = a0 + a1;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4;
+    const int i = i0 + ty, j = j0 + tx;
+    if (i < h && j < w) {
+        const float* col = hp + ty * sf * (DT + 1) + tx;
+        float a0 = 0.f, a1 = 0.f;
+        int a = 0;
+        for (; a + 1 < k; a += 2) { a0 = fmaf(tv[a], col[a * (DT + 1)], a0); a1 = fmaf(tv[a + 1], col[(a + 1) * (DT + 1)], a1); }
+        if (a < k) a0 = fmaf(tv[a], col[a * (DT + 1)], a0);
+        float acc = a0 + a1;
+        if (lr) {
+            const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
+            acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
+        }
+        d[(bc * h + i) * (long long)w + j] = acc;
+    }
+}
+
+// Polyphase upscale, separable: the vertical pass combines, for every output ROW of the tile, the <= ceil(k/sf) window rows whose taps land on
+// samples (plus the pre == 0 replicate rule) into one row of window-column values; the horizontal pass does the same along the row.
+template <bool TWO>
+__global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf, int pre,
+                                                            const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
+                                                            int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc) {
+    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [UT_Y][wc] | vertical pass 2
+    float* const w1 = sm;
+    float* const w2 = w1 + wr * wc;
+    float* const v1 = w2 + (TWO ? wr * wc : 0);
+    float* const v2 = v1 + UT_Y * wc;
+    const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
+    const long long bc = blockIdx.z;
+    const int xo0 = blockIdx.x * UT_X, yo0 = blockIdx.y * UT_Y;
+    const int fy = yo0 + crop - p - pre, fx = xo0 + crop - p - pre;
+    const int ib = (fy >= 0 ? fy / sf : -((-fy + sf - 1) / sf)), jb = (fx >= 0 ? fx / sf : -((-fx + sf - 1) / sf));
+    const float* s1 = f + bc * h * (long long)w;
+    const float* s2 = TWO ? f2 + bc * h * (long long)w : nullptr;
+    for (int e = threadIdx.x; e < wr * wc; e += 256) {
+        const int r = e / wc, c = e - r * wc;
+        const int i = ib + r, j = jb + c;
+        const bool in = i >= 0 && i < h && j >= 0 && j < w;
+        w1[e] = in ? s1[(long long)i * w + j] : 0.f;
+        if (TWO) w2[e] = in ? s2[(long long)i * w + j] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < UT_Y * wc; e += 256) {      // vertical pass
+        const int ry = e / wc, c = e - ry * wc;
+        const int Y = yo0 + ry + crop;
+        float u1 = 0.f, u2 = 0.f;
+        if (Y < Hh) {
+            int a0 = (pre + p - Y) % sf; if (a0 < 0) a0 += sf;
+            int il = (Y + a0 - p - pre) / sf - ib;
+            for (int a = a0; a < k; a += sf, ++il) {
+                const int yy = Y + a - p;
+                if (yy < 0 || yy >= Hh) continue;
+                u1 = fmaf(tv[a], w1[il * wc + c], u1);
+                if (TWO) u2 = fmaf(tv[a], w2[il * wc + c], u2);
+            }
+            if (pre == 0)
+                for (int a = 0; Y + a - p < 0 && a < k; ++a) {
+                    u1 = fmaf(tv[a], w1[-ib * wc + c], u1);
+                    if (TWO) u2 = fmaf(tv[a], w2[-ib * wc + c], u2);
+                }
+        }
+        v1[e] = u1;
+        if (TWO) v2[e] = u2;
+    }
+    __syncthreads();
+    const int xo = xo0 + (threadIdx.x & 63);
+#pragma unroll 1
+    for (int ry = threadIdx.x >> 6; ry < UT_Y; ry += 4) {
+        const int yq = yo0 + ry;
+        if (xo >= Wo || yq >= Ho) continue;
+        const int Y = yq + crop, X = xo + crop;
+        const float* r1 = v1 + ry * wc;
+        const float* r2 = v2 + ry * wc;
+        float u1 = 0.f, u2 = 0.f;
+        int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
+        int jl = (X + b0 - p - pre) / sf - jb;
+        for (int b = b0; b < k; b += sf, ++jl) {
+            const int xx = X + b - p;
+            if (xx < 0 || xx >= Wh) continue;
+            u1 = fmaf(th[b], r1[jl], u1);
+            if (TWO) u2 = fmaf(th[b], r2[jl], u2);
+        }
+        if (pre == 0)
+            for (int b = 0; X + b - p < 0 && b < k; ++b) {
+                u1 = fmaf(th[b], r1[-jb], u1);
+                if (TWO) u2 = fmaf(th[b], r2[-jb], u2);
+            }
+        const long long go = (bc * Hh + Y) * (long long)Wh + X;
+        const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
+        float r;
+        if (mode == 0) r = u1;
+        else if (mode == 1) r = g[go] + u1;
+        else if (mode == 2) r = u1 + tanhf(g[go] - u2) * range;
+        else { r = u1; out2[idx] = g[go] - u2; }
+        out[idx] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k, const float* lr,
@@ -373,6 +546,63 @@ extern "C" int esr_cem_upscale(const float* f, const float* f2, int B, int C, in
     else
         hipLaunchKernelGGL(cem_upscale_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f, f2, h, w, sf, pre, taps, k, g, crop, mode, range,
                            out, out2, total);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+
+// ---- separable variants: taps[a][b] = tv[a] * th[b] (device arrays of k floats each).  Same arguments and results as the 2-D entry points
+// above up to fp32 rounding of the tap products; ESR_E_UNSUPPORTED when the tile does not fit (the caller then uses the 2-D entry point).
+extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k, const float* lr,
+                                     int lr_pad, float* d, esr_stream_t stream) {
+    if (!y || !tv || !th || !d || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 1 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
+    if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
+    const int rows = (DT - 1) * sf + k, qcols = (rows + sf - 1) / sf + 1;
+    int qpitch = qcols;
+    while ((sf * qpitch) % 32 != 16 && qpitch < qcols + 32) ++qpitch;
+    if ((sf * qpitch) % 32 != 16) qpitch = qcols | 1;
+    const size_t lds = ((size_t)sf * rows * qpitch + (size_t)rows * (DT + 1)) * 4;
+    if (lds > 150 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
+    ESR_CLEAR_ERR();
+    ESR_ALLOW_160K_LDS(cem_downscale_sep_kernel);
+    hipLaunchKernelGGL(cem_downscale_sep_kernel, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w, sf, pre, tv, th,
+                       k, lr, lr_pad, d, qpitch, rows);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+extern "C" int esr_cem_lrfilter_sep(const float* x, int B, int C, int h, int w, const float* tv, const float* th, int k, float* out, esr_stream_t stream) {
+    if (!x || !tv || !th || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || k < 1 || !(k & 1)) return ESR_E_ARG;
+    int pitch = LT_TX + k - 1;
+    pitch += (16 - pitch % 32 + 32) % 32;
+    const size_t lds = ((size_t)(LT_TY + k - 1) * pitch + (size_t)(LT_TY + k - 1) * (LT_TX + 1)) * 4;
+    if (lds > 150 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
+    ESR_CLEAR_ERR();
+    ESR_ALLOW_160K_LDS(cem_lrfilter_sep_kernel);
+    hipLaunchKernelGGL(cem_lrfilter_sep_kernel, dim3((w + LT_TX - 1) / LT_TX, (h + LT_TY - 1) / LT_TY, B * C), dim3(256), lds, (hipStream_t)stream, x, h, w, tv, th,
+                       k, out, pitch);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
+extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k,
+                                   const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream) {
+    if (!f || !tv || !th || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 2 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
+    if (mode < 0 || mode > 3 || crop < 0 || 2 * crop >= h * sf || 2 * crop >= w * sf) return ESR_E_ARG;
+    if ((mode >= 1 && !g) || (mode >= 2 && !f2) || (mode == 3 && !out2)) return ESR_E_ARG;
+    const int wr = (UT_Y + 2 * (k / 2)) / sf + 3, wc = (UT_X + 2 * (k / 2)) / sf + 3;
+    const int two = mode >= 2 ? 2 : 1;
+    const size_t lds = ((size_t)two * wr * wc + (size_t)two * UT_Y * wc) * 4;
+    if (lds > 60 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
+    const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
+    const dim3 tg((Wo + UT_X - 1) / UT_X, (Ho + UT_Y - 1) / UT_Y, B * C);
+    ESR_CLEAR_ERR();
+    if (mode >= 2)
+        hipLaunchKernelGGL(cem_upscale_sep_kernel<true>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2,
+                           wr, wc);
+    else
+        hipLaunchKernelGGL(cem_upscale_sep_kernel<false>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2,
+                           wr, wc);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }

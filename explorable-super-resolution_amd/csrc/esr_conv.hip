@@ -81,6 +81,7 @@ struct ConvArgs {
     int lo_chunks;                  // chunks [0, lo_chunks) carry a lo activation plane, later ones are hi-only (PARTLO kernels)
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
+    int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -567,7 +568,12 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                             lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
                         }
                         if (cgs < ncg_out) {
-                            const long long o = b * a.out.bs + cgs * a.out.cs + pix;
+                            long long o = b * a.out.bs + cgs * a.out.cs + pix;
+                            if (a.ps) {            // row group -> (output group, sub-position) of the r x r block at (Y, X)
+                                const int rg = a.ps_rg0 + cgs, r2 = a.ps * a.ps;
+                                const int sp = rg % r2;
+                                o = b * a.out.bs + (rg / r2) * a.out.cs + (long long)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1);
+                            }
                             ((uint4*)a.out.hi)[o] = hv;
                             if (NPL == 2 && (!PARTLO || a.out.lo)) ((uint4*)a.out.lo)[o] = lv;
                             if (EPI & EPI_OUT2) {
@@ -796,7 +802,8 @@ extern "C" int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(PackEntry), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
     if (hipMemcpyAsync((char*)workspace + tb, map.data(), (size_t)nb * sizeof(int2), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return ESR_E_LAUNCH;     // the host vectors go out of scope
+    // (pageable host memory: the runtime stages both copies before hipMemcpyAsync returns, so the vectors may go out of scope; the stream is
+    // not synchronised)
     return nb;
 }
 
@@ -826,7 +833,12 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->in0.hi && ((d->in0.lo != nullptr) != split)) return ESR_E_ARG;
     const int mt = (d->cout + 31) / 32;
     if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches
-    if (d->out.hi && d->out.ncg * 8 < d->cout) return ESR_E_ARG;
+    const int ps = d->pixel_shuffle > 1 ? d->pixel_shuffle : 0;
+    if (ps) {
+        if (!d->out.hi || d->out_nchw || d->out2.hi || d->res1.hi || d->res2.hi || d->mask_src.hi || d->cout % 8) return ESR_E_UNSUPPORTED;
+        if (d->out.H != ps * d->H || d->out.W != ps * d->W || (d->ps_rowgroup0 + d->cout / 8 + ps * ps - 1) / (ps * ps) > d->out.ncg) return ESR_E_ARG;
+    } else if (d->out.hi && (d->out.H != d->H || d->out.W != d->W)) return ESR_E_ARG;
+    if (!ps && d->out.hi && d->out.ncg * 8 < d->cout) return ESR_E_ARG;
     // a missing lo OUTPUT plane with hi+lo inputs is the single-plane-intermediate case (fp16 formats only, checked below)
     if (d->out.hi && d->out.lo && !split) return ESR_E_ARG;
     if (d->out2.hi && (!d->out.hi || (d->out2.lo != nullptr) != (d->out.lo != nullptr))) return ESR_E_ARG;
@@ -864,6 +876,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
     a.reverse = d->reverse_order;
+    a.ps = ps;
+    a.ps_rg0 = d->ps_rowgroup0;
 #ifdef ESR_TRACE
     a.trace = g_trace;
 #endif

@@ -24,7 +24,8 @@ class Conv3x3Desc(C.Structure):
                 ('res1', ActView), ('beta1', C.c_float), ('res2', ActView), ('beta2', C.c_float),
                 ('out', ActView), ('out2', ActView), ('out_nchw', C.c_void_p),
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
-                ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32)]
+                ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32),
+                ('pixel_shuffle', C.c_int32), ('ps_rowgroup0', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -32,6 +33,11 @@ class WgradDesc(C.Structure):
     _fields_ = [('dy', ActView), ('x', ActView), ('xlat', ActView), ('lat', C.c_int32), ('upsample', C.c_int32), ('cout', C.c_int32),
                 ('cin_main', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('alpha', C.c_float), ('dw', C.c_void_p),
                 ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_floats', C.c_int64)]
+
+
+class WgradBatchPlan(C.Structure):
+    """esr_wgrad_batch_plan (include/esr_hip.h)."""
+    _fields_ = [('nwg', C.c_int64), ('table_bytes', C.c_int64), ('n', C.c_int32), ('max_red', C.c_int32), ('split', C.c_int32), ('f16', C.c_int32)]
 
 
 class PackDesc(C.Structure):
@@ -43,6 +49,7 @@ class PackDesc(C.Structure):
 _SIGS = {
     'esr_version': (C.c_int, []),
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
+    'esr_pixel_unshuffle': (C.c_int, [C.POINTER(ActView), C.c_int, C.POINTER(ActView), C.c_int, C.c_void_p]),
     'esr_conv_wpack_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'esr_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p]),
@@ -65,11 +72,18 @@ _SIGS = {
     'esr_conv3x3_wgrad_workspace_floats': (C.c_int64, [C.POINTER(WgradDesc)]),
     'esr_conv3x3_wgrad_batch_workspace_bytes': (C.c_int64, [C.POINTER(WgradDesc), C.c_int]),
     'esr_conv3x3_wgrad_batch': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'esr_conv3x3_wgrad_batch_upload': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.POINTER(WgradBatchPlan), C.c_void_p]),
+    'esr_conv3x3_wgrad_batch_run': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_void_p]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_upscale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'esr_cem_downscale_sep': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_cem_lrfilter_sep': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_cem_upscale_sep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -115,6 +129,7 @@ class _LazyLib:
 
 lib = _LazyLib()
 
+ESR_OK, ESR_E_ARG, ESR_E_UNSUPPORTED, ESR_E_LAUNCH = 0, -1, -2, -3
 _ERR = {-1: 'ESR_E_ARG (bad argument)', -2: 'ESR_E_UNSUPPORTED (unsupported shape)', -3: 'ESR_E_LAUNCH (HIP launch error)'}
 
 

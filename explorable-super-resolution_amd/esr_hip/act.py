@@ -123,9 +123,12 @@ class PackedConv:
     """MFMA-fragment-ordered copy of one nn.Conv2d(k=3) weight (+ zero-padded bias), re-packed on demand when the
     parameter changes (torch bumps `_version` on every in-place update, e.g. an optimizer step or load_state_dict)."""
 
-    def __init__(self, weight, bias, lat, split=True, transposed=False, m_slice=None):
+    def __init__(self, weight, bias, lat, split=True, transposed=False, m_slice=None, rows=None):
         self.weight, self.bias_p, self.lat, self.split, self.transposed = weight, bias, lat, split, transposed
-        self.m_slice = m_slice        # data-gradient packs: (lo, hi) slice of the main input channels, or 'latent' 
+        self.m_slice = m_slice        # data-gradient packs: (lo, hi) slice of the main input channels, or 'latent'
+        # explicit order of the tensor's OUTPUT channels (pixel-shuffle convs, see esr_conv3x3_desc.pixel_shuffle): forward packs take
+        # them as the M rows of this launch, data-gradient packs as the K axis (the layout esr_pixel_unshuffle leaves the gradient in)
+        self.rows = rows
         self._key = None
         self.wpack = None
         self.bias = None
@@ -143,13 +146,20 @@ class PackedConv:
                 kmap += [e if e < lat else -1 for e in range(8)]
             ncg_main = (main + 7) // 8
             kmap += [lat + c if c < main else -1 for c in range(ncg_main * 8)]
-            mt = (cout_w + 31) // 32
-            mmap = [m if m < cout_w else -1 for m in range(mt * 32)]
+            if self.rows is not None:
+                mt = (len(self.rows) + 31) // 32
+                mmap = list(self.rows) + [-1] * (mt * 32 - len(self.rows))
+            else:
+                mt = (cout_w + 31) // 32
+                mmap = [m if m < cout_w else -1 for m in range(mt * 32)]
         else:
             # data-gradient: K axis = cout_w (upstream gradient channels), M axis = input channels laid out
             # [main groups | latent group]
             ncg_k = (cout_w + 7) // 8
             kmap = [c if c < cout_w else -1 for c in range(ncg_k * 8)]
+            if self.rows is not None:
+                assert len(self.rows) % 8 == 0
+                kmap = list(self.rows)
             if self.m_slice == 'latent':
                 mlist = list(range(lat))
             else:
@@ -177,10 +187,12 @@ class PackedConv:
         if self.wpack is None:
             dev = w.device
             self.kmap, self.mmap = self._maps(dev)
+            if self.rows is not None:
+                self._rows_t = torch.tensor(self.rows, dtype=torch.long, device=dev)
             nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, fmt_code(self.split))
             self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             bp = self.bias_p
-            if bp is not None and not self.transposed and bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == self.mtiles * 32:
+            if bp is not None and not self.transposed and self.rows is None and bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == self.mtiles * 32:
                 self.bias, self._bias_shared = bp.detach(), True        # the kernel reads the parameter itself: always current
             else:
                 self.bias, self._bias_shared = torch.zeros(self.mtiles * 32, dtype=torch.float32, device=dev), False
@@ -196,7 +208,10 @@ class PackedConv:
 
     def after_pack(self):
         if self.bias_p is not None and not self.transposed and not self._bias_shared:
-            self.bias[:self.weight.shape[0]].copy_(self.bias_p.detach().float())
+            if self.rows is not None:
+                self.bias[:len(self.rows)].copy_(self.bias_p.detach().float()[self._rows_t])
+            else:
+                self.bias[:self.weight.shape[0]].copy_(self.bias_p.detach().float())
         if self._bias_shared and self.bias.data_ptr() != self.bias_p.data_ptr():
             self.bias = self.bias_p.detach()      # the parameter's storage was replaced
         self._key = self.key()
@@ -312,7 +327,8 @@ ALTERNATE_ORDER = os.environ.get('ESR_ALTERNATE_ORDER', '1') != '0'
 
 
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
-            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0):
+            out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0,
+            pixel_shuffle=0, ps_rowgroup0=0):
     d = _lib.Conv3x3Desc()
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
@@ -340,7 +356,13 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
     d.reverse_order = 1 if reverse else 0
     d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
     d.in1_lo_groups = in1_lo_groups
+    d.pixel_shuffle, d.ps_rowgroup0 = pixel_shuffle, ps_rowgroup0
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
+
+
+def pixel_unshuffle(src, r, dst, B):
+    """dst[g*r^2 + s][y][x] = src[g][r*y + s//r][r*x + s%r]  (esr_pixel_unshuffle): adjoint of the conv kernel's pixel-shuffle store."""
+    check(_lib.lib.esr_pixel_unshuffle(C.byref(src), r, C.byref(dst), B, stream_ptr()), 'esr_pixel_unshuffle')
 
 
 def act_combine(out, B, A_=None, alpha=1.0, Bv=None, beta=1.0, s=1, mask=None, mask_slope=0.2):
@@ -472,16 +494,28 @@ def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, devi
     return dw, db
 
 
+_WGB = {}        # per device: (descriptor bytes, workspace tensor, plan) of the last batched weight-gradient launch
+
+
 def conv3x3_wgrad_batch(descs, device):
-    """All recorded layers' weight gradients in one launch (esr_conv3x3_wgrad_batch).  The caller keeps every dy / x buffer alive
-    and unmodified until this returns (the launch is enqueued behind the kernels that produced them)."""
+    """All recorded layers' weight gradients in one launch (esr_conv3x3_wgrad_batch_upload / _run).  The caller keeps every dy / x buffer
+    alive and unmodified until this returns (the launch is enqueued behind the kernels that produced them).  The descriptor table is
+    uploaded only when it differs from the previous call's: with pooled gradient buffers and the allocator handing back the same dW
+    storage, a steady-state training step re-runs the table that is already on the device (no host->device copy)."""
     if not descs:
         return
     arr = (_lib.WgradDesc * len(descs))(*descs)
-    need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, len(descs))
-    check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
-    ws = _wgrad_workspace(device, (need + 3) // 4)
-    check(_lib.lib.esr_conv3x3_wgrad_batch(arr, len(descs), ws.data_ptr(), ws.numel() * 4, stream_ptr()), 'esr_conv3x3_wgrad_batch')
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    raw = bytes(arr)
+    cached = _WGB.get(key)
+    if cached is None or cached[0] != raw:
+        need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, len(descs))
+        check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+        ws = cached[1] if (cached is not None and cached[1].numel() >= need) else torch.empty(int(need), dtype=torch.uint8, device=device)
+        plan = _lib.WgradBatchPlan()
+        check(_lib.lib.esr_conv3x3_wgrad_batch_upload(arr, len(descs), ws.data_ptr(), ws.numel(), C.byref(plan), stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
+        cached = _WGB[key] = (raw, ws, plan)
+    check(_lib.lib.esr_conv3x3_wgrad_batch_run(cached[1].data_ptr(), C.byref(cached[2]), stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
 
 
 _WS = {}

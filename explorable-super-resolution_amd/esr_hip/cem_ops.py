@@ -1,7 +1,9 @@
 """Host wrappers of the CEM kernels (csrc/esr_cem.hip).  fp32 NCHW in/out.  Differentiable: every op is linear with
 fixed taps, so its backward is the adjoint filter (esr_hip/autograd.py)."""
 import ctypes as C
+import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -15,12 +17,41 @@ def _prep(x, what):
     return x.contiguous()
 
 
-def _taps(t, dev):
+_TAPS = {}          # (storage, version, shape, device) of a tap tensor -> (fp32 device copy, rank-one factors (tv, th) or None)
+USE_SEPARABLE = os.environ.get('ESR_CEM_SEPARABLE', '1') != '0'
+
+
+def _taps_entry(t, dev):
+    """Device copy of a 2-D tap array and, when it is rank one (sigma_2 <= 1e-6 sigma_1: the bicubic ds_kernel and its inv_hTh, SURVEY.md
+    7.3), its 1-D factors taps = outer(tv, th) for the separable kernels.  Cached per tap tensor: the taps are construction-time constants
+    (frozen Filter_OP.weight), so steady-state calls do no host work and no host->device copy."""
     t = t.detach()
-    if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
-        t = t.to(device=dev, dtype=torch.float32).contiguous()
-    assert t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1, 'CEM filters are odd square 2-D arrays'
-    return t
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device), str(dev))
+    hit = _TAPS.get(key)
+    if hit is None:
+        assert t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1, 'CEM filters are odd square 2-D arrays'
+        d = t.to(device=dev, dtype=torch.float32).contiguous()
+        if d.data_ptr() == t.data_ptr():
+            d = d.clone()                    # the cache must not alias a tensor the caller may edit in place
+        a = t.double().cpu().numpy()
+        u, sv, vt = np.linalg.svd(a)
+        sep = None
+        if sv[0] > 0 and (len(sv) == 1 or sv[1] <= 1e-6 * sv[0]):
+            sgn = 1.0 if u[:, 0].sum() >= 0 else -1.0
+            tv, th = sgn * u[:, 0] * np.sqrt(sv[0]), sgn * vt[0] * np.sqrt(sv[0])
+            sep = (torch.tensor(tv, dtype=torch.float32, device=dev), torch.tensor(th, dtype=torch.float32, device=dev))
+        if len(_TAPS) > 64:
+            _TAPS.clear()
+        hit = _TAPS[key] = (d, sep)
+    return hit
+
+
+def _taps(t, dev):
+    return _taps_entry(t, dev)[0]
+
+
+def _sep(t, dev):
+    return _taps_entry(t, dev)[1] if USE_SEPARABLE else None
 
 
 def _needs_grad(*ts):
@@ -29,7 +60,7 @@ def _needs_grad(*ts):
 
 def downscale_raw(y, taps, sf, pre, lr=None, lr_pad=0):
     y = _prep(y, 'HR image')
-    taps = _taps(taps, y.device)
+    sep, taps = _sep(taps, y.device), _taps(taps, y.device)
     B, Cc, Hh, Wh = y.shape
     assert Hh % sf == 0 and Wh % sf == 0, 'HR size must be divisible by the scale factor'
     h, w = Hh // sf, Wh // sf
@@ -37,23 +68,34 @@ def downscale_raw(y, taps, sf, pre, lr=None, lr_pad=0):
     if lr is not None:
         lr = _prep(lr, 'LR image')
         assert lr.shape == (B, Cc, h - 2 * lr_pad, w - 2 * lr_pad), 'LR / HR sizes do not match'
-    check(_lib.lib.esr_cem_downscale(y.data_ptr(), B, Cc, h, w, sf, pre, taps.data_ptr(), taps.shape[0],
-                                     lr.data_ptr() if lr is not None else None, lr_pad, out.data_ptr(), stream_ptr()), 'esr_cem_downscale')
+    rc = _lib.ESR_E_UNSUPPORTED
+    if sep is not None:
+        rc = _lib.lib.esr_cem_downscale_sep(y.data_ptr(), B, Cc, h, w, sf, pre, sep[0].data_ptr(), sep[1].data_ptr(), taps.shape[0],
+                                            lr.data_ptr() if lr is not None else None, lr_pad, out.data_ptr(), stream_ptr())
+    if rc == _lib.ESR_E_UNSUPPORTED:
+        rc = _lib.lib.esr_cem_downscale(y.data_ptr(), B, Cc, h, w, sf, pre, taps.data_ptr(), taps.shape[0],
+                                        lr.data_ptr() if lr is not None else None, lr_pad, out.data_ptr(), stream_ptr())
+    check(rc, 'esr_cem_downscale')
     return out
 
 
 def lr_filter_raw(x, taps):
     x = _prep(x, 'LR image')
-    taps = _taps(taps, x.device)
+    sep, taps = _sep(taps, x.device), _taps(taps, x.device)
     B, Cc, h, w = x.shape
     out = torch.empty_like(x)
-    check(_lib.lib.esr_cem_lrfilter(x.data_ptr(), B, Cc, h, w, taps.data_ptr(), taps.shape[0], out.data_ptr(), stream_ptr()), 'esr_cem_lrfilter')
+    rc = _lib.ESR_E_UNSUPPORTED
+    if sep is not None:
+        rc = _lib.lib.esr_cem_lrfilter_sep(x.data_ptr(), B, Cc, h, w, sep[0].data_ptr(), sep[1].data_ptr(), taps.shape[0], out.data_ptr(), stream_ptr())
+    if rc == _lib.ESR_E_UNSUPPORTED:
+        rc = _lib.lib.esr_cem_lrfilter(x.data_ptr(), B, Cc, h, w, taps.data_ptr(), taps.shape[0], out.data_ptr(), stream_ptr())
+    check(rc, 'esr_cem_lrfilter')
     return out
 
 
 def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0):
     f = _prep(f, 'LR image')
-    taps = _taps(taps, f.device)
+    sep, taps = _sep(taps, f.device), _taps(taps, f.device)
     B, Cc, h, w = f.shape
     Ho, Wo = sf * h - 2 * crop, sf * w - 2 * crop
     out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=f.device)
@@ -63,9 +105,15 @@ def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0):
     if g is not None:
         g = _prep(g, 'generated image')
         assert g.shape == (B, Cc, sf * h, sf * w)
-    check(_lib.lib.esr_cem_upscale(f.data_ptr(), f2.data_ptr() if f2 is not None else None, B, Cc, h, w, sf, pre, taps.data_ptr(), taps.shape[0],
-                                   g.data_ptr() if g is not None else None, crop, mode, float(rng), out.data_ptr(),
-                                   out2.data_ptr() if out2 is not None else None, stream_ptr()), 'esr_cem_upscale')
+    tail = (g.data_ptr() if g is not None else None, crop, mode, float(rng if rng is not None else 0.0), out.data_ptr(), out2.data_ptr() if out2 is not None else None,
+            stream_ptr())
+    head = (f.data_ptr(), f2.data_ptr() if f2 is not None else None, B, Cc, h, w, sf, pre)
+    rc = _lib.ESR_E_UNSUPPORTED
+    if sep is not None:
+        rc = _lib.lib.esr_cem_upscale_sep(*head, sep[0].data_ptr(), sep[1].data_ptr(), taps.shape[0], *tail)
+    if rc == _lib.ESR_E_UNSUPPORTED:
+        rc = _lib.lib.esr_cem_upscale(*head, taps.data_ptr(), taps.shape[0], *tail)
+    check(rc, 'esr_cem_upscale')
     return (out, out2) if mode == 3 else out
 
 

@@ -55,8 +55,13 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank `src`'s weights (once, at construction: afterwards identical updates keep them equal)."""
     if not is_distributed():
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)
+    # a collective writing into a parameter does not necessarily bump its version counter: tell the kernels' weight packs explicitly
+    for m in module.modules():
+        if hasattr(m, 'invalidate_packs'):
+            m.invalidate_packs()
 
 
 class GradBucketAllReducer:

@@ -40,6 +40,7 @@ class RRDBEngine:
         self._bufs = {}
         self._gpool, self._gpool_key = {}, None
         self._pack_batch = A.PackBatch()
+        self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
@@ -55,6 +56,16 @@ class RRDBEngine:
             self._bufs = {}
 
     # ------------------------------------------------------------------ weights
+    def invalidate(self):
+        """Force every weight pack to be rebuilt at the next forward / backward.  Packs are refreshed automatically when a parameter's
+        (storage, torch version counter) changes — optimizer steps, load_state_dict, in-place ops on the parameter all bump the counter —
+        but writes through `.data` (p.data.mul_(2), dist.broadcast(p.data), the reference's m.bias.data.zero_()) do NOT: after such an
+        edit call this (RRDBNet.invalidate_packs(); esr_hip.dist.broadcast_parameters does)."""
+        for d in (self._packed, self._packed_t, self._packed_rdb_t):
+            for p in (d or {}).values():
+                p._key = None
+        self.generation += 1
+
     def _convs(self):
         """(name, conv module, n_latent) in execution order, following the reference's module tree (walked once: the tree is static)."""
         if self._convs_cache is None:
@@ -112,9 +123,28 @@ class RRDBEngine:
             return self.split
         return 'f16x2' if name.startswith('rrdb') else 'f16x3'
 
+    @property
+    def _pshuf(self):
+        """Pixel-shuffle upsamplers (block.py:278-291): the shuffle factor, or 0 for the reference's default nearest + conv ('upconv')."""
+        return 0 if self.net.upsample_mode == 'upconv' else (3 if self.net.upscale == 3 else 2)
+
+    def _ps_rows(self, q=None):
+        """Conv output channels of a pixel-shuffle upsampler in the kernel's row-group order (esr_conv3x3_desc.pixel_shuffle): row group
+        g = (output group g // r^2, sub-position g % r^2); launch q covers row groups 8q .. 8q+7, q = None all of them."""
+        r2 = self._pshuf ** 2
+        groups = range(8 * r2) if q is None else range(8 * q, min(8 * q + 8, 8 * r2))
+        return [((g // r2) * 8 + e) * r2 + g % r2 for g in groups for e in range(8)]
+
     def packed(self):
         if self._packed is None:
-            self._packed = {name: A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name)) for name, c, lat in self._convs()}
+            d = {}
+            for name, c, lat in self._convs():
+                if name.startswith('up') and self._pshuf:
+                    for q in range(self._pshuf ** 2):         # 64 * r^2 conv channels = r^2 launches of 64 rows
+                        d[name, q] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name), rows=self._ps_rows(q))
+                else:
+                    d[name] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name))
+            self._packed = d
         self._refresh_packs()
         return self._packed
 
@@ -127,8 +157,9 @@ class RRDBEngine:
                 if name.startswith('rrdb'):
                     continue                  # dense blocks: packed_rdb_t()
                 main = c.weight.shape[1] - lat
+                rows = self._ps_rows() if (name.startswith('up') and self._pshuf) else None      # K axis in esr_pixel_unshuffle's order
                 for j in range((main + 63) // 64):
-                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)))
+                    d[name, 'm%d' % j] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice=(64 * j, min(main, 64 * j + 64)), rows=rows)
                 if lat:
                     d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice='latent')
             self._packed_t = d
@@ -221,9 +252,6 @@ class RRDBEngine:
 
     def _check(self, x):
         net = self.net
-        if net.upsample_mode != 'upconv':
-            raise NotImplementedError("upsample_mode='pixelshuffle' is constructible (state_dict parity) but only 'upconv' — the mode the "
-                                      "reference hard-wires for RRDB_net (networks.py:99) — is executed by the HIP engine")
         sf = net.upscale
         has_lat = net.latent_input is not None and net.num_latent_channels > 0
         lat1 = net.num_latent_channels if has_lat else 0
@@ -302,7 +330,11 @@ class RRDBEngine:
         for j in range(self.n_up):
             f = 3 if sf == 3 else 2
             s *= f
-            conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view())
+            if self._pshuf:     # conv 64 -> 64*f^2 at the INPUT resolution, pixel shuffle folded into the store, LeakyReLU before it (it commutes)
+                for q in range(f * f):
+                    conv(pk['up%d' % j, q], src.view(), B, s // f * h, s // f * w, 64, act_slope=0.2, out=bufs['ups'][j].view(), pixel_shuffle=f, ps_rowgroup0=8 * q)
+            else:
+                conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view())
             src = bufs['ups'][j]
         conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view())
         g = torch.empty(B, net.out_nc, H, W, dtype=torch.float32, device=x.device)
@@ -417,6 +449,17 @@ class RRDBEngine:
             f = 3 if sf == 3 else 2
             Hj, Wj = s * h, s * w
             below = bufs['ups'][j - 1] if j > 0 else bufs['trunk']
+            if self._pshuf:
+                # cur_g = d(shuffled, pre-activation conv output); back to the conv's own channel layout (row-group order), then the plain
+                # weight / data gradients of a 64 -> 64*f^2 conv at the lower resolution
+                s //= f
+                Gc = galloc(B, 8 * f * f, s * h, s * w)
+                A.pixel_unshuffle(cur_g.view(), f, Gc.view(), B)
+                wg.conv('up%d' % j, Gc.view(), below.view(), None, s * h, s * w, keep=(Gc, cur_g), rows=self._ps_rows())
+                nxt_g = galloc(B, 8, s * h, s * w)
+                dgrad('up%d' % j, Gc.view(), nxt_g, 0, 8, s * h, s * w, mask=(below, 0, 8) if j > 0 else None)
+                cur_g = nxt_g
+                continue
             wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f, keep=(cur_g,))
             tmp = galloc(B, 8, Hj, Wj)
             dgrad('up%d' % j, cur_g.view(), tmp, 0, 8, Hj, Wj)
@@ -536,7 +579,7 @@ class WGrad:
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
-        self.descs, self.keep = [], []
+        self.descs, self.keep, self.permuted = [], [], []
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0
@@ -545,7 +588,8 @@ class WGrad:
                 n += c.weight.numel() + c.weight.shape[0]
             self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(self.mods.values())).weight.device)
 
-    def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=()):
+    def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=(), rows=None):
+        """rows: dy's channels are a permutation of the layer's output channels (pixel-shuffle convs): dy channel i is output channel rows[i]."""
         if not self.enabled:
             return
         c = self.mods[name]
@@ -553,11 +597,17 @@ class WGrad:
             dy, x_main, x_lat = A.hi_plane(dy), A.hi_plane(x_main), A.hi_plane(x_lat)
         o, nw = self.offsets[name], c.weight.numel()
         out = (self.flat[o:o + nw].view(c.weight.shape), self.flat[o + nw:o + nw + c.weight.shape[0]])
+        if rows is not None:       # accumulate in dy's channel order, un-permute after the launch (result())
+            tmp = (torch.zeros_like(out[0]), torch.zeros_like(out[1]))
+            self.permuted.append((tmp, out, torch.tensor(rows, dtype=torch.long, device=out[0].device)))
+            final, out = out, tmp
         if self.gscale is not None:
             self.scaled.append((o, nw + c.weight.shape[0], self.gscale))
         d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device, out=out)
         self.descs.append(d)
         self.keep.extend(keep)
+        if rows is not None:
+            dw, db = final
         self.grads[c.weight] = dw
         if c.bias is not None:
             self.grads[c.bias] = db
@@ -567,6 +617,9 @@ class WGrad:
     def result(self):
         if self.enabled and self.descs:
             A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device)
+            for (tdw, tdb), (dw, db), rows in self.permuted:
+                dw.index_copy_(0, rows, tdw)
+                db.index_copy_(0, rows, tdb)
             # undo the gradient scaling: consecutive layers recorded under the same scale are contiguous in `flat` more often than not
             runs = []
             for o, n, g in sorted(self.scaled, key=lambda t: t[0]):

@@ -15,6 +15,8 @@ must survive the next call.
 """
 import torch
 
+from ._lib import EsrError
+
 
 class GraphedForward:
     def __init__(self, module, max_graphs=4):
@@ -22,10 +24,14 @@ class GraphedForward:
         self._graphs = {}
 
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        # (storage, version) of every parameter plus the engines' invalidation counters: `.data` edits do not bump a version (see
+        # RRDBEngine.invalidate), an explicit invalidate() does bump the counter
+        engines = tuple(m.engine.generation for m in self.module.modules() if hasattr(m, 'invalidate_packs'))
+        return tuple((p.data_ptr(), p._version) for p in self.module.parameters()) + engines
 
     def __call__(self, x):
-        assert x.is_cuda and not torch.is_grad_enabled() or not x.requires_grad, 'GraphedForward is an inference path'
+        if not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad):
+            raise EsrError('GraphedForward is an inference path: it takes a GPU tensor that does not require grad')
         key = (tuple(x.shape), x.dtype, x.device.index)
         entry = self._graphs.get(key)
         pkey = self._param_key()

@@ -94,6 +94,15 @@ class SRRaGANModel(BaseModel):
                 self.netD = networks.define_D(opt, CEM=self.CEM_net).to(self.device)
                 esr_dist.broadcast_parameters(self.netD)
                 self.netD.train()
+                # network_D.precision = 'bf16': the critic's convolutions run under bf16 autocast (fp32 parameters, fp32 losses; configs[2] of
+                # BASELINE.json names bf16); default: fp32 like the reference.  network_D.channels_last: NHWC activations for MIOpen.
+                self.D_dtype = torch.bfloat16 if (net_D.get('precision') or os.environ.get('ESR_D_PRECISION')) == 'bf16' else None
+                if net_D.get('channels_last') or os.environ.get('ESR_D_CHANNELS_LAST') == '1':
+                    self.netD = self.netD.to(memory_format=torch.channels_last)
+                # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (measured on the configs[2] shapes: no gain
+                # over the default heuristics, 20.0 vs 20.4 ms per D step, and tens of seconds of search at start-up: off by default)
+                if net_D.get('miopen_find') or os.environ.get('ESR_D_MIOPEN_FIND') == '1':
+                    torch.backends.cudnn.benchmark = True
             self.cri_pix = None
             if train_opt['pixel_weight'] is not None:
                 l_pix_type = train_opt['pixel_criterion']
@@ -217,6 +226,13 @@ class SRRaGANModel(BaseModel):
         replay the reference's draws."""
         return torch.rand(batch_size, 1, 1, 1, device=self.device)
 
+    def _D(self, x):
+        """The critic's logits in fp32 (under bf16 autocast when network_D.precision = 'bf16')."""
+        if self.D_dtype is None:
+            return self.netD(x)
+        with torch.autocast(device_type='cuda', dtype=self.D_dtype):
+            return self.netD(x).float()
+
     def _tick(self, name):
         """Phase timer (only when self.timing is a dict): GPU time since the previous tick is charged to `name`."""
         if self.timing is None:
@@ -276,8 +292,8 @@ class SRRaGANModel(BaseModel):
                     self.optimizer_D.zero_grad()
                     self._d_acc = {k: [] for k in ('l_d_real', 'l_d_fake', 'D_real', 'D_fake', 'D_logits_diff')}
                 if first_dual:
-                    pred_d_real = self.netD(self.var_ref)
-                pred_d_fake = self.netD(self.fake_H.detach())
+                    pred_d_real = self._D(self.var_ref)
+                pred_d_fake = self._D(self.fake_H.detach())
                 if self.relativistic_D:
                     assert train_opt['hinge_threshold'] is None, 'Unsupported yet, should think whether it reuires special adaptation of hinge loss'
                     l_d_real = self.cri_gan(pred_d_real - torch.mean(pred_d_fake), True)
@@ -290,7 +306,7 @@ class SRRaGANModel(BaseModel):
                 if train_opt['gan_type'] == 'wgan-gp':
                     pt = self._draw_interp_points(self.var_ref.size(0))
                     interp = (pt * self.fake_H.detach() + (1 - pt) * self.var_ref).requires_grad_(True)
-                    l_d_gp = self.l_gp_w * self.cri_gp(interp, self.netD(interp))
+                    l_d_gp = self.l_gp_w * self.cri_gp(interp, self._D(interp))
                     l_d_total = l_d_total + l_d_gp
                 logits_diff = torch.mean(pred_d_real.detach() - pred_d_fake.detach(), dim=list(range(1, pred_d_real.dim())))
                 self._d_acc['l_d_real'].append(l_d_real.detach()); self._d_acc['l_d_fake'].append(l_d_fake.detach())
@@ -347,9 +363,9 @@ class SRRaGANModel(BaseModel):
                     l_g_total = l_g_total + self.l_g_optimalZ_w * l_g_optimalZ / acc_G
                     self._g_acc['l_g_optimalZ'].append(l_g_optimalZ.detach())
                 if self.D_exists:
-                    pred_g_fake = self.netD(self.fake_H)
+                    pred_g_fake = self._D(self.fake_H)
                     if self.relativistic_D:
-                        pred_d_real = self.netD(self.var_ref).detach()
+                        pred_d_real = self._D(self.var_ref).detach()
                         l_g_gan = self.l_gan_w * (self.cri_gan(pred_d_real - torch.mean(pred_g_fake), False) +
                                                   self.cri_gan(pred_g_fake - torch.mean(pred_d_real), True)) / 2 / scale
                     else:

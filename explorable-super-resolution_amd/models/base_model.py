@@ -80,8 +80,11 @@ class BaseModel():
         network.load_state_dict(loaded, strict=strict)
 
     def Set_Require_Grad_Status(self, network, status):
-        for p in network.parameters():
-            p.requires_grad = status
+        # (the CEM's fixed filter taps stay frozen: the reference flips them too, harmlessly — they are in no optimizer — but autograd then
+        # spends a depth-wise weight gradient on them every step)
+        for name, p in network.named_parameters():
+            if 'Filter_OP' not in name:
+                p.requires_grad = status
 
     def process_loaded_state_dict(self, loaded_state_dict, current_state_dict):
         """Positional key matching + latent zero-extension (reference base_model.py:146-190)."""

@@ -90,6 +90,11 @@ class RRDBNet(nn.Module):
         assert precision in ('split', 'mixed', 'f16x2', 'f16', 'bf16')
         self.engine.set_precision(precision)
 
+    def invalidate_packs(self):
+        """Call after editing parameters through `.data` (such writes bypass torch's version counters, which is what the engine watches)."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
     def forward(self, x, pad=0):
         """x: [B, num_latent_channels*upscale^2 + 3, h, w] (Z packed by the raw view of SRRaGAN_model.py:233, LR image last).
         `pad` > 0 evaluates the generator on the replicate-padded input (CEM eval mode, CEMnet.py:286-295) without
@@ -144,5 +149,5 @@ class Discriminator_VGG_128(nn.Module):
     def forward(self, x):
         x = self.features(x)
         if self.last_FC_layers:
-            x = x.view(x.size(0), -1)
+            x = x.reshape(x.size(0), -1)          # (NCHW order also when the features ran channels_last)
         return self.classifier(x)

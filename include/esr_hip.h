@@ -11,7 +11,11 @@
  *   - plain C: pointers + sizes only; every pointer is a caller-owned DEVICE pointer unless it is a
  *     descriptor struct (host memory, read during the call).
  *   - return 0 on success, <0 on bad argument / unsupported shape (ESR_E_*); never throws, never
- *     allocates device memory, never synchronises: work is enqueued on `stream` (hipStream_t).
+ *     allocates device memory, never synchronises the stream: work is enqueued on `stream`
+ *     (hipStream_t).  Two entry points copy a HOST descriptor table to the device
+ *     (esr_pack_batch_upload, esr_conv3x3_wgrad_batch[_upload]): pageable memory, staged by the
+ *     runtime before the call returns — host-blocking for the duration of that staging and not
+ *     capturable in a HIP graph; their *_run counterparts have no host traffic.
  *   - stateless and thread-safe: one process per GPU or several host threads may call concurrently.
  *
  * Internal activation layout ("act view"), used between the conv kernels so that dense-block
@@ -103,9 +107,21 @@ typedef struct {
      * them are single-plane intermediates (a dense block's conv outputs, consumed only inside the block, where 11 bits suffice): their
      * lo plane is neither read nor multiplied.  Likewise `out.lo == NULL` with hi+lo inputs stores the result as one fp16 plane. */
     int32_t in1_lo_groups;
+    /* pixel-shuffle store (codes/models/modules/block.py:278-291: conv to out_nc*r^2 channels, nn.PixelShuffle(r), act): with
+     * pixel_shuffle = r > 1 the launch's output rows are taken in groups of 8 ("row groups"); row group g = ps_rowgroup0 + (row / 8)
+     * holds the 8 channels of output group g / r^2 at sub-position s = g % r^2, and is stored to out[group][r*y + s / r][r*x + s % r]
+     * (out.H == r*H, out.W == r*W).  The caller packs the weights with the matching row map: row -> conv channel
+     * ((g / r^2)*8 + row % 8) * r^2 + s.  The activation commutes with the shuffle and is applied before it.  0: plain store. */
+    int32_t pixel_shuffle;
+    int32_t ps_rowgroup0;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
+
+/* Adjoint of the pixel-shuffle store: dst[b][g*r^2 + s][y][x] = src[b][g][r*y + s / r][r*x + s % r] for every group g of `src`
+ * (dst.ncg == src.ncg * r^2, src.H == r*dst.H): the gradient of the shuffled tensor laid out in the conv's row-group order
+ * (autograd of nn.PixelShuffle, block.py:287). */
+int esr_pixel_unshuffle(const esr_act_view* src, int r, const esr_act_view* dst, int B, esr_stream_t stream);
 
 /* Packed-weight size in bytes for `ncg_in` input groups and `cout` output channels
  * (`split` = 1: bf16 hi+lo planes; 0: bf16 hi only; 2: f16, one plane; 3: f16 hi+lo planes). */
@@ -177,6 +193,17 @@ int esr_cem_upscale(const float* f, const float* f2, int B, int C, int h, int w,
                     const float* taps, int k, const float* g, int crop, int mode, float range,
                     float* out, float* out2, esr_stream_t stream);
 
+/* Separable variants of the three CEM filters for rank-one taps  taps[a][b] = tv[a] * th[b]  (the bicubic ds_kernel and its inv_hTh are
+ * rank one; estimated / anisotropic kernels are not and use the 2-D entry points): a horizontal and a vertical 1-D pass on the tile a
+ * workgroup holds on chip, 2k instead of k^2 MACs per output.  Arguments, index conventions, fused forms and results as esr_cem_downscale /
+ * esr_cem_lrfilter / esr_cem_upscale (up to fp32 rounding of the tap products); `tv`, `th`: device arrays of k floats.
+ * ESR_E_UNSUPPORTED: the tile does not fit on chip for this (sf, k) — use the 2-D entry point. */
+int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k, const float* lr,
+                          int lr_pad, float* d, esr_stream_t stream);
+int esr_cem_lrfilter_sep(const float* x, int B, int C, int h, int w, const float* tv, const float* th, int k, float* out, esr_stream_t stream);
+int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k,
+                        const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream);
+
 /* ---- backward-pass helpers (autograd of the reference's torch ops) ----
  * out = alpha*A + beta*sumpool_s(Bv), optionally * LeakyReLU'(mask) — gradient of the nearest upsample
  * (block.py:293-300), of residual sums, and of LeakyReLU (block.py:18).  A / Bv / mask may be NULL. */
@@ -230,6 +257,14 @@ int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream);
  * All dy / x buffers must stay alive and unmodified until the launch has run; every layer must use the same operand format. */
 int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc* descs, int n);
 int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
+/* The same in two steps, for callers whose descriptor set repeats from one backward pass to the next (pooled gradient buffers, the
+ * allocator handing back the same dW storage): _upload writes the descriptor table into `workspace` (a host-blocking copy from pageable
+ * memory: NOT capturable in a HIP graph) and fills `plan`; _run enqueues the launch from the table already on the device (capturable; no
+ * host traffic).  esr_conv3x3_wgrad_batch == _upload followed by _run. */
+typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16; } esr_wgrad_batch_plan;
+int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
+                                   esr_stream_t stream);
+int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
 
 int esr_version(void);
 

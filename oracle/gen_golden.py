@@ -200,6 +200,31 @@ def gen_F8():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_first_layer.npz'), **out)
 
 
+def gen_F9():
+    """RRDBNet(upsample_mode='pixelshuffle') (architecture.py:254-259 -> block.py:278-291): forward, input gradient, weight-gradient digests."""
+    import models.modules.architecture as arch
+    out = {}
+    for name, nb, sf, lat in [('nb1_x4_ps', 1, 4, 0), ('nb2_x2_ps', 2, 2, 0)]:      # (with a latent input the reference's forward fails: it concatenates Z in front of the shuffle block)
+        torch.manual_seed(0)
+        net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='pixelshuffle',
+                           latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+        n = fill_formula_weights(net, gain=1.0)
+        x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 81 + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+        if lat:
+            x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+        x.requires_grad_(True)
+        y = net(x)
+        cot = seeded_uniform(tuple(y.shape), 91 + nb + sf + lat, -1.0, 1.0)
+        (y * cot).sum().backward()
+        out[name + '/out'] = y.detach().numpy()
+        out[name + '/dx'] = x.grad.numpy()
+        out[name + '/dparams'] = np.stack([_param_digest(p.grad) for _, p in net.named_parameters()])
+        out[name + '/keys'] = np.array(list(net.state_dict().keys()))
+        out[name + '/nparams'] = np.array([n, sum(p.numel() for p in net.parameters())])
+        print(name, tuple(y.shape), float(y.detach().abs().mean()), float(x.grad.abs().mean()))
+    np.savez_compressed(os.path.join(GOLDEN, 'rrdb_pixelshuffle.npz'), **out)
+
+
 def _wrapped_G(nb, sf, lat=0, kernel=None, gain=1.0):
     import models.modules.architecture as arch
     cem = _cem(sf, kernel)
@@ -369,7 +394,7 @@ def gen_F7():
     np.savez_compressed(os.path.join(GOLDEN, 'callers_f7.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8}
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9}
 
 if __name__ == '__main__':
     _refshim.install()

@@ -324,3 +324,56 @@ def test_c2_rrdb23_probe_matches_reference_golden(precision, tol):
     e1, e2 = rel_l2(y[:, :, 200:264, 300:364], g['crop64']), rel_l2(y[:, :, 3::8, 5::8], g['stride8'])
     print("F6 %s: crop %.2e stride8 %.2e" % (precision, e1, e2))
     assert e1 < tol and e2 < tol, (precision, e1, e2)
+
+
+# ---- separable CEM fast path (rank-one taps: bicubic ds_kernel / inv_hTh) against the general 2-D kernels
+@pytest.mark.parametrize('sf,kernel', [(2, None), (3, None), (4, None), (8, None), (4, 'blurry_cubic_1.0')])
+def test_separable_cem_kernels_match_the_2d_kernels(sf, kernel):
+    """The three filters and the fused projection (all modes) evaluated by the separable kernels (esr_cem_*_sep: tv (x) th factors of the
+    taps, 2k MACs per output) and by the 2-D kernels (k^2 MACs): same index conventions (strided pick at sf*i+pre, zero-stuffing offset,
+    replicate clamps, crop), results equal to fp32 rounding of the tap products."""
+    from esr_hip import cem_ops
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    import CEM.CEMnet as C
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    td, ti, tu = G.DownscaleOP.taps(), G.Conv_LR_with_Inv_hTh_OP.taps(), G.Upscale_OP.taps()
+    assert all(cem_ops._taps_entry(t, torch.device(DEV, 0))[1] is not None for t in (td, ti, tu)), 'bicubic-family kernels are rank one'
+    pre = sf - sf // 2 - 1
+    h, w = 21, 37
+    y = seeded_uniform((2, 3, sf * h, sf * w), 301).to(DEV)
+    lr = seeded_uniform((2, 3, h - 6, w - 6), 302).to(DEV)
+    x = seeded_uniform((2, 3, h, w), 303, -1.0, 1.0).to(DEV)
+    x2 = seeded_uniform((2, 3, h, w), 304, -1.0, 1.0).to(DEV)
+
+    def run():
+        out = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=3), cem_ops.lr_filter_raw(x, ti),
+               cem_ops.upscale_raw(x, tu, sf, pre), cem_ops.upscale_raw(x, tu, sf, pre, g=y, crop=2 * sf, mode=1),
+               cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=sf, mode=2, rng=1.0)]
+        out += list(cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=0, mode=3))
+        return out
+    try:
+        cem_ops.USE_SEPARABLE = True
+        a = run()
+        cem_ops.USE_SEPARABLE = False
+        b = run()
+    finally:
+        cem_ops.USE_SEPARABLE = True
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert u.shape == v.shape
+        assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max())), (i, float((u - v).abs().max()))
+
+
+def test_anisotropic_kernels_keep_the_2d_path():
+    from esr_hip import cem_ops
+    from oracle.gen_golden import aniso_gaussian_kernel
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    import CEM.CEMnet as C
+    conf = C.Get_CEM_Conf(4)
+    conf.lower_magnitude_bound = 0.1
+    cem = C.CEMnet(conf, upscale_kernel=aniso_gaussian_kernel())
+    G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    assert cem_ops._taps_entry(G.DownscaleOP.taps(), torch.device(DEV, 0))[1] is None
+    imresize.kernels = {}

@@ -232,3 +232,41 @@ def test_rrdb_first_layer_latent_matches_reference(name, nb, sf, lat):
     cot = seeded_uniform(tuple(y.shape), 71 + nb + sf + lat, -1.0, 1.0)
     (y * cot).sum().backward()
     assert rel_l2(x.grad.numpy(), g[name + '/dx']) < 5e-6
+
+
+# ---- F9: RRDBNet(upsample_mode='pixelshuffle') (architecture.py:254-259 -> block.py:278-291)
+F9_CASES = [('nb1_x4_ps', 1, 4, 0), ('nb2_x2_ps', 2, 2, 0)]
+
+
+def pixelshuffle_keys(nb, sf):
+    """The pixel-shuffle block is Sequential(conv 64 -> 64*r^2, PixelShuffle, act): its conv is child 0 (upconv: child 1) and has r^2 x the rows."""
+    keys, shapes = rrdb_keys(nb, sf, 0)
+    r = 3 if sf == 3 else 2
+    n_up = 1 if sf == 3 else int(np.log2(sf))
+    for j in range(n_up):
+        for i, k in enumerate(keys):
+            if k.startswith('model.%d.1.' % (2 + j)):
+                keys[i] = k.replace('model.%d.1.' % (2 + j), 'model.%d.0.' % (2 + j))
+                shapes[i] = (64 * r * r,) + tuple(shapes[i][1:])
+    return keys, shapes
+
+
+@pytest.mark.parametrize('name,nb,sf,lat', F9_CASES, ids=[c[0] for c in F9_CASES])
+def test_rrdb_pixelshuffle_matches_reference(name, nb, sf, lat):
+    g = load('rrdb_pixelshuffle.npz')
+    keys, shapes = pixelshuffle_keys(nb, sf)
+    assert keys == [str(k) for k in g[name + '/keys']]
+    sd = formula_state_dict(keys, shapes)
+    assert int(g[name + '/nparams'][1]) == sum(int(np.prod(s)) for s in shapes)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = seeded_uniform((1, 3, 12, 16), 81 + nb + sf + lat).requires_grad_(True)
+    y = ro.rrdb_forward(sd, x, nb, sf, lat, upsample_mode='pixelshuffle')
+    assert rel_l2(y.detach().numpy(), g[name + '/out']) < 2e-6
+    cot = seeded_uniform(tuple(y.shape), 91 + nb + sf + lat, -1.0, 1.0)
+    (y * cot).sum().backward()
+    assert rel_l2(x.grad.numpy(), g[name + '/dx']) < 5e-6
+    dig = g[name + '/dparams']
+    for j, k in enumerate(keys):
+        f = sd[k].grad.reshape(-1).double()
+        assert abs(float(f.norm()) - dig[j][1]) <= 1e-5 * max(dig[j][1], 1e-6), k
