@@ -3,9 +3,10 @@
     Z = Z_range*tanh(P)  ->  model.feed_data({'LR', 'Z'})  ->  model.test(prevent_grads_calc=False)   (G + CEM forward WITH graph,
     weights frozen)  ->  clamp(0,1)  ->  objective  ->  loss.mean().backward()  (data-gradient kernels only)  ->  Adam step,
 keeping the iterate with the smallest loss.  The forward/backward are the HIP kernels; the objectives below are element-wise /
-reduction torch ops on the SR output.  Implemented objectives: 'max_STD', 'min_STD', 'STD_increase', 'STD_decrease', 'TV', 'l1'
-(whole-image, no user masks).  The GUI's scribble / histogram / periodicity / dictionary / adversarial objectives are outside
-the hot path and raise NotImplementedError.
+reduction torch ops on the SR output.  Implemented objectives: 'max_STD', 'min_STD', 'STD_increase', 'STD_decrease', 'TV', 'l1',
+whole-image or restricted to a user-marked region (image_mask: where the objective looks; Z_mask: which latent entries may move — the
+GUI's region tools, GUI.py:1925-2057).  The GUI's scribble / histogram / periodicity / dictionary / adversarial / 'local_*' patch objectives are
+not part of this build and raise NotImplementedError.
 
 Multi-GPU: the Z batch is sharded over ranks (independent samples, no data-path collective).  Like the reference, the loss is the
 mean over the WHOLE batch, so each shard scales its local sum by 1/B_global; the loss history that picks the best iterate is
@@ -71,9 +72,10 @@ class Z_optimizer():
 
     def __init__(self, objective, Z_size, model, Z_range, max_iters, data=None, loggers=None, image_mask=None, Z_mask=None, initial_Z=None,
                  initial_LR=None, existing_optimizer=None, batch_size=1, HR_unpadder=None, random_Z_inits=False, **unsupported):
-        if objective not in self.SUPPORTED or image_mask is not None or Z_mask is not None:
-            raise NotImplementedError("Z objective '%s' (or user masks): only the whole-image objectives %s are implemented; the GUI's other "
-                                      "editing objectives are outside the RRDB+CEM hot path" % (objective, self.SUPPORTED))
+        if objective not in self.SUPPORTED or ((image_mask is not None or Z_mask is not None) and 'l1' in objective):
+            raise NotImplementedError("Z objective '%s': implemented are %s (optionally with image_mask / Z_mask, except 'l1'); the GUI's other "
+                                      "editing objectives are not part of this build" % (objective, self.SUPPORTED))
+        assert (image_mask is None) == (Z_mask is None), 'Should either supply both masks or niether'        # (reference :384)
         self.objective, self.model, self.data, self.loggers = objective, model, data, loggers
         self.device = model.device
         initial_pre_tanh_Z = None
@@ -88,10 +90,14 @@ class Z_optimizer():
         local_bs = self.shard[1] - self.shard[0]
         if initial_pre_tanh_Z is not None and initial_pre_tanh_Z.size(0) == batch_size and batch_size > 1:
             initial_pre_tanh_Z = initial_pre_tanh_Z[self.shard[0]:self.shard[1]]
+        if Z_mask is not None and initial_pre_tanh_Z is None:       # a masked search keeps the unmasked entries at the model's current latent
+            z_now = model.GetLatent() / Z_range
+            eps = torch.finfo(z_now.dtype).eps
+            initial_pre_tanh_Z = ArcTanH(torch.clamp(z_now, min=-1 + eps, max=1. - eps))
         self.Z_model = Optimizable_Z(Z_shape=[local_bs, model.num_latent_channels] + list(Z_size), Z_range=Z_range,
-                                     initial_pre_tanh_Z=initial_pre_tanh_Z, random_perturbations=random_Z_inits, device=self.device)
+                                     initial_pre_tanh_Z=initial_pre_tanh_Z, Z_mask=Z_mask, random_perturbations=random_Z_inits, device=self.device)
         assert (initial_LR is not None) or (existing_optimizer is not None), 'Should either supply optimizer from previous iterations or initial LR for new optimizer'
-        self.image_mask = None
+        self.image_mask = None if image_mask is None else torch.from_numpy(np.asarray(image_mask, dtype=np.float32)).to(self.device)
         if not self.model_training and 'fake_H' in model.__dict__:
             self.initial_output = model.Output_Batch(within_0_1=True).detach()
             # every sample's own initial STD (the reference's first_image_only flag is honoured by its 'local' objectives only,
@@ -117,7 +123,8 @@ class Z_optimizer():
 
     def Masked_STD(self, first_image_only=False):
         # whole-image objectives: the STD of EVERY sample, [1, B], whatever the flag says (as the reference, see __init__)
-        return torch.std(self.model.Output_Batch(within_0_1=True), dim=(1, 2, 3)).view(1, -1)
+        out = self.model.Output_Batch(within_0_1=True)
+        return torch.std(out if self.image_mask is None else out * self.image_mask, dim=(1, 2, 3)).view(1, -1)
 
     def feed_data(self, data):
         self.data = data
@@ -173,7 +180,8 @@ class Z_optimizer():
             if 'l1' in self.objective:
                 Z_loss = (self.output_image - self.desired_im).abs().mean(dim=(1, 2, 3))
             elif 'TV' in self.objective:
-                Z_loss = (self.STD_PRESERVING_WEIGHT * (self.Masked_STD() - self.initial_STD) ** 2).mean(0) + TV_Loss(self.output_image)
+                Z_loss = (self.STD_PRESERVING_WEIGHT * (self.Masked_STD() - self.initial_STD) ** 2).mean(0) + \
+                    TV_Loss(self.output_image if self.image_mask is None else self.output_image * self.image_mask)
             else:
                 Z_loss = self.Masked_STD()
                 if any(p in self.objective for p in ['increase', 'decrease']):

@@ -17,22 +17,29 @@ def _prep(x, what):
     return x.contiguous()
 
 
-_TAPS = {}          # (storage, version, shape, device) of a tap tensor -> (fp32 device copy, rank-one factors (tv, th) or None)
 USE_SEPARABLE = os.environ.get('ESR_CEM_SEPARABLE', '1') != '0'
 
 
 def _taps_entry(t, dev):
     """Device copy of a 2-D tap array and, when it is rank one (sigma_2 <= 1e-6 sigma_1: the bicubic ds_kernel and its inv_hTh, SURVEY.md
-    7.3), its 1-D factors taps = outer(tv, th) for the separable kernels.  Cached per tap tensor: the taps are construction-time constants
-    (frozen Filter_OP.weight), so steady-state calls do no host work and no host->device copy."""
+    7.3), its 1-D factors taps = outer(tv, th) for the separable kernels.  The taps are construction-time constants (a view of the frozen
+    Filter_OP.weight): the entry is cached ON the tensor that owns the storage (the Parameter), keyed by its version counter and the target
+    device, so steady-state calls do no host work and no host->device copy — and the cache dies with the module (a cache keyed by data
+    pointers would be handed stale taps when the allocator recycles a freed module's storage)."""
+    owner = t._base if t._base is not None else t          # taps() hands out a view of the frozen Filter_OP.weight Parameter
     t = t.detach()
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device), str(dev))
-    hit = _TAPS.get(key)
+    key = (owner._version, tuple(t.shape), t.storage_offset(), tuple(t.stride()), str(dev))
+    cache = getattr(owner, '_esr_taps', None)
+    if cache is None:
+        cache = {}
+        try:
+            owner._esr_taps = cache
+        except Exception:          # a tensor type that takes no attributes: no caching
+            pass
+    hit = cache.get(key)
     if hit is None:
         assert t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1, 'CEM filters are odd square 2-D arrays'
-        d = t.to(device=dev, dtype=torch.float32).contiguous()
-        if d.data_ptr() == t.data_ptr():
-            d = d.clone()                    # the cache must not alias a tensor the caller may edit in place
+        d = t.to(device=dev, dtype=torch.float32).contiguous().clone()
         a = t.double().cpu().numpy()
         u, sv, vt = np.linalg.svd(a)
         sep = None
@@ -40,9 +47,9 @@ def _taps_entry(t, dev):
             sgn = 1.0 if u[:, 0].sum() >= 0 else -1.0
             tv, th = sgn * u[:, 0] * np.sqrt(sv[0]), sgn * vt[0] * np.sqrt(sv[0])
             sep = (torch.tensor(tv, dtype=torch.float32, device=dev), torch.tensor(th, dtype=torch.float32, device=dev))
-        if len(_TAPS) > 64:
-            _TAPS.clear()
-        hit = _TAPS[key] = (d, sep)
+        if len(cache) > 8:
+            cache.clear()
+        hit = cache[key] = (d, sep)
     return hit
 
 

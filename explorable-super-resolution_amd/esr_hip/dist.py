@@ -64,13 +64,35 @@ def broadcast_parameters(module, src=0):
             m.invalidate_packs()
 
 
+def _flat_view(grads):
+    """One 1-D tensor aliasing all of `grads` when they tile a single contiguous range of one storage in order (the engine's batched
+    weight-gradient launch writes every layer's dW / db into one flat buffer and hands out views of it), else None."""
+    g0 = grads[0]
+    if any(g is None or not g.is_contiguous() or g.dtype != g0.dtype or g.device != g0.device for g in grads):
+        return None
+    st = g0.untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads):
+        return None
+    off = g0.storage_offset()
+    for g in grads:
+        if g.storage_offset() != off:
+            return None
+        off += g.numel()
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, g0.storage_offset(), (off - g0.storage_offset(),))
+
+
 class GradBucketAllReducer:
-    """Averages .grad of the given parameters across ranks in flat buckets of ~bucket_mb megabytes.  Buckets are reduced with
-    async collectives issued back to back (they pipeline on the RCCL stream) and copied back after the waits."""
+    """Averages .grad of the given parameters across ranks in flat buckets of ~bucket_mb megabytes (68 MB of generator gradients -> 3
+    collectives: xGMI rings are per-link bound, so few large messages), issued back to back as async collectives that pipeline on the RCCL
+    stream.  Nothing is overlapped with the backward pass, by construction of the backward: the weight gradients of ALL layers come out of ONE
+    batched launch at its very end (esr_conv3x3_wgrad_batch), so there is no earlier moment at which a bucket is complete.  When the
+    gradients of a bucket are consecutive views of one buffer — the flat buffer that launch writes — the collective runs in place on that
+    buffer: no gather copy before, no scatter copy after."""
 
     def __init__(self, params, bucket_mb=32.0):
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
+        self.in_place = 0          # buckets of the last call that were reduced in place (diagnostics / tests)
         cur, cur_bytes, limit = [], 0, int(bucket_mb * 2 ** 20)
         for p in self.params:
             nbytes = p.numel() * p.element_size()
@@ -87,13 +109,22 @@ class GradBucketAllReducer:
             return
         w = world_size()
         work = []
+        self.in_place = 0
         for bucket in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            grads = [p.grad for p in bucket]
+            flat = _flat_view(grads) if all(g is not None for g in grads) else None
+            if flat is not None:
+                self.in_place += 1
+                work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, None))
+                continue
+            grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, bucket)]
             flat = torch.cat([g.reshape(-1) for g in grads])
             work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
         for handle, flat, bucket in work:
             handle.wait()
             flat.div_(w)
+            if bucket is None:
+                continue
             off = 0
             for p in bucket:
                 n = p.numel()

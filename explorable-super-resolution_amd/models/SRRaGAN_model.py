@@ -22,7 +22,7 @@ import torch.nn as nn
 import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
-from models.modules.loss import CreateRangeLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
+from models.modules.loss import CreateRangeLoss, FilterLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
 
 
@@ -58,7 +58,7 @@ class SRRaGANModel(BaseModel):
         esr_dist.broadcast_parameters(self.netG)          # every rank starts from rank 0's weights
         logs_2_keep = ['l_g_pix', 'l_g_fea', 'l_g_range', 'l_g_gan', 'l_d_real', 'l_d_fake', 'D_loss_STD', 'l_d_real_fake', 'D_real', 'D_fake',
                        'D_logits_diff', 'psnr_val', 'D_update_ratio', 'LR_decrease', 'Correctly_distinguished', 'l_d_gp', 'per_pix_STD_val',
-                       'l_g_optimalZ', 'Z_effect']
+                       'l_g_optimalZ', 'Z_effect'] + ['l_g_latent_%d' % i for i in range(self.num_latent_channels)]
         self._log_dict = OrderedDict(zip(logs_2_keep, [[] for _ in logs_2_keep]))
         self._pending_logs = []          # (key, step, [device scalars of the accumulation steps]): read back lazily, see log_dict
         self.D_exists = False
@@ -70,7 +70,12 @@ class SRRaGANModel(BaseModel):
             if train_opt['feature_weight'] is not None:
                 raise NotImplementedError('The VGG-feature loss needs define_F (torchvision), which is outside this build; set train.feature_weight to null')
             if self.latent_input is not None and train_opt['latent_weight'] is not None:
-                raise NotImplementedError('FilterLoss (train.latent_weight) is not part of this build; set it to null')
+                # L_struct: the structure tensor of G's output against the value the latent code asks for (reference :35-40)
+                self.l_latent_w = train_opt['latent_weight']
+                self.cri_latent = FilterLoss(latent_channels=opt['network_G']['latent_channels'])
+                if not self.cri_latent.supported:
+                    raise NotImplementedError("train.latent_weight with network_G.latent_channels = %r: only the structure-tensor codes are part of this build"
+                                              % (opt['network_G']['latent_channels'],))
             if self.latent_input is not None and train_opt['optimalZ_loss_type'] is not None and train_opt['optimalZ_loss_weight'] is not None:
                 self.optimalZ_loss_type = train_opt['optimalZ_loss_type']
             self.D_verification = train_opt['D_verification']
@@ -190,6 +195,17 @@ class SRRaGANModel(BaseModel):
         if self.latent_input is not None:
             if 'Z' in data.keys():
                 cur_Z = data['Z']
+            elif self.cri_latent is not None:
+                # training with L_struct: one latent code per image, constant over the image (reference :252-254); for the
+                # 'SVD*structure_tensor' codes it is drawn as (lambda0, lambda1, theta) and converted (utils/util.py:285-291)
+                cur_Z = torch.rand([self.var_L.size(0), self.num_latent_channels, 1, 1])
+                if self.opt['network_G']['latent_channels'] in ['SVD_structure_tensor', 'SVDinNormedOut_structure_tensor']:
+                    l0, l1, th = cur_Z[:, 0], cur_Z[:, 1], 2 * np.pi * cur_Z[:, -1]
+                    self.SVD = {'theta': th, 'lambda0_ratio': 1 * l0, 'lambda1_ratio': 1 * l1}
+                    cur_Z = torch.stack([2 * (l1 * torch.sin(th) ** 2 + l0 * torch.cos(th) ** 2) - 1, 2 * (l0 * torch.sin(th) ** 2 + l1 * torch.cos(th) ** 2) - 1,
+                                         2 * (l0 - l1) * torch.sin(th) * torch.cos(th)], 1)
+                else:
+                    cur_Z = 2 * cur_Z - 1
             else:
                 cur_Z = 2 * torch.rand([self.var_L.size(0), self.num_latent_channels] + [self.Z_size_factor * v for v in list(self.var_L.size()[2:])]) - 1
             if isinstance(cur_Z, (int, float)) or (not torch.is_tensor(cur_Z) and np.ndim(cur_Z) < 4):
@@ -345,7 +361,7 @@ class SRRaGANModel(BaseModel):
                 self.Set_Require_Grad_Status(self.netG, True)
                 if first_acc_G and first_dual:
                     self.optimizer_G.zero_grad()
-                    self._g_acc = {k: [] for k in ('l_g_pix', 'l_g_range', 'l_g_gan', 'l_g_optimalZ')}
+                    self._g_acc = {k: [] for k in ['l_g_pix', 'l_g_range', 'l_g_gan', 'l_g_optimalZ'] + ['l_g_latent_%d' % i for i in range(self.num_latent_channels)]}
                 scale = acc_G * dual_steps
                 l_g_total = 0
                 if self.cri_pix is not None:
@@ -358,6 +374,11 @@ class SRRaGANModel(BaseModel):
                     l_g_range = self.cri_range(self.fake_H)
                     l_g_total = l_g_total + self.l_range_w * l_g_range / scale
                     self._g_acc['l_g_range'].append(l_g_range.detach())
+                if self.cri_latent is not None and last_dual:
+                    l_g_latent = self.cri_latent({'SR': self.fake_H, 'HR': self.var_H, 'Z': static_Z}).mean(0)      # [num_latent_channels]
+                    l_g_total = l_g_total + self.l_latent_w * l_g_latent.mean() / acc_G
+                    for i in range(self.num_latent_channels):
+                        self._g_acc['l_g_latent_%d' % i].append(l_g_latent[i].detach())
                 if self.cri_optimalZ is not None and first_dual:
                     l_g_optimalZ = self.cri_optimalZ(self.fake_H, self.var_H)
                     l_g_total = l_g_total + self.l_g_optimalZ_w * l_g_optimalZ / acc_G

@@ -1,7 +1,7 @@
 """Losses around the generator (reference: codes/models/modules/loss.py): GANLoss (:212-246), GradientPenaltyLoss (:260-279),
-CreateRangeLoss (:248-258), Latent_channels_desc_2_num_channels (:16-25).  Element-wise / reduction torch ops on the generator's and the
-discriminator's outputs; device-agnostic (the reference hard-codes torch.cuda.FloatTensor).  FilterLoss — the structure-tensor
-latent-control loss (:27-209) — needs OpenCV's Sobel taps for one of its variants and is not part of this build (it raises)."""
+CreateRangeLoss (:248-258), Latent_channels_desc_2_num_channels (:16-25), FilterLoss (:27-209, the structure-tensor codes).
+Element-wise / reduction torch ops on the generator's and the discriminator's outputs; device-agnostic (the reference hard-codes
+torch.cuda.FloatTensor)."""
 import re
 
 import torch
@@ -78,11 +78,51 @@ class GradientPenaltyLoss(nn.Module):
 
 
 class FilterLoss(nn.Module):
-    def __init__(self, latent_channels, **kwargs):
+    """L_struct of the explorable-SR training (reference loss.py:27-209), model-training form for the structure-tensor latent codes
+    ('structure_tensor*' and 'SVDinNormedOut_structure_tensor*'): the image's mean structure tensor, from forward differences
+        Ix = x[.., 1:] - x[.., :-1] (first H-1 rows),  Iy = x[1:, ..] - x[:-1, ..] (first W-1 columns)        (2x2 filters, :49-62)
+        S = [mean Ix^2, mean Iy^2, mean Ix*Iy]  over channels and pixels, per image                            (:141-151)
+    measured on the SR output and turned into ratios against the ground truth's tensor (:160-175):
+        'SVDinNormedOut_*': S_SR / (sqrt(S_HR[0] * S_HR[1]) + 1/255);   'structure_tensor*': S_SR[i] / (S_HR[i] + sign*1/255) for i < 2, S_SR[2] as is
+    The target for each ratio is the latent code mapped affinely onto the [5th, 95th] percentile range of the ratios seen so far
+    (a 10000-deep history per channel, updated with the current batch first — :178-186): the loss is |measured - target|, shape [B, 3].
+    The percentile bounds are host-side statistics (not differentiated), exactly as in the reference.  Other latent codes
+    ('STD_1dir', 'STD_directional', 'SVD_structure_tensor') and the GUI's constant-Z form are not part of this build."""
+    NOISE_STD = 1 / 255
+    LOWER_PERCENTILE, HIGHER_PERCENTILE = 5, 95
+
+    def __init__(self, latent_channels, constant_Z=None, reference_images=None, masks=None, task='SR', gray_scale=False):
         super(FilterLoss, self).__init__()
+        from collections import deque
         self.latent_channels = latent_channels
         self.num_channels = Latent_channels_desc_2_num_channels(latent_channels)
+        self.model_training = isinstance(latent_channels, str)
+        self.supported = self.model_training and 'structure_tensor' in latent_channels and not latent_channels.startswith('SVD_') and \
+            constant_Z is None and task == 'SR'
+        if self.supported:
+            self.collected_ratios = [deque(maxlen=10000) for _ in range(self.num_channels)]
+
+    @staticmethod
+    def structure_tensor(x):
+        ix = (x[..., :, 1:] - x[..., :, :-1])[..., :-1, :]
+        iy = (x[..., 1:, :] - x[..., :-1, :])[..., :, :-1]
+        return torch.stack([(ix * ix).mean(dim=(1, 2, 3)), (iy * iy).mean(dim=(1, 2, 3)), (ix * iy).mean(dim=(1, 2, 3))], 0)      # [3, B]
 
     def forward(self, data):
-        raise NotImplementedError('FilterLoss (structure-tensor latent-control loss, reference loss.py:27-209) is not part of this build: '
-                                  'set train.latent_weight to null')
+        if not self.supported:
+            raise NotImplementedError("FilterLoss(latent_channels=%r): only the model-training structure-tensor codes are part of this build" % (self.latent_channels,))
+        import numpy as np
+        cur_Z = data['Z'].mean(dim=(2, 3))
+        s_sr, s_hr = self.structure_tensor(data['SR']), self.structure_tensor(data['HR'])
+        if self.latent_channels.startswith('SVDinNormedOut'):
+            norm = torch.sqrt(s_hr[0]) * torch.sqrt(s_hr[1])
+            measured = [s_sr[i] / (norm + self.NOISE_STD) for i in range(3)]
+        else:
+            measured = [s_sr[i] / (s_hr[i] + torch.sign(s_sr[i]) * self.NOISE_STD) if i < 2 else s_sr[i] for i in range(3)]
+        targets = []
+        for i in range(3):
+            self.collected_ratios[i] += [float(v) for v in measured[i].detach()]
+            hi = np.percentile(self.collected_ratios[i], self.HIGHER_PERCENTILE)
+            lo = np.percentile(self.collected_ratios[i], self.LOWER_PERCENTILE)
+            targets.append(cur_Z[:, i] / 2 * (hi - lo) + np.mean([hi, lo]))
+        return (torch.stack(measured, 1) - torch.stack(targets, 1)).abs()

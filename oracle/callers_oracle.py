@@ -79,10 +79,12 @@ def arctanh(t):
     return 0.5 * torch.log((1 + t + eps) / (1 - t + eps))
 
 
-def z_search(sd, lr, z0, nb, lat, sf, taps, objective, iters, lr_adam, std_increment=None, z_range=1.0):
-    """Returns (loss history, final Z).  lr: [B,3,h,w]; z0: [B,lat,sf*h,sf*w] in (-z_range, z_range)."""
+def z_search(sd, lr, z0, nb, lat, sf, taps, objective, iters, lr_adam, std_increment=None, z_range=1.0, image_mask=None, z_mask=None):
+    """Returns (loss history, final Z).  lr: [B,3,h,w]; z0: [B,lat,sf*h,sf*w] in (-z_range, z_range).  image_mask [H,W]: the objective sees
+    output * mask (Z_optimization.py:383-388,627,728); z_mask [H,W]: entries outside it are pinned to their initial value (:278-299)."""
     def output(z):
-        return torch.clamp(generator_output(sd, lr, z, nb, lat, sf, taps, eval_mode=True), 0, 1)
+        img = torch.clamp(generator_output(sd, lr, z, nb, lat, sf, taps, eval_mode=True), 0, 1)
+        return img if image_mask is None else img * image_mask
 
     def std_of(img):
         return torch.std(img, dim=(1, 2, 3)).view(1, -1)
@@ -94,11 +96,14 @@ def z_search(sd, lr, z0, nb, lat, sf, taps, objective, iters, lr_adam, std_incre
     if 'increase' in objective or 'decrease' in objective:
         sign = 1 if 'increase' in objective else -1
         desired = initial_std * (1.05 ** sign) if std_increment is None else initial_std + sign * std_increment
-    pre = arctanh(torch.clamp(z0 / z_range, -1 + torch.finfo(z0.dtype).eps, 1 - torch.finfo(z0.dtype).eps)).clone().requires_grad_(True)
+    pre0 = arctanh(torch.clamp(z0 / z_range, -1 + torch.finfo(z0.dtype).eps, 1 - torch.finfo(z0.dtype).eps))
+    pre = pre0.clone().requires_grad_(True)
     opt = torch.optim.Adam([pre], lr=lr_adam)
     losses, history = [], []
     for _ in range(iters):
         opt.zero_grad()
+        if z_mask is not None:
+            pre.data = z_mask * pre.data + (1 - z_mask) * pre0
         history.append(pre.detach().clone())
         img = output(z_range * torch.tanh(pre))
         if 'TV' in objective:
@@ -114,7 +119,7 @@ def z_search(sd, lr, z0, nb, lat, sf, taps, objective, iters, lr_adam, std_incre
         loss.backward()
         losses.append(float(loss))
         opt.step()
-    final = pre.detach()
+    final = pre.detach() if z_mask is None else z_mask * pre.detach() + (1 - z_mask) * pre0
     if np.min(losses) != losses[-1]:                   # keep the iterate with the smallest loss (Z_optimization.py:755-762)
         k = int(np.argmin(losses))
         final, losses = history[k], losses[:k + 1]

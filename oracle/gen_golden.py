@@ -225,6 +225,25 @@ def gen_F9():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_pixelshuffle.npz'), **out)
 
 
+def gen_F10():
+    """FilterLoss (loss.py:27-209) in its model-training form for two structure-tensor latent codes: three consecutive calls (the
+    percentile history of the ratios accumulates), loss values [B, 3] of each call and d(sum of the last loss)/d(SR)."""
+    from models.modules.loss import FilterLoss
+    out = {}
+    for code in ('SVDinNormedOut_structure_tensor', 'structure_tensor'):
+        fl = FilterLoss(latent_channels=code)
+        for call in range(3):
+            sr = seeded_uniform((4, 3, 24, 20), 1000 + call).requires_grad_(True)
+            hr = seeded_uniform((4, 3, 24, 20), 1010 + call)
+            z = seeded_uniform((4, 3, 1, 1), 1020 + call, -1.0, 1.0) * torch.ones(4, 3, 24, 20)
+            loss = fl({'SR': sr, 'HR': hr, 'Z': z})
+            out['%s/call%d' % (code, call)] = loss.detach().numpy()
+        loss.sum().backward()
+        out[code + '/dSR'] = sr.grad.numpy()
+        print(code, loss.detach().numpy()[0])
+    np.savez_compressed(os.path.join(GOLDEN, 'filter_loss.npz'), **out)
+
+
 def _wrapped_G(nb, sf, lat=0, kernel=None, gain=1.0):
     import models.modules.architecture as arch
     cem = _cem(sf, kernel)
@@ -391,10 +410,25 @@ def gen_F7():
         out['z_%s/final_Z_sub' % obj] = z[:, :, ::16, ::16].numpy().copy()
         out['z_%s/initial_STD' % obj] = zo.initial_STD.detach().numpy().copy()
         print(obj, zo.loss_values)
+    # a user-marked region (GUI.py:1925-2057): image_mask limits the objective, Z_mask limits which latent entries may move
+    for obj in ('max_STD', 'TV'):
+        im_mask = np.zeros([96, 112], dtype=np.float32); im_mask[24:72, 32:96] = 1
+        z_mask = np.zeros([96, 112], dtype=np.float32); z_mask[16:80, 24:104] = 1
+        z0 = seeded_uniform((B, 3, 96, 112), 921, -0.3, 0.3)
+        m.feed_data({'LR': lr.expand(B, -1, -1, -1).clone(), 'Z': z0.clone()}, need_GT=False)
+        m.test()
+        with quiet:
+            zo = Z_optimizer(objective=obj, Z_size=[96, 112], model=m, Z_range=1, max_iters=3, data={'LR': lr.expand(B, -1, -1, -1).clone(), 'STD_increment': 0.01},
+                             initial_Z=z0.clone(), initial_LR=0.1, batch_size=B, image_mask=im_mask, Z_mask=z_mask)
+            z = zo.optimize()
+        out['zmask_%s/loss' % obj] = np.array(zo.loss_values, dtype=np.float64)
+        out['zmask_%s/final_Z_sub' % obj] = z[:, :, ::8, ::8].numpy().copy()
+        out['zmask_%s/initial_STD' % obj] = zo.initial_STD.detach().numpy().copy()
+        print('masked', obj, zo.loss_values)
     np.savez_compressed(os.path.join(GOLDEN, 'callers_f7.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9}
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10}
 
 if __name__ == '__main__':
     _refshim.install()

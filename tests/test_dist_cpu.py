@@ -110,3 +110,34 @@ def test_sharded_z_search_matches_single_process():
     np.testing.assert_allclose(Z, Z_ref.numpy(), atol=1e-6)           # each Z sample has its own Adam state: sharding is exact
     np.testing.assert_allclose(res[0][2], loss_ref, rtol=1e-5)        # the (all-reduced) loss history is the global batch mean
     np.testing.assert_allclose(res[1][2], loss_ref, rtol=1e-5)
+
+
+def _worker_flat(rank, world, port, q):
+    D = _setup(rank, world, port)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(8, 5, 3))
+    params = list(net.parameters())
+    # gradients handed out as consecutive views of ONE flat buffer, as the engine's batched weight-gradient launch does (engine.WGrad)
+    flat = torch.arange(sum(p.numel() for p in params), dtype=torch.float32) * (rank + 1)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    red = D.GradBucketAllReducer(params, bucket_mb=0.001)        # 2 buckets: each one a contiguous slice of the flat buffer
+    ptrs = [p.grad.data_ptr() for p in params]
+    red()
+    q.put((rank, red.in_place, len(red.buckets), flat.clone().numpy(), ptrs == [p.grad.data_ptr() for p in params]))
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_reduce_in_place_out_of_the_flat_gradient_buffer():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    for rank, in_place, nb, flat, same_storage in res:
+        assert nb >= 2 and in_place == nb and same_storage          # every bucket reduced in place: no gather / scatter copies
+        assert np.allclose(flat, np.arange(flat.size) * 1.5)        # mean of (1x, 2x)

@@ -368,7 +368,11 @@ def test_pixelshuffle_generator_matches_oracle(sf, lat, prec):
     cot = seeded_uniform(tuple(ref.shape), 96, -1.0, 1.0)
     (ref * cot).sum().backward()
     (y * cot.to(DEV)).sum().backward()
-    assert_grad_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 'pixelshuffle x%d dx' % sf)
+    if prec == 'split':
+        assert_grad_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 'pixelshuffle x%d dx' % sf)
+    else:       # fp16 data gradient of 'mixed': bulk within 2e-3 of the gradient's rms (its own tests: tests/test_gpu_backward.py, mixed section)
+        gg, rr = xg.grad.cpu().numpy().astype(np.float64), xc.grad.numpy().astype(np.float64)
+        assert np.median(np.abs(gg - rr)) / np.sqrt((rr ** 2).mean()) < 2e-3 and rel_l2(gg, rr) < 5e-2
 
 
 # ---- the sign-flip statement, tested: with the activation pattern the GPU forward actually took, the HIP backward is the exact adjoint

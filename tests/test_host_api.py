@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle.check_golden import load
+from oracle.weights import seeded_uniform
 from oracle.gen_golden import aniso_gaussian_kernel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -309,3 +310,35 @@ def test_unsupported_generator_configurations_fail_loudly():
     net = arch.RRDBNet(**dict(base, upsample_mode='pixelshuffle'))          # constructible (state_dict parity), not executable
     with pytest.raises(Exception):
         net(torch.zeros(1, 3, 8, 8))
+
+
+def test_bench_launches_its_own_ranks_for_several_gpus():
+    """`python bench.py --gpus N` (how the driver starts the N = 1 run) must work for N > 1 too: when no launcher set WORLD_SIZE it
+    re-executes itself under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1; under a launcher it runs as a rank."""
+    import bench
+    assert not bench.needs_self_launch(1, {}) and bench.needs_self_launch(8, {}) and not bench.needs_self_launch(8, {'WORLD_SIZE': '8'})
+    cmd = bench.launch_command(8, ['--gpus', '8', '--steps', '5', '--warmup', '2'], port=29511)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29511'
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '5', '--warmup', '2'] and cmd[-7].endswith('bench.py')
+    a = bench.parse_args(['--gpus', '4'])
+    assert a.gpus == 4 and a.workload == 'c2' and a.precision is None
+    assert bench.free_port() > 1024
+
+
+@pytest.mark.parametrize('code', ['SVDinNormedOut_structure_tensor', 'structure_tensor'])
+def test_filter_loss_matches_reference(code):
+    """The product's FilterLoss (structure-tensor latent-control loss of the explorable training, reference loss.py:27-209) against values the
+    reference's class produced over three consecutive calls (fixture F10: the percentile history accumulates), and its gradient."""
+    from models.modules.loss import FilterLoss
+    g = load('filter_loss.npz')
+    fl = FilterLoss(latent_channels=code)
+    assert fl.num_channels == 3
+    for call in range(3):
+        sr = seeded_uniform((4, 3, 24, 20), 1000 + call).requires_grad_(True)
+        hr = seeded_uniform((4, 3, 24, 20), 1010 + call)
+        z = seeded_uniform((4, 3, 1, 1), 1020 + call, -1.0, 1.0) * torch.ones(4, 3, 24, 20)
+        loss = fl({'SR': sr, 'HR': hr, 'Z': z})
+        np.testing.assert_allclose(loss.detach().numpy(), g['%s/call%d' % (code, call)], rtol=1e-5, atol=1e-7)
+    loss.sum().backward()
+    np.testing.assert_allclose(sr.grad.numpy(), g[code + '/dSR'], rtol=1e-4, atol=1e-8)

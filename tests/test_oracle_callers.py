@@ -136,3 +136,23 @@ def test_z_search_of_the_oracle_matches_the_reference(objective):
     assert np.median(d) < 1e-4 and np.mean(d > 1e-2) < 0.01
     expect0 = g['z_%s/initial_STD' % objective] - (0.01 if objective == 'STD_increase' else 0)     # the reference's desired_STD aliases initial_STD
     np.testing.assert_allclose(std0.numpy(), expect0, rtol=1e-4)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('objective', ['max_STD', 'TV'])
+def test_masked_z_search_of_the_oracle_matches_the_reference(objective):
+    """The GUI's region tools: the objective is evaluated on output * image_mask, latent entries outside Z_mask stay where they were."""
+    g = f7()
+    taps = co.CEMTaps(SF)
+    sd = generator_state(0.5)
+    B = 3
+    lr = seeded_uniform((1, 3, 24, 28), 920).expand(B, -1, -1, -1)
+    z0 = seeded_uniform((B, 3, 96, 112), 921, -0.3, 0.3)
+    im_mask = torch.zeros(96, 112); im_mask[24:72, 32:96] = 1
+    z_mask = torch.zeros(96, 112); z_mask[16:80, 24:104] = 1
+    losses, z, std0 = cao.z_search(sd, lr, z0, NB, LAT, SF, taps, objective, 3, 0.1, std_increment=0.01, image_mask=im_mask, z_mask=z_mask)
+    np.testing.assert_allclose(losses, g['zmask_%s/loss' % objective], rtol=1e-3)
+    np.testing.assert_allclose(std0.numpy(), g['zmask_%s/initial_STD' % objective], rtol=1e-4)
+    d = np.abs(z[:, :, ::8, ::8].numpy() - g['zmask_%s/final_Z_sub' % objective])
+    assert np.median(d) < 1e-4 and np.mean(d > 1e-2) < 0.01
+    assert float((z[:, :, :16] - z0[:, :, :16]).abs().max()) < 1e-6          # outside Z_mask nothing moved (tanh(arctanh(z0)) round trip)
