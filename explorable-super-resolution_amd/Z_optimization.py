@@ -27,6 +27,50 @@ def TV_Loss(image):
     return (image[:, :, :, :-1] - image[:, :, :, 1:]).abs().mean(dim=(1, 2, 3)) + (image[:, :, :-1, :] - image[:, :, 1:, :]).abs().mean(dim=(1, 2, 3))
 
 
+class SoftHistogramLoss(torch.nn.Module):
+    """KL divergence between the soft gray-level histogram of the produced image(s) and that of a desired image — the 'hist' Z objective
+    (reference Z_optimization.py:24-230), in the form the whole-image tool uses: gray scale, patch size 1, fixed temperature.
+        h[k] = mean_i exp(-(d(v_i, c_k) + 1e-7)^2 / T) over the (masked) pixels, c = linspace(min, max, bins), d wrapped with period max;
+        p = h / sum(h);   loss = KLDivLoss()(log(p_current + eps) stacked over the batch, p_desired)      (:170-209, :211-229)
+    The O(pixels x bins) histogram and its gradient are the HIP kernels of csrc/esr_zobj.hip (the reference materialises that matrix in
+    float64).  Patch (KDE) histograms, dictionaries and the automatic temperature search are not part of this build."""
+
+    def __init__(self, bins, min, max, desired_hist_image_mask=None, desired_hist_image=None, gray_scale=True, input_im_HR_mask=None, patch_size=1,
+                 automatic_temperature=False, image_Z=None, temperature=0.05, dictionary_not_histogram=False, no_patch_DC=False, no_patch_STD=False):
+        super(SoftHistogramLoss, self).__init__()
+        if not gray_scale or patch_size != 1 or automatic_temperature or dictionary_not_histogram:
+            raise NotImplementedError('SoftHistogramLoss: gray-scale, patch_size 1, fixed temperature histograms only')
+        self.bins_n, self.min, self.max, self.temperature = int(bins), float(min), float(max), float(temperature)
+        self.SQRT_EPSILON = 1e-7
+        self.image_mask = None if input_im_HR_mask is None else input_im_HR_mask.reshape(-1).bool()
+        self.loss = torch.nn.KLDivLoss()
+        self.desired_hists_list = []
+        if desired_hist_image is not None:
+            # (the reference ignores desired_hist_image_mask for non-patch gray histograms: it is applied in its KDE branch only, :74-76)
+            self.Feed_Desired_Hist_Im([im[0] if im.dim() == 4 else im for im in desired_hist_image][:1])
+
+    def _hist(self, gray_values, log):
+        from esr_hip import zobj
+        h = zobj.soft_histogram(gray_values, self.bins_n, self.min, self.max, self.temperature, self.SQRT_EPSILON)
+        h = (h / h.sum()).float()
+        return torch.log(h + torch.finfo(h.dtype).eps).view(1, -1) if log else h.view(1, -1)
+
+    def Feed_Desired_Hist_Im(self, desired_hist_image):
+        self.desired_hists_list = []
+        with torch.no_grad():
+            for im in desired_hist_image:
+                self.desired_hists_list.append(self._hist(im.mean(0).reshape(-1), log=False).detach())
+
+    def forward(self, cur_images):
+        logs = []
+        for im in cur_images:
+            gray = im.mean(0).reshape(-1)
+            if self.image_mask is not None:
+                gray = gray[self.image_mask.to(gray.device)]
+            logs.append(self._hist(gray, log=True))
+        return self.loss(torch.cat(logs, 0), torch.cat(self.desired_hists_list, 0).to(logs[0].device)).float()
+
+
 class Optimizable_Z(torch.nn.Module):
     def __init__(self, Z_shape, Z_range=None, initial_pre_tanh_Z=None, Z_mask=None, random_perturbations=False, device=None):
         super(Optimizable_Z, self).__init__()
@@ -68,7 +112,7 @@ class Optimizable_Z(torch.nn.Module):
 
 class Z_optimizer():
     MIN_LR = 1e-5
-    SUPPORTED = ['max_STD', 'min_STD', 'STD_increase', 'STD_decrease', 'TV', 'l1']
+    SUPPORTED = ['max_STD', 'min_STD', 'STD_increase', 'STD_decrease', 'TV', 'l1', 'hist']
 
     def __init__(self, objective, Z_size, model, Z_range, max_iters, data=None, loggers=None, image_mask=None, Z_mask=None, initial_Z=None,
                  initial_LR=None, existing_optimizer=None, batch_size=1, HR_unpadder=None, random_Z_inits=False, **unsupported):
@@ -113,6 +157,10 @@ class Z_optimizer():
                 self.desired_STD = self.desired_STD + (inc if 'increase' in objective else -inc)
         if 'l1' in objective and data is not None and 'desired' in data:
             self.desired_im = data['desired'].to(self.device)
+        if objective == 'hist':          # reference :536-541: 256 bins on [0, 1], temperature 5e-4
+            self.loss = SoftHistogramLoss(bins=256, min=0, max=1, desired_hist_image=[d.to(self.device) for d in data['desired']] if data is not None else None,
+                                          desired_hist_image_mask=data.get('Desired_Im_Mask') if data is not None else None, input_im_HR_mask=self.image_mask,
+                                          gray_scale=True, patch_size=1, temperature=5e-4)
         self.optimizer = torch.optim.Adam(self.Z_model.parameters(), lr=initial_LR) if existing_optimizer is None else existing_optimizer
         self.LR = initial_LR
         self.cur_iter = 0
@@ -177,7 +225,9 @@ class Z_optimizer():
             self.output_image = self.model.Output_Batch(within_0_1=True)
             if self.model_training:
                 self.output_image = self.HR_unpadder(self.output_image)
-            if 'l1' in self.objective:
+            if self.objective == 'hist':
+                Z_loss = self.loss(self.output_image).reshape(1)
+            elif 'l1' in self.objective:
                 Z_loss = (self.output_image - self.desired_im).abs().mean(dim=(1, 2, 3))
             elif 'TV' in self.objective:
                 Z_loss = (self.STD_PRESERVING_WEIGHT * (self.Masked_STD() - self.initial_STD) ** 2).mean(0) + \

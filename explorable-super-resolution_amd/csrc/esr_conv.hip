@@ -59,6 +59,26 @@ constexpr int WGS_MT1 = ESR_WGS_MT1, WGS_MT2 = ESR_WGS_MT2;   // resident workgr
 constexpr int r_of(int mt) { return mt == 1 ? ESR_R_MT1 : 3; }
 constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE; }
 
+// EXPERIMENT (-DESR_WREG=1; off by default): the weight fragments of the kernels with ONE weight plane (bf16 / f16 / the dense-block convs of
+// 'mixed') bypass LDS — every wave loads the A fragments of the next chunk straight from L2 into registers (global_load_dwordx4: the pack
+// order IS the fragment order) while it multiplies the current one.  Motivation: these kernels looked paced by the per-CU LDS-DMA ingest rate
+// (~26 KB per chunk against 864-1728 MFMA cycles) and the weights are a third of those bytes and a quarter of the LDS operand
+// reads.  Measured, same GPU, results bit-identical (profiles/r02_wreg_ab.log): C2 forward in 'mixed' 39.2 vs 38.7 ms, C3 generator step in
+// bf16 32.1 vs 32.0 ms, C5 inference in f16 78.3 vs 70.8 ms — the 36-72 extra live registers cost more (occupancy of the one-plane 64-channel
+// kernels) than the LDS-DMA bytes they save.  Kept as a build knob because the next attempt at the ingest limit starts from it.
+#ifndef ESR_WREG
+#define ESR_WREG 0
+#endif
+constexpr bool wreg_of(int npw) { return ESR_WREG != 0 && npw == 1; }
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// asynchronous 16-byte global load into a register quad, hidden from the compiler like glds16 (same reason: no vmcnt(0) drains); the value
+// is only valid after the next s_waitcnt vmcnt(...) that covers it — pin_frag() below ties the uses to that wait
+__device__ __forceinline__ void gload16(u32x4& dst, const uint4* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+__device__ __forceinline__ void pin_frag(u32x4& f) { asm volatile("" : "+v"(f)); }
+
 // epilogue feature bits (template parameter EPI)
 constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
 // residual 1 is a channel-group slice of the conv's own input (RDB conv5: out = 0.2*conv + x, block.py:235): it is added to the
@@ -181,7 +201,7 @@ template <int NPL, int MT, int NPW>
 __device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave,
                                        bool xlo = true) {
     constexpr int MAXS = maxs_of(MT);
-    constexpr int NWI = 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
+    constexpr int NWI = wreg_of(NPW) ? 0 : 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
     if (op < NACT) {
         const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
         if (!xlo && (cgpl % NPL) == 1) return;      // this chunk's groups have no lo plane
@@ -269,18 +289,27 @@ __device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const Con
 // MFMAs of tap t (sched_barrier-pinned).  XLO: the chunk's activations have a lo plane.  Terms per product, in issue order:
 // Wlo*Xhi (if the weights have a lo plane), Whi*Xlo (if XLO), Whi*Xhi.
 template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP>
-__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes) {
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes,
+                                           u32x4 (&wa)[9 * MT], const uint4* wnext) {
+    // wa / wnext (weights-in-registers kernels): wa holds this chunk's A fragments [tap][mtile]; once a tap's MFMAs are issued its slots are
+    // refilled with the NEXT chunk's fragments from wnext (nullptr: last chunk) — in flight for the rest of this chunk's MFMA phase
+    constexpr bool WREG = wreg_of(NPW);
     constexpr int NPB = XLO ? NPL : 1;                                   // activation planes read
     constexpr int NT_FULL = 1 + (NPW == 2 ? 1 : 0) + (NPB == 2 ? 1 : 0);
     constexpr int NTERM = NT_FULL < NTERM_CAP ? NT_FULL : NTERM_CAP;      // NTERM_CAP < 3 only in ablation builds
     constexpr int NM = MT * R * NTERM;
-    constexpr int NLA = MT * NPW, NLB = R * NPB, NL = NLA + NLB;
+    constexpr int NLA = WREG ? 0 : MT * NPW, NLB = R * NPB, NL = NLA + NLB;
     constexpr int NSLOT = NM > NL ? NM : NL;
     uint4 fa[2][MT][NPW], fb[2][R][NPB];
     // read order inside a tap: [A plane of the first term x MT, B hi x R, then the other A plane x MT (if any), B lo x R (if any)] — what
     // the first MFMAs of the next tap need comes first
     auto load_frag = [&](int t, int k, int buf) {
         const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+        if (WREG) {                                  // only activation fragments come from LDS: [B hi x R, then B lo x R (if any)]
+            if (k < R) fb[buf][k][0] = *(const uint4*)(sb + k * NW * 512 + tapoff);
+            else fb[buf][k - R][NPB - 1] = *(const uint4*)(sb + (k - R) * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
+            return;
+        }
         if (k < MT) {
             const int pl = NPW == 2 ? 1 : 0;
             fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
@@ -312,9 +341,15 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
                 const int idx = ti + skip;                                    // index into the present-term list
                 const int term = (idx < has0) ? 0 : ((idx < has0 + has1) ? 1 : 2);
                 const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
-                acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+                if (WREG) acc[m][r] = mfma<FMT>(__builtin_bit_cast(uint4, wa[t * MT + m]), fb[cb][r][pb], acc[m][r]);
+                else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
             }
             if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (WREG && wnext) {                          // this tap's MFMAs are issued: its register slots take the next chunk's fragments
+#pragma unroll
+            for (int m = 0; m < MT; ++m) gload16(wa[t * MT + m], wnext + (t * MT + m) * 64);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -340,7 +375,8 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
-    constexpr int NWI = 9 * MT * NPW;
+    constexpr bool WREG = wreg_of(NPW);
+    constexpr int NWI = WREG ? 0 : 9 * MT * NPW;                   // weight fragments staged in LDS per chunk
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
     float* const s_bias = (float*)(smem + NST * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
@@ -378,6 +414,12 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     constexpr int NTERM_CAP = 3;
 #endif
     constexpr int NOPS_HI = NACT / NPL + NWOP;       // DMA instructions of a hi-only chunk
+    u32x4 wa[9 * MT];                                // (WREG) the current chunk's A fragments
+    const uint4* const wbase = a.wpack + lane;       // fragment f of chunk cp: wbase + (cp * 9 * MT + f) * 64
+    if (WREG) {
+#pragma unroll
+        for (int f = 0; f < 9 * MT; ++f) gload16(wa[f], wbase + f * 64);
+    }
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
         const bool xlo0 = !PARTLO || 0 < a.lo_chunks;
@@ -424,7 +466,12 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         ESR_TR();
         __syncthreads();
         ESR_TR();
-        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes);
+        if (WREG) {              // every wait above covers the fragment loads issued during the previous chunk: from here on wa is valid
+#pragma unroll
+            for (int f = 0; f < 9 * MT; ++f) pin_frag(wa[f]);
+        }
+        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa,
+                                                         (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr);
         if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
         ESR_TR();
         __syncthreads();
@@ -694,7 +741,7 @@ template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
     ESR_ALLOW_160K_LDS(k);
-    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024) + (size_t)MT * 32 * 4;
+    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NTHREADS), lds, s, a);

@@ -74,6 +74,9 @@ _SIGS = {
     'esr_conv3x3_wgrad_batch': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'esr_conv3x3_wgrad_batch_upload': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.POINTER(WgradBatchPlan), C.c_void_p]),
     'esr_conv3x3_wgrad_batch_run': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_void_p]),
+    'esr_soft_hist_slabs': (C.c_int64, [C.c_int64]),
+    'esr_soft_hist_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'esr_soft_hist_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -30,36 +30,24 @@ class HipConv2d(nn.Conv2d):
 
 
 def act(act_type, inplace=True, neg_slope=0.2, n_prelu=1):
+    """Activation module by name (reference block.py:10-23).  The generator's kernels fuse LeakyReLU(0.2); 'relu' is kept for callers
+    that build plain blocks, 'prelu' (SRResNet only in the reference) is not part of this build."""
     act_type = act_type.lower()
     if act_type == 'relu':
-        layer = nn.ReLU(inplace)
-    elif act_type == 'leakyrelu':
-        layer = nn.LeakyReLU(neg_slope, inplace)
-    elif act_type == 'prelu':
-        layer = nn.PReLU(num_parameters=n_prelu, init=neg_slope)
-    else:
-        raise NotImplementedError('activation layer [{:s}] is not found'.format(act_type))
-    return layer
+        return nn.ReLU(inplace)
+    if act_type == 'leakyrelu':
+        return nn.LeakyReLU(neg_slope, inplace)
+    raise NotImplementedError('activation layer [{:s}] is not found'.format(act_type))
 
 
 def norm(norm_type, nc):
+    """Normalisation module by name (reference block.py:26-36); used by the discriminator only — the generator has none."""
     norm_type = norm_type.lower()
     if norm_type == 'batch':
         return nn.BatchNorm2d(nc, affine=True)
     if norm_type == 'instance':
         return nn.InstanceNorm2d(nc, affine=False)
     raise NotImplementedError('normalization layer [{:s}] is not found'.format(norm_type))
-
-
-def pad(pad_type, padding):
-    pad_type = pad_type.lower()
-    if padding == 0:
-        return None
-    if pad_type == 'reflect':
-        return nn.ReflectionPad2d(padding)
-    if pad_type == 'replicate':
-        return nn.ReplicationPad2d(padding)
-    raise NotImplementedError('padding layer [{:s}] is not implemented'.format(pad_type))
 
 
 def get_valid_padding(kernel_size, dilation):
@@ -84,20 +72,16 @@ def sequential(*args, return_module_list=False):
 
 def conv_block(in_nc, out_nc, kernel_size, stride=1, dilation=1, groups=1, bias=True, pad_type='zero', norm_type=None,
                act_type='relu', mode='CNA', return_module_list=False):
-    """Conv (+norm) (+act), reference block.py:129-155.  Only what the RRDB path uses is backed by HIP kernels."""
+    """Conv (+norm) (+act), reference block.py:129-155, in the one arrangement the RRDB generator uses: zero padding, 'CNA' order.  The
+    reference's other arrangements (reflect / replicate padding modules, 'NAC' / 'CNAC' orders) serve SRResNet-style nets outside this build."""
     assert mode in ['CNA', 'NAC', 'CNAC'], 'Wong conv mode [{:s}]'.format(mode)
-    padding = get_valid_padding(kernel_size, dilation)
-    p = pad(pad_type, padding) if pad_type and pad_type != 'zero' else None
-    padding = padding if pad_type == 'zero' else 0
-    c = HipConv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=bias, groups=groups)
+    if mode != 'CNA' or pad_type != 'zero':
+        raise NotImplementedError("conv_block(mode=%r, pad_type=%r): the RRDB path uses mode='CNA' with zero padding" % (mode, pad_type))
+    c = HipConv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride, padding=get_valid_padding(kernel_size, dilation), dilation=dilation, bias=bias,
+                  groups=groups)
+    n = norm(norm_type, out_nc) if norm_type else None
     a = act(act_type) if act_type else None
-    if 'CNA' in mode:
-        n = norm(norm_type, out_nc) if norm_type else None
-        return sequential(p, c, n, a, return_module_list=return_module_list)
-    if norm_type is None and act_type is not None:
-        a = act(act_type, inplace=False)
-    n = norm(norm_type, in_nc) if norm_type else None
-    return sequential(n, a, p, c)
+    return sequential(c, n, a, return_module_list=return_module_list)
 
 
 class ShortcutBlock(nn.Module):

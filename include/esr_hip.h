@@ -266,6 +266,15 @@ int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* wor
                                    esr_stream_t stream);
 int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
 
+/* ---- Z-objective kernels (reference: codes/Z_optimization.py:170-209, SoftHistogramLoss.ComputeSoftHistogram, gray-scale / patch-size-1
+ * form).  Soft histogram of n values with K bins whose centres run from lo to hi:  h[k] = (1/n) sum_i exp(-(d(v_i, c_k) + eps)^2 / T), the
+ * distance wrapped with period hi as the reference does.  The forward writes one partial (un-normalised) histogram of K doubles per slab of
+ * pixels — esr_soft_hist_slabs(n) of them — which the caller sums and divides by n; the backward takes d loss / d h[k] (already divided by n)
+ * and writes d loss / d v.  The reference builds the n x K matrix in float64; these kernels never materialise it. */
+int64_t esr_soft_hist_slabs(int64_t n);
+int esr_soft_hist_fwd(const float* v, int64_t n, int K, float lo, float hi, float T, float eps, double* partial, esr_stream_t stream);
+int esr_soft_hist_bwd(const float* v, int64_t n, int K, float lo, float hi, float T, float eps, const float* gh, float* gv, esr_stream_t stream);
+
 int esr_version(void);
 
 #ifdef __cplusplus

@@ -124,3 +124,28 @@ def z_search(sd, lr, z0, nb, lat, sf, taps, objective, iters, lr_adam, std_incre
         k = int(np.argmin(losses))
         final, losses = history[k], losses[:k + 1]
     return losses, z_range * torch.tanh(final), initial_std
+
+
+# ------------------------------------------------------------------------------------------------ soft histogram objective
+def soft_hist(gray, bins, lo, hi, T, eps=1e-7):
+    """Z_optimization.py:170-209 (ComputeSoftHistogram, non-KDE form): normalised soft histogram of the gray values [n] in float64."""
+    c = torch.linspace(lo, hi, bins).double().view(1, -1)
+    v = gray.double().view(-1, 1)
+    d = (v - c).abs()
+    d = torch.min(d, (v - c - hi).abs())
+    d = torch.min(d, (v - c + hi).abs())
+    h = torch.exp(-((d + eps) ** 2) / T).mean(0)
+    return (h / h.sum()).float()
+
+
+def soft_hist_loss(cur_images, desired_image, bins, lo, hi, T, mask=None):
+    """SoftHistogramLoss.forward (:211-229) for gray scale / patch size 1: KLDivLoss(log p_cur stacked over the batch, p_desired)."""
+    p_des = soft_hist(desired_image.mean(0).reshape(-1), bins, lo, hi, T).view(1, -1)
+    logs = []
+    for im in cur_images:
+        g = im.mean(0).reshape(-1)
+        if mask is not None:
+            g = g[mask.reshape(-1).bool()]
+        p = soft_hist(g, bins, lo, hi, T)
+        logs.append(torch.log(p + torch.finfo(p.dtype).eps).view(1, -1))
+    return F.kl_div(torch.cat(logs, 0), p_des, reduction='mean')

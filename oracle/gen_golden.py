@@ -244,6 +244,27 @@ def gen_F10():
     np.savez_compressed(os.path.join(GOLDEN, 'filter_loss.npz'), **out)
 
 
+def gen_F11():
+    """SoftHistogramLoss (Z_optimization.py:24-230), gray scale / patch size 1 / fixed temperature: KL loss of a batch of two images against a
+    desired image's histogram, with and without an image mask, and its gradient w.r.t. the images."""
+    from Z_optimization import SoftHistogramLoss
+    out = {}
+    desired = seeded_uniform((1, 3, 40, 36), 1101)
+    for name, mask in (('plain', None), ('masked', (seeded_uniform((40, 36), 1103) > 0.4).float())):
+        loss_fn = SoftHistogramLoss(bins=64, min=0, max=1, desired_hist_image=[desired], desired_hist_image_mask=[None], input_im_HR_mask=mask, gray_scale=True,
+                                    patch_size=1, temperature=2e-3)
+        cur = (seeded_uniform((2, 3, 40, 36), 1102) ** 2).requires_grad_(True)
+        loss = loss_fn(cur)
+        loss.backward()
+        out[name + '/loss'] = np.array(float(loss))
+        out[name + '/grad'] = cur.grad.numpy().copy()
+        out[name + '/desired_hist'] = loss_fn.desired_hists_list[0].numpy().copy()
+        if mask is not None:
+            out[name + '/mask'] = mask.numpy()
+        print(name, float(loss), float(cur.grad.abs().max()))
+    np.savez_compressed(os.path.join(GOLDEN, 'soft_histogram.npz'), **out)
+
+
 def _wrapped_G(nb, sf, lat=0, kernel=None, gain=1.0):
     import models.modules.architecture as arch
     cem = _cem(sf, kernel)
@@ -428,7 +449,7 @@ def gen_F7():
     np.savez_compressed(os.path.join(GOLDEN, 'callers_f7.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10}
+ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10, 'F11': gen_F11}
 
 if __name__ == '__main__':
     _refshim.install()

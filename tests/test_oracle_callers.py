@@ -156,3 +156,15 @@ def test_masked_z_search_of_the_oracle_matches_the_reference(objective):
     d = np.abs(z[:, :, ::8, ::8].numpy() - g['zmask_%s/final_Z_sub' % objective])
     assert np.median(d) < 1e-4 and np.mean(d > 1e-2) < 0.01
     assert float((z[:, :, :16] - z0[:, :, :16]).abs().max()) < 1e-6          # outside Z_mask nothing moved (tanh(arctanh(z0)) round trip)
+
+
+@pytest.mark.parametrize('name', ['plain', 'masked'])
+def test_soft_histogram_loss_of_the_oracle_matches_the_reference(name):
+    g = np.load(os.path.join(GOLDEN, 'soft_histogram.npz'))
+    desired = seeded_uniform((1, 3, 40, 36), 1101)
+    cur = (seeded_uniform((2, 3, 40, 36), 1102) ** 2).requires_grad_(True)
+    mask = torch.from_numpy(g['masked/mask']) if name == 'masked' else None
+    loss = cao.soft_hist_loss(cur, desired[0], 64, 0.0, 1.0, 2e-3, mask)
+    loss.backward()
+    assert abs(float(loss) - float(g[name + '/loss'])) < 1e-5 * float(g[name + '/loss'])
+    np.testing.assert_allclose(cur.grad.numpy(), g[name + '/grad'], rtol=1e-3, atol=1e-9)
