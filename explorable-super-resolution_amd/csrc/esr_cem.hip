@@ -306,9 +306,20 @@ __global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __re
     const float* src = x + bc * h * (long long)w;
     const int rows = LT_TY + k - 1, cols = LT_TX + k - 1;
     float* const hp = tile + rows * pitch;
-    for (int e = threadIdx.x; e < rows * cols; e += 256) {
-        const int r = e / cols, c = e - r * cols;
-        tile[r * pitch + c] = src[(long long)clampi(y0 + r - p, 0, h - 1) * w + clampi(x0 + c - p, 0, w - 1)];
+    // staging in batches of SB independent loads per thread: a load -> LDS-write -> next-load chain costs one memory latency per element
+    constexpr int SB = 8;
+    for (int e0 = threadIdx.x; e0 < rows * cols; e0 += 256 * SB) {
+        float tmp[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int e = e0 + u * 256, r = e / cols, c = e - r * cols;
+            tmp[u] = e < rows * cols ? src[(long long)clampi(y0 + r - p, 0, h - 1) * w + clampi(x0 + c - p, 0, w - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int e = e0 + u * 256, r = e / cols, c = e - r * cols;
+            if (e < rows * cols) tile[r * pitch + c] = tmp[u];
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x & 63;
@@ -332,10 +343,13 @@ __global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __restrict__ y, int h, int w, int sf, int pre, const float* __restrict__ tv,
+// SFT: the scale factor as a compile-time constant (2, 3, 4, 8) so that the index divisions / modulos fold into shifts and multiplies; 0 = run-time
+template <int SFT>
+__global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __restrict__ y, int h, int w, int sf_rt, int pre, const float* __restrict__ tv,
                                                               const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
                                                               float* __restrict__ d, int qpitch, int rows) {
     extern __shared__ float tile[];          // [sf][rows][qpitch] de-interleaved window (as cem_downscale_tiled_kernel) | horizontal pass [rows][DT + 1]
+    const int sf = SFT ? SFT : sf_rt;
     const int p = k / 2, Hh = h * sf, Wh = w * sf;
     const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
     const long long bc = blockIdx.z;
@@ -344,11 +358,27 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
     const int cols = (DT - 1) * sf + k;
     const int lg = (sf & (sf - 1)) == 0 ? __builtin_ctz(sf) : -1;
     float* const hp = tile + sf * rows * qpitch;
-    for (int r = threadIdx.x >> 6; r < rows; r += 4) {
-        const float* grow = src + (long long)clampi(Yb + r, 0, Hh - 1) * Wh;
-        for (int c = threadIdx.x & 63; c < cols; c += 64) {
+    {
+        // each wave walks window rows (64 lanes along a row: coalesced); SB rows' loads are in flight together
+        constexpr int SB = 8;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int c0 = 0; c0 < cols; c0 += 64) {
+            const int c = c0 + lane;
             const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
-            tile[(ph * rows + r) * qpitch + q] = grow[clampi(Xb + c, 0, Wh - 1)];
+            const int xs = clampi(Xb + c, 0, Wh - 1);
+            for (int r0 = wv; r0 < rows; r0 += 4 * SB) {
+                float tmp[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int r = r0 + 4 * u;
+                    tmp[u] = (r < rows && c < cols) ? src[(long long)clampi(Yb + r, 0, Hh - 1) * Wh + xs] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int r = r0 + 4 * u;
+                    if (r < rows && c < cols) tile[(ph * rows + r) * qpitch + q] = tmp[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -383,8 +413,8 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
 
 // Polyphase upscale, separable: the vertical pass combines, for every output ROW of the tile, the <= ceil(k/sf) window rows whose taps land on
 // samples (plus the pre == 0 replicate rule) into one row of window-column values; the horizontal pass does the same along the row.
-template <bool TWO>
-__global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf, int pre,
+template <bool TWO, int SFT>
+__global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf_rt, int pre,
                                                             const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
                                                             int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc) {
     extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [UT_Y][wc] | vertical pass 2
@@ -392,6 +422,7 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
     float* const w2 = w1 + wr * wc;
     float* const v1 = w2 + (TWO ? wr * wc : 0);
     float* const v2 = v1 + UT_Y * wc;
+    const int sf = SFT ? SFT : sf_rt;
     const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
     const long long bc = blockIdx.z;
     const int xo0 = blockIdx.x * UT_X, yo0 = blockIdx.y * UT_Y;
@@ -431,8 +462,15 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
     }
     __syncthreads();
     const int xo = xo0 + (threadIdx.x & 63);
-#pragma unroll 1
-    for (int ry = threadIdx.x >> 6; ry < UT_Y; ry += 4) {
+    float gval[UT_Y / 4];                      // the tile's g values first: four independent loads in flight instead of one per iteration
+#pragma unroll
+    for (int q = 0; q < UT_Y / 4; ++q) {
+        const int yq = yo0 + (threadIdx.x >> 6) + 4 * q;
+        gval[q] = (mode >= 1 && xo < Wo && yq < Ho) ? g[(bc * Hh + yq + crop) * (long long)Wh + xo + crop] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < UT_Y / 4; ++q) {
+        const int ry = (threadIdx.x >> 6) + 4 * q;
         const int yq = yo0 + ry;
         if (xo >= Wo || yq >= Ho) continue;
         const int Y = yq + crop, X = xo + crop;
@@ -452,13 +490,12 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
                 u1 = fmaf(th[b], r1[-jb], u1);
                 if (TWO) u2 = fmaf(th[b], r2[-jb], u2);
             }
-        const long long go = (bc * Hh + Y) * (long long)Wh + X;
         const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
         float r;
         if (mode == 0) r = u1;
-        else if (mode == 1) r = g[go] + u1;
-        else if (mode == 2) r = u1 + tanhf(g[go] - u2) * range;
-        else { r = u1; out2[idx] = g[go] - u2; }
+        else if (mode == 1) r = gval[q] + u1;
+        else if (mode == 2) r = u1 + tanhf(gval[q] - u2) * range;
+        else { r = u1; out2[idx] = gval[q] - u2; }
         out[idx] = r;
     }
 }
@@ -564,9 +601,12 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
     const size_t lds = ((size_t)sf * rows * qpitch + (size_t)rows * (DT + 1)) * 4;
     if (lds > 150 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     ESR_CLEAR_ERR();
-    ESR_ALLOW_160K_LDS(cem_downscale_sep_kernel);
-    hipLaunchKernelGGL(cem_downscale_sep_kernel, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w, sf, pre, tv, th,
-                       k, lr, lr_pad, d, qpitch, rows);
+    void (*kern)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int) =
+        sf == 2 ? cem_downscale_sep_kernel<2> : sf == 3 ? cem_downscale_sep_kernel<3> : sf == 4 ? cem_downscale_sep_kernel<4> : sf == 8 ? cem_downscale_sep_kernel<8>
+                                                                                                                              : cem_downscale_sep_kernel<0>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w, sf, pre, tv, th, k, lr, lr_pad, d,
+                       qpitch, rows);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -597,12 +637,15 @@ extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C
     const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
     const dim3 tg((Wo + UT_X - 1) / UT_X, (Ho + UT_Y - 1) / UT_Y, B * C);
     ESR_CLEAR_ERR();
+    typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int);
+    up_t kern;
     if (mode >= 2)
-        hipLaunchKernelGGL(cem_upscale_sep_kernel<true>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2,
-                           wr, wc);
+        kern = sf == 2 ? cem_upscale_sep_kernel<true, 2> : sf == 3 ? cem_upscale_sep_kernel<true, 3> : sf == 4 ? cem_upscale_sep_kernel<true, 4>
+               : sf == 8 ? cem_upscale_sep_kernel<true, 8> : cem_upscale_sep_kernel<true, 0>;
     else
-        hipLaunchKernelGGL(cem_upscale_sep_kernel<false>, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2,
-                           wr, wc);
+        kern = sf == 2 ? cem_upscale_sep_kernel<false, 2> : sf == 3 ? cem_upscale_sep_kernel<false, 3> : sf == 4 ? cem_upscale_sep_kernel<false, 4>
+               : sf == 8 ? cem_upscale_sep_kernel<false, 8> : cem_upscale_sep_kernel<false, 0>;
+    hipLaunchKernelGGL(kern, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2, wr, wc);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }

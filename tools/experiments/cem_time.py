@@ -1,17 +1,37 @@
+"""The CEM filter kernels and the fused projection at the configs[1] size (x4 bicubic, 32 x 128x128 -> 512x512, G output on the padded 148x148
+frame = 592x592) and at the configs[4] size (x8, 'blurry_cubic_2.0': 45x45 / 35x35 taps, 16 x 256x256 -> 2048x2048).
+ESR_CEM_SEPARABLE=0 times the general 2-D kernels instead of the separable fast path."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd')); sys.path.insert(0, ROOT)
 import torch
 import CEM.CEMnet as C
-cem = C.CEMnet(C.Get_CEM_Conf(4))
-net = cem.WrapArchitecture_PyTorch(generated_image=None).cuda().eval()
-lr = torch.rand(32, 3, 128, 128, device='cuda'); g = torch.rand(32, 3, 592, 592, device='cuda'); g512 = torch.rand(32, 3, 512, 512, device='cuda')
+from CEM.imresize_CEM import imresize
+from esr_hip import cem_ops
+
+
 def t(f, n=20):
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-with torch.no_grad():
-    lrp = torch.rand(32, 3, 148, 148, device='cuda')
-    print('downscale %.3f ms  lrfilter %.3f ms  upscale %.3f ms  whole projection (eval) %.3f ms' % (
-        t(lambda: net.DownscaleOP(g)), t(lambda: net.Conv_LR_with_Inv_hTh_OP(lrp)), t(lambda: net.Upscale_OP(lrp)), t(lambda: net([lr, g512]))))
+
+
+for name, sf, kernel, B, lr_size in (('configs[1] x4 bicubic', 4, None, 32, 128), ('configs[4] x8 blurry_cubic_2.0', 8, 'blurry_cubic_2.0', 16, 256)):
+    imresize.kernels = {}
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    net = cem.WrapArchitecture_PyTorch(generated_image=None).cuda().eval()
+    m = int(cem.invalidity_margins_LR)
+    hp = lr_size + 2 * m
+    lr = torch.rand(B, 3, lr_size, lr_size, device='cuda')
+    lrp = torch.rand(B, 3, hp, hp, device='cuda')
+    g = torch.rand(B, 3, sf * hp, sf * hp, device='cuda')
+    td, ti, tu = net.DownscaleOP.taps(), net.Conv_LR_with_Inv_hTh_OP.taps(), net.Upscale_OP.taps()
+    pre = sf - sf // 2 - 1
+    with torch.no_grad():
+        print('%s (taps %d / %d, margin %d): downscale %.3f ms  lrfilter %.3f ms  upscale+combine+crop %.3f ms  fused projection as the forward runs it %.3f ms' % (
+            name, td.shape[0], ti.shape[0], m, t(lambda: cem_ops.downscale_raw(g, td, sf, pre, lr=lr, lr_pad=m)), t(lambda: cem_ops.lr_filter_raw(lrp, ti)),
+            t(lambda: cem_ops.upscale_raw(lrp, tu, sf, pre, g=g, crop=sf * m, mode=1)),
+            t(lambda: cem_ops.project(lr, g, td, ti, tu, sf, pre, lr_pad=m, crop=sf * m))))
+    del g, lr, lrp
+    torch.cuda.empty_cache()
