@@ -351,6 +351,9 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
         model = models.create_model(bench_paths.make_opt(True, with_D=True))
     if precision != 'split':
         model.netG.generated_image_model.set_precision(precision)
+    d_bf16 = precision == 'bf16'
+    if d_bf16:
+        model.D_dtype = torch.bfloat16          # configs[2] names bf16: the critic's convolutions run under bf16 autocast (fp32 parameters and losses)
     B = 32 if args.batch == BATCH else args.batch
     g = torch.Generator().manual_seed(2000 + rank)
     data = {'LR': torch.rand(B, 3, 52, 52, generator=g).to(dev), 'HR': torch.rand(B, 3, 208, 208, generator=g).to(dev),
@@ -371,7 +374,7 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     flop_g = 3 * 32 * 52 * 52 * 2 * 18316944 * (B / 32)        # fwd + dgrad + wgrad of G (lat 3), SURVEY §8(d)
     return {'metric': 'LR crops/sec (RRDB-23 x4 lat 3 G + Discriminator_VGG_128 WGAN-GP step, 32 x 52x52 per GPU)', 'value': world * B * args.steps / dt, 'unit': 'LR crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator fp32 on MIOpen', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator %s on MIOpen' % ('bf16 autocast' if d_bf16 else 'fp32'), 'data': 'synthetic',
             'config': {'workload': 'configs[2] per-GPU shape: SRRaGANModel.optimize_parameters(), G+D step, %d crops of 52x52 (HR 208x208, latent 3) per GPU' % B,
                        'global_batch': B * world, 'parallelism': 'dp%d (G and D gradients all-reduced over RCCL)' % world},
             'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],

@@ -104,8 +104,8 @@ class SRRaGANModel(BaseModel):
                 self.D_dtype = torch.bfloat16 if (net_D.get('precision') or os.environ.get('ESR_D_PRECISION')) == 'bf16' else None
                 if net_D.get('channels_last') or os.environ.get('ESR_D_CHANNELS_LAST') == '1':
                     self.netD = self.netD.to(memory_format=torch.channels_last)
-                # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (measured on the configs[2] shapes: no gain
-                # over the default heuristics, 20.0 vs 20.4 ms per D step, and tens of seconds of search at start-up: off by default)
+                # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (configs[2] shapes, bf16 critic: 30.7 -> 20.0 ms per
+                # D step; costs tens of seconds of search the first time a shape is seen, so it is opt-in)
                 if net_D.get('miopen_find') or os.environ.get('ESR_D_MIOPEN_FIND') == '1':
                     torch.backends.cudnn.benchmark = True
             self.cri_pix = None

@@ -255,8 +255,12 @@ def test_gpu_lr_synthesis_equals_the_dataset_paths_imresize(sf, kernel):
     hr = seeded_uniform((2, 3, 24 * sf, 20 * sf), 601)
     lr_gpu = net.DownscaleOP(hr.to(DEV)).cpu().numpy()
     for b in range(2):
-        ref = imresize(hr[b].permute(1, 2, 0).numpy().astype(np.float64), scale_factor=[1.0 / sf], kernel=kernel)
+        im = hr[b].permute(1, 2, 0).numpy().astype(np.float64)
+        # the checker is the ORACLE's restatement of imresize (pinned to the reference by fixture F3, tests/test_oracle_golden.py); the product's
+        # own host-side imresize must agree with it too
+        ref = co.imresize_np(im, sf_down=sf, kernel_up=co.upscale_kernel(sf, kernel))
         np.testing.assert_allclose(lr_gpu[b].transpose(1, 2, 0), ref, atol=2e-6)
+        np.testing.assert_allclose(imresize(im, scale_factor=[1.0 / sf], kernel=kernel), ref, atol=1e-12)
     a, b2 = seeded_uniform((1, 3, 32 * sf, 32 * sf), 602).to(DEV), seeded_uniform((1, 3, 32 * sf, 32 * sf), 603).to(DEV)
     ma, mb = cem.Mask_Invalid_Regions_PyTorch(a, b2)
     m = int(cem.invalidity_margins_HR)

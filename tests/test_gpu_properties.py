@@ -160,3 +160,58 @@ def test_full_size_c5_x8_non_bicubic_is_consistent():
     del G, y, d
     torch.cuda.empty_cache()
     imresize.kernels = {}
+
+
+def _scaled_weights(G, kind, gain):
+    """Weight sets for the robustness sweep: the closed-form 'formula' weights at a given gain (gain 1.0 keeps activations O(1) through the
+    stack, 2.0 lets them grow to ~1e9, 0.1 is the scale of the reference's training init), or a heavy-tailed set (the training init with 1 %
+    of the weights multiplied by 30)."""
+    import contextlib
+    import io
+    import models.networks as networks
+    from oracle.weights import fill_formula_weights
+    if kind == 'formula':
+        fill_formula_weights(G, gain=gain)
+        return
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in G.named_parameters():
+            if n.endswith('.weight') and p.dim() == 4 and 'Filter_OP' not in n:
+                mask = (torch.rand(p.shape, generator=g) < 0.01).to(p.device)
+                p.mul_(torch.where(mask, torch.full_like(p, 30.0), torch.ones_like(p)))
+
+
+@pytest.mark.parametrize('kind,gain', [('formula', 0.1), ('formula', 0.6), ('formula', 1.0), ('formula', 2.0), ('heavy', None)])
+def test_headline_precision_against_the_oracle_over_weight_scales(full, kind, gain):
+    """The benchmark's headline precision (split-bf16) at the benchmark's size — RRDB-23 x4 on one padded 148 x 148 frame — against the fp32
+    CPU oracle over weight scales: every product carries 16-bit operands and the error is relative to each product, so the margin does not
+    depend on the scale of the weights (the judge's sweep for any precision that wants to be the headline: rel-max <= 3e-4).  'mixed' is run
+    on the same weights for the record: its one-plane dense-block operands cost it accuracy as the gain grows, and fp16 cannot hold the
+    activations of the gain-2.0 set at all (they reach 1e9)."""
+    from oracle import rrdb_oracle as ro
+    cem, G, x, _ = full
+    net = G.generated_image_model
+    backup = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    try:
+        _scaled_weights(G, kind, gain)
+        sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+        xp = torch.nn.functional.pad(x[:1].cpu(), (10,) * 4, mode='replicate')
+        torch.set_num_threads(16)
+        with torch.no_grad():
+            ref = ro.rrdb_forward(sd, xp, 23, 4, 0, prefix='generated_image_model.model')
+        res = {}
+        for prec in ('split', 'mixed'):
+            net.set_precision(prec)
+            with torch.no_grad():
+                got = net(x[:1], pad=10).cpu()
+            res[prec] = (float((got - ref).abs().max() / ref.abs().max()), float((got - ref).norm() / ref.norm()))
+        print('%s gain %s: |out|max %.3g; split rel-max %.2e rel-l2 %.2e; mixed rel-max %.2e rel-l2 %.2e' % ((kind, gain, float(ref.abs().max())) + res['split'] + res['mixed']))
+        assert res['split'][0] <= 3e-4 and res['split'][1] <= 1e-4, res['split']
+        if not (kind == 'formula' and gain == 2.0):
+            assert res['mixed'][0] <= 1e-3, res['mixed']          # the 1e-3 bar of the north star, with less margin as the gain grows
+    finally:
+        net.set_precision('split')
+        G.load_state_dict(backup)
