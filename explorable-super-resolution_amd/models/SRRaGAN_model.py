@@ -106,7 +106,10 @@ class SRRaGANModel(BaseModel):
                     self.netD = self.netD.to(memory_format=torch.channels_last)
                 # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (configs[2] shapes, bf16 critic: 30.7 -> 20.0 ms per
                 # D step; costs tens of seconds of search the first time a shape is seen, so it is opt-in)
-                if net_D.get('miopen_find') or os.environ.get('ESR_D_MIOPEN_FIND') == '1':
+                find = bool(net_D.get('miopen_find'))
+                if os.environ.get('ESR_D_MIOPEN_FIND') in ('0', '1'):          # override (tests keep start-up short)
+                    find = os.environ['ESR_D_MIOPEN_FIND'] == '1'
+                if find:
                     torch.backends.cudnn.benchmark = True
             self.cri_pix = None
             if train_opt['pixel_weight'] is not None:

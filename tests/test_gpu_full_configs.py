@@ -132,3 +132,18 @@ def test_configs2_generator_plus_discriminator_step_bf16_against_fp32():
         cos = [_cos(a, b) for a, b in zip(a_list, b_list) if float(a.norm()) > 1e-4 * top]
         assert len(cos) >= 5 and min(cos) > 0.95, (what, len(cos), min(cos))
     print('configs[2] G+D step: ' + ', '.join('%s %.4f/%.4f' % (k, lr_[k], lb[k]) for k in ('l_d_real', 'l_d_fake', 'l_d_gp', 'l_g_gan', 'l_g_pix')))
+
+
+def test_bench_c3_workload_prints_the_contract_line(capsys, monkeypatch):
+    """`python bench.py --workload c3` (configs[2] G+D step at its per-GPU shape): one JSON line with the contract's keys, phase times and losses."""
+    import json
+    import bench
+    monkeypatch.setenv('ESR_D_MIOPEN_FIND', '0')
+    bench.main(['--workload', 'c3', '--steps', '2', '--warmup', '2'])
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0 and 'bf16' in d['dtype'] and 'workload' in d['config']
+    assert set(d['phases_ms']) >= {'G_forward', 'D_step', 'G_losses_and_backward', 'G_allreduce_and_Adam'}
+    assert all(np.isfinite(v) for v in d['losses'].values()) and {'l_d_real', 'l_d_gp', 'l_g_gan', 'l_g_pix'} <= set(d['losses'])
