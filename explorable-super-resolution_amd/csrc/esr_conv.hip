@@ -621,8 +621,16 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                                 const int sp = rg % r2;
                                 o = b * a.out.bs + (rg / r2) * a.out.cs + (long long)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1);
                             }
+#ifdef ESR_ABL_NOSTORE                     // ablation (timing only, wrong results): the epilogue computes but stores one pixel per wave
+                            if ((lane & 63) != 0) continue;
+#endif
+#ifdef ESR_ABL_NTSTORE                     // experiment: non-temporal stores (the next layer reads through L2 / MALL anyway)
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hv), &((u32x4*)a.out.hi)[o]);
+                            if (NPL == 2 && (!PARTLO || a.out.lo)) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, lv), &((u32x4*)a.out.lo)[o]);
+#else
                             ((uint4*)a.out.hi)[o] = hv;
                             if (NPL == 2 && (!PARTLO || a.out.lo)) ((uint4*)a.out.lo)[o] = lv;
+#endif
                             if (EPI & EPI_OUT2) {
                                 const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
                                 ((uint4*)a.out2.hi)[o2] = hv;
