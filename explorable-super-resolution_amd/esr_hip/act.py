@@ -174,6 +174,9 @@ class PackedConv:
         return (torch.tensor(kmap, dtype=torch.int32, device=dev), torch.tensor(mmap, dtype=torch.int32, device=dev))
 
     # -- pieces the engine's batched re-pack is assembled from (esr_pack_batch_*); get() is the stand-alone path
+    def weights(self):
+        return (self.weight,)
+
     def key(self):
         w = self.weight
         return (w.data_ptr(), w._version, None if self.bias_p is None else (self.bias_p.data_ptr(), self.bias_p._version))
@@ -236,15 +239,20 @@ class PackBatch:
     re-uploaded only when a pointer changes, so a training step costs one kernel instead of ~1700 tiny ones."""
 
     def __init__(self):
-        self.ptr_key, self.ws, self.n, self.nblocks = None, None, 0, 0
+        self.pack_ids, self.wptrs, self.ws, self.n, self.nblocks = None, None, None, 0, 0
 
     def run(self, packs):
-        jobs = []
-        for pk in packs:
-            pk.prepare()
-            jobs += [j + (fmt_code(pk.split),) for j in pk.jobs()]
-        ptr_key = tuple((j[0].data_ptr(), j[7]) for j in jobs)
-        if ptr_key != self.ptr_key:
+        """Steady state of a training step (same packs, same weight storages, new values): one esr_pack_batch_run — the per-pack job lists are
+        rebuilt only when a pack or a weight pointer changed."""
+        ids = tuple(id(pk) for pk in packs)
+        wptrs = tuple(w.data_ptr() for pk in packs for w in pk.weights())
+        if ids != self.pack_ids or wptrs != self.wptrs:
+            jobs = []
+            for pk in packs:
+                pk.prepare()
+                jobs += [j + (fmt_code(pk.split),) for j in pk.jobs()]
+            if any(j[0].dtype != torch.float32 or not j[0].is_contiguous() for j in jobs):
+                wptrs = None            # a converted copy is packed: it must be refreshed every time, no fast path
             arr = (_lib.PackDesc * len(jobs))()
             for d, (wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst, code) in zip(arr, jobs):
                 d.w, d.cout_w, d.cin_w = wd.data_ptr(), wd.shape[0], wd.shape[1]
@@ -255,7 +263,8 @@ class PackBatch:
             self.ws = torch.empty(int(need), dtype=torch.uint8, device=jobs[0][0].device)
             nb = _lib.lib.esr_pack_batch_upload(arr, len(jobs), self.ws.data_ptr(), self.ws.numel(), stream_ptr())
             check(min(nb, 0), 'esr_pack_batch_upload')
-            self.ptr_key, self.n, self.nblocks = ptr_key, len(jobs), int(nb)
+            self.n, self.nblocks = len(jobs), int(nb)
+            self.pack_ids, self.wptrs = ids, wptrs
         check(_lib.lib.esr_pack_batch_run(self.ws.data_ptr(), self.n, self.nblocks, stream_ptr()), 'esr_pack_batch_run')
         for pk in packs:
             pk.after_pack()
@@ -273,6 +282,9 @@ class PackedSum:
         self._key = None
         self.wpack = None
         self.bias = None
+
+    def weights(self):
+        return tuple(w for w, _ in self.pieces)
 
     def key(self):
         return tuple((w.data_ptr(), w._version) for w, _ in self.pieces)

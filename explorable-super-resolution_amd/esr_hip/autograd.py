@@ -73,9 +73,21 @@ def tap_tables(taps):
 
 
 def _tabs_for(taps):
-    # built per call (a handful of k x k cumsums): a cache keyed on the tensor's address would go stale when the allocator
-    # hands the same address to another module's taps
-    return tap_tables(taps)
+    """The adjoint's cumulative tap tables, cached next to the taps' device copy ON the tensor that owns the storage (the frozen
+    Filter_OP.weight; see cem_ops._taps_entry — a cache keyed on data pointers would go stale when the allocator recycles an address)."""
+    owner = taps._base if taps._base is not None else taps
+    key = ('tabs', owner._version, tuple(taps.shape), taps.storage_offset(), str(taps.device))
+    cache = getattr(owner, '_esr_taps', None)
+    if cache is None:
+        cache = {}
+        try:
+            owner._esr_taps = cache
+        except Exception:
+            return tap_tables(taps)
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = tap_tables(taps)
+    return hit
 
 
 class CemLinear(torch.autograd.Function):

@@ -40,6 +40,7 @@ class RRDBEngine:
         self._bufs = {}
         self._gpool, self._gpool_key = {}, None
         self._pack_batch = A.PackBatch()
+        self._packs_fp = None
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
@@ -96,10 +97,17 @@ class RRDBEngine:
         return out
 
     def _refresh_packs(self):
-        """Re-pack every existing pack (forward and data-gradient ones) in one launch if any parameter changed since the last time."""
-        packs = [p for d in (self._packed, self._packed_t, self._packed_rdb_t) if d for p in d.values()]
+        """Re-pack every existing pack (forward and data-gradient ones) in one launch if any parameter changed since the last time.
+        Steady state is one tuple comparison: the (storage, version) fingerprint of the parameters and the identity of the pack set; the
+        per-pack staleness keys are only consulted when that fingerprint moved."""
+        dicts = (self._packed, self._packed_t, self._packed_rdb_t)
+        fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(id(d) for d in dicts), self.generation)
+        if fp == self._packs_fp:
+            return
+        packs = [p for d in dicts if d for p in d.values()]
         if any(p.stale() for p in packs):
             self._pack_batch.run(packs)
+        self._packs_fp = fp
 
     @property
     def _bwd_split(self):

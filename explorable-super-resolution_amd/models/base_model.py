@@ -82,9 +82,12 @@ class BaseModel():
     def Set_Require_Grad_Status(self, network, status):
         # (the CEM's fixed filter taps stay frozen: the reference flips them too, harmlessly — they are in no optimizer — but autograd then
         # spends a depth-wise weight gradient on them every step)
-        for name, p in network.named_parameters():
-            if 'Filter_OP' not in name:
-                p.requires_grad = status
+        cache = self.__dict__.setdefault('_trainable', {})
+        entry = cache.get(id(network))
+        if entry is None or entry[0] is not network:      # the module tree is walked once per network (702 parameters for RRDB-23)
+            entry = cache[id(network)] = (network, [p for name, p in network.named_parameters() if 'Filter_OP' not in name])
+        for p in entry[1]:
+            p.requires_grad = status
 
     def process_loaded_state_dict(self, loaded_state_dict, current_state_dict):
         """Positional key matching + latent zero-extension (reference base_model.py:146-190)."""

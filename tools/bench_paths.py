@@ -100,7 +100,10 @@ def main():
                 'Z': torch.rand(B, 3, 208, 208, device=dev) * 2 - 1}
         for _ in range(3):
             model.feed_data(data); model.optimize_parameters()
-        model.timing = {}
+        if os.environ.get('ESR_GC_OFF') == '1':
+            import gc
+            gc.collect(); gc.disable()
+        model.timing = None if os.environ.get('ESR_NO_PHASES') == '1' else {}      # the phase timers synchronise every step: ESR_NO_PHASES=1 measures the free-running step
         sync(); t0 = time.perf_counter()
         for _ in range(a.steps):
             model.feed_data(data); model.optimize_parameters()
@@ -108,7 +111,8 @@ def main():
         if D.rank() == 0:
             print('c3 generator step [' + a.precision + '] (RRDB-%d x4 + CEM, lat 3, %d x 52x52 per GPU, %d GPU(s)): %.1f ms/step, %.0f LR crops/s, l_g_pix %.4f, peak %.1f GB'
                   % (a.nb, B, D.world_size(), dt * 1e3, B * D.world_size() / dt, model.get_current_log()['l_g_pix'], torch.cuda.max_memory_allocated() / 2 ** 30))
-            print('   phases (GPU ms per step, step synchronised for the timers): ' + ', '.join('%s %.1f' % (k, v / a.steps) for k, v in model.timing.items()))
+            if model.timing is not None:
+                print('   phases (GPU ms per step, step synchronised for the timers): ' + ', '.join('%s %.1f' % (k, v / a.steps) for k, v in model.timing.items()))
     else:
         from Z_optimization import Z_optimizer
         B = a.batch or 64
