@@ -70,6 +70,15 @@ constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE;
 #define ESR_WREG 0
 #endif
 constexpr bool wreg_of(int npw) { return ESR_WREG != 0 && npw == 1; }
+// EXPERIMENT (-DESR_PC=1 builds the variants, ESR_CONV_STAGES=3 selects them at run time): producer / consumer waves for the launches with
+// one workgroup per CU, see NST == 3 at conv3x3_tile_kernel.  Measured at the 32 x 52x52 training shape (same GPU, bit-identical results):
+// 19 % fewer shader cycles per chunk for the split 32-channel kernel (4806 -> 3893) at a 15 % lower shader clock (1.79 -> 1.53 GHz) —
+// 27.9 -> 26.2 us per launch; 72.5 -> 72.5 us for the split 64-channel kernel; bf16 13.3 -> 14.8 and 36.1 -> 30.1 us; whole training step
+// 47.7 -> 47.3 ms (split), 24.5 -> 25.8 ms (bf16) — while the two-stage kernel with the exact, balanced copies of dma_share() alone runs that
+// step in 45.6 ms.  The chip gives the saved cycles back as clock, so it is not the default.
+#ifndef ESR_PC
+#define ESR_PC 0
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // asynchronous 16-byte global load into a register quad, hidden from the compiler like glds16 (same reason: no vmcnt(0) drains); the value
@@ -132,7 +141,8 @@ template <> __device__ __forceinline__ uint32_t cvt_pk<1>(float lo, float hi) { 
 // copy is ordered by hand: wait_vm_upto() + barrier before the first read of a stage (see the step loop).
 // M0 (the DMA's LDS base) is not preserved by hipcc across statements and no other instruction of this kernel reads it.
 __device__ __forceinline__ void glds16(const uint4* src, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
+    // (readfirstlane: the destination is wave-uniform by construction, but the compiler cannot always prove it and M0 takes a scalar)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
@@ -195,24 +205,62 @@ __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int 
     return r;
 }
 
-// the DMA of one step is a list of independent 1 KiB instructions so that it can be issued in slices between MFMAs:
-// ops [0, 2*NPL*MAXS) = activation slot s, plane (group, hi|lo);  then ceil(9*MT*NPL / NW) weight-fragment ops
-template <int NPL, int MT, int NPW>
-__device__ __forceinline__ void dma_op(const FetchState& f, const Bases<NPL>& bs, int op, unsigned stage, int plane_bytes, int wave,
-                                       bool xlo = true) {
-    constexpr int MAXS = maxs_of(MT);
-    constexpr int NWI = wreg_of(NPW) ? 0 : 9 * MT * NPW, NACT = 2 * NPL * MAXS, NOPS = NACT + (NWI + NW - 1) / NW;
-    if (op < NACT) {
-        const int s = op / (2 * NPL), cgpl = op % (2 * NPL);
-        if (!xlo && (cgpl % NPL) == 1) return;      // this chunk's groups have no lo plane
-        const int so = f.soff[s];
-        const int slot = f.slot[s];
-        if (so >= 0) glds16(bs.p[cgpl] + so, stage + cgpl * plane_bytes + slot * 1024);
-    } else if (op < NOPS) {
-        int j = (op - NACT) * NW + wave;
-        if (j >= NWI) j = wave;            // constant instruction count per wave: re-fetch the first fragment
-        glds16(bs.w + j * 64, stage + 2 * NPL * plane_bytes + j * 1024);
+// Which copies of a chunk this wave issues.  A chunk is 2*NPL activation planes x `nslots` 1-KiB slots plus NWI 1-KiB weight fragments; wave w
+// owns the slots w, w + NW, ... (setup_tile) and a contiguous range of weight fragments sized so that every wave issues the same number of
+// copies (+-1): a 1-KiB global_load_lds occupies its in-order wave for 90-150 cycles (profiles/microbench/ingest_paths.hip), the barrier
+// behind the copies waits for the slowest wave, and nothing is fetched twice.
+struct DmaShare {
+    int nsl;                   // activation slots of this wave
+    int w0, wc;                // its weight fragments [w0, w0 + wc)
+};
+template <int NPL, int NWI>
+__device__ __forceinline__ DmaShare dma_share(int npix_l, int wave) {
+    const int nslots = (npix_l + 63) >> 6;
+    const int target = (2 * NPL * nslots + NWI + NW - 1) / NW;
+    DmaShare d{0, 0, 0};
+    int start = 0;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) {
+        const int nv = (nslots - v + NW - 1) / NW;
+        int c = target - 2 * NPL * nv;
+        c = c < 0 ? 0 : c;
+        if (c > NWI - start || v == NW - 1) c = NWI - start;
+        if (v == wave) { d.nsl = nv; d.w0 = start; d.wc = c; }
+        start += c;
     }
+    return d;
+}
+// number of copies dma_chunk() issues (for the counted waits of the two-stage kernels)
+template <int NPL>
+__device__ __forceinline__ int dma_count(const DmaShare& d, bool xlo) { return (xlo ? 2 * NPL : 2) * d.nsl + d.wc; }
+
+template <int NPL, int MT, int NPW>
+__device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo) {
+    constexpr int MAXS = maxs_of(MT);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s >= d.nsl) break;                          // wave-uniform
+        const int so = f.soff[s];
+        const unsigned dst = stage + (unsigned)f.slot[s] * 1024;
+#pragma unroll
+        for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
+            if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
+            if (so >= 0) glds16(bs.p[cgpl] + so, dst + cgpl * plane_bytes);
+        }
+    }
+    for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16(bs.w + j * 64, stage + 2 * NPL * plane_bytes + j * 1024);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm_upto(int n) {
+#define ESR_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        ESR_VMC(1) ESR_VMC(2) ESR_VMC(3) ESR_VMC(4) ESR_VMC(5) ESR_VMC(6) ESR_VMC(7) ESR_VMC(8) ESR_VMC(9) ESR_VMC(10) ESR_VMC(11) ESR_VMC(12)
+        ESR_VMC(13) ESR_VMC(14) ESR_VMC(15) ESR_VMC(16) ESR_VMC(17) ESR_VMC(18) ESR_VMC(19) ESR_VMC(20) ESR_VMC(21) ESR_VMC(22) ESR_VMC(23)
+        ESR_VMC(24) ESR_VMC(25) ESR_VMC(26) ESR_VMC(27) ESR_VMC(28) ESR_VMC(29) ESR_VMC(30) ESR_VMC(31) ESR_VMC(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;       // 0, or more than the cases cover: wait for everything (always safe)
+    }
+#undef ESR_VMC
 }
 
 // Residual / mask operand of one PAIR of channel groups (cg0, cg0+1) at this lane's pixel, read the way the output is stored:
@@ -361,8 +409,12 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
+//   NST == 3: the same two LDS stages with EIGHT waves: waves 4-7 ("producers") only issue the DMA of chunk c+1 and wait for it, waves 0-3
+//             ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
+//             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
+//             placed), so only a second wave on the same SIMD can multiply meanwhile.
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
-__global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
     // PARTLO: only the first a.lo_chunks chunks of the input carry a lo plane (a dense block's trunk input), the rest are single-plane
     // intermediates; and the output's lo plane is optional.  Non-PARTLO kernels treat every chunk alike.
     static_assert(!PARTLO || NPL == 2, "partial lo needs hi+lo activations");
@@ -372,13 +424,18 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool PC = NST == 3;                                  // producer / consumer waves
+    constexpr int NSTAGES = NST == 1 ? 1 : 2;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = PC && wave_all >= NW;
+    const int wave = PC ? (wave_all % NW) : wave_all;
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
     constexpr bool WREG = wreg_of(NPW);
+    static_assert(!(PC && WREG), "the weights-in-registers experiment has no producer/consumer form");
     constexpr int NWI = WREG ? 0 : 9 * MT * NPW;                   // weight fragments staged in LDS per chunk
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    float* const s_bias = (float*)(smem + NST * stage_bytes);
+    float* const s_bias = (float*)(smem + NSTAGES * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
@@ -386,9 +443,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     if (blockIdx.x / nxcd >= per_xcd || tile_f >= ntiles) return;
     const int tile = a.reverse ? ntiles - 1 - tile_f : tile_f;
     if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
-    constexpr int NACT = 2 * NPL * MAXS;
-    constexpr int NWOP = (NWI + NW - 1) / NW;
-    constexpr int NOPS = NACT + NWOP;
+    const DmaShare share = dma_share<NPL, NWI>(a.NPIX_L, wave);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 #ifdef ESR_TRACE
     unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
@@ -413,7 +468,6 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #else
     constexpr int NTERM_CAP = 3;
 #endif
-    constexpr int NOPS_HI = NACT / NPL + NWOP;       // DMA instructions of a hi-only chunk
     u32x4 wa[9 * MT];                                // (WREG) the current chunk's A fragments
     const uint4* const wbase = a.wpack + lane;       // fragment f of chunk cp: wbase + (cp * 9 * MT + f) * 64
     if (WREG) {
@@ -422,43 +476,59 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     }
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
-        const bool xlo0 = !PARTLO || 0 < a.lo_chunks;
-#pragma unroll
-        for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave, xlo0);
+        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks);
+    }
+    auto produce = [&](const int cp) {          // (producer waves) all copies of chunk cp into its stage, landed when this returns
+        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
+        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (cp & 1) * stage_bytes, plane_bytes, !PARTLO || cp < a.lo_chunks);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (PC) {
+        if (producer) produce(0);
+        __syncthreads();
     }
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
     // plane.  The chunks with a lo plane come first, so the K loop is two loops over the same step with XLO = true / false: a run-time
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
     auto step = [&](auto XLO_T, const int cp) {
         constexpr bool xlo = decltype(XLO_T)::value;
-        const int st = NST == 2 ? (cp & 1) : 0;
+        const int st = NST >= 2 ? (cp & 1) : 0;
         const unsigned char* const sb = sb0 + st * stage_bytes;
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
+        if constexpr (PC) {
+            // stage (cp+1)&1 was last read in iteration cp-1, closed by that iteration's barrier
+            if (producer) {
+                if (cp + 1 < a.ncp) produce(cp + 1);
+            } else {
+                ESR_TR(); ESR_TR(); ESR_TR();
+                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr);
+                if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
+            }
+            ESR_TR();
+            __syncthreads();
+            return;
+        }
         if (NST == 1) {
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
-#pragma unroll
-            for (int op = 0; op < NOPS; ++op) {
+            DmaShare sh = share;
 #ifdef ESR_ABL_NOWDMA
-                if (op >= NACT && cp > 0) continue;
+            if (cp > 0) sh.wc = 0;
 #endif
 #ifdef ESR_ABL_NOADMA
-                if (op < NACT && cp > 0) continue;
+            if (cp > 0) sh.nsl = 0;
 #endif
-                dma_op<NPL, MT, NPW>(fs, bs, op, lds0, plane_bytes, wave, xlo);
-            }
+            dma_chunk<NPL, MT, NPW>(fs, bs, sh, lds0, plane_bytes, xlo);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (cp + 1 < a.ncp) {
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
-            // everything EXCEPT the NOPS copies just issued (every wave issues exactly NOPS per chunk, see dma_op / setup_tile)
+            // everything EXCEPT the copies just issued
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 1, fs.b, lane);
             const bool xlo_next = !PARTLO || cp + 1 < a.lo_chunks;
-#pragma unroll
-            for (int op = 0; op < NOPS; ++op) dma_op<NPL, MT, NPW>(fs, bs, op, lds0 + (st ^ 1) * stage_bytes, plane_bytes, wave, xlo_next);
+            dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (st ^ 1) * stage_bytes, plane_bytes, xlo_next);
             ESR_TR();
-            if (xlo_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPS_HI) : "memory");
+            wait_vm_upto(dma_count<NPL>(share, xlo_next));
         } else {
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -481,6 +551,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     if constexpr (PARTLO)
         for (int cp = lo_end; cp < a.ncp; ++cp) step(std::false_type{}, cp);
     ESR_TR();
+    if (PC && producer) return;
     {
         // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
         // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
@@ -749,10 +820,10 @@ template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
     ESR_ALLOW_160K_LDS(k);
-    const size_t lds = NST * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024) + (size_t)MT * 32 * 4;
+    const size_t lds = (NST == 1 ? 1 : 2) * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024) + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -763,7 +834,13 @@ int launch(const ConvArgs& a, hipStream_t s) {
     // geometry is chosen for two resident single-stage workgroups)
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
-    const bool two = force ? force == 2 : ntiles <= 320;
+    const bool small = ntiles <= 320;
+#if ESR_PC
+    if constexpr (!wreg_of(NPW)) {
+        if (force == 3) return launch_nst<NPL, MT, EPI, 3, FMT, NPW, PARTLO>(a, s);
+    }
+#endif
+    const bool two = force ? force == 2 : small;
     return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO>(a, s);
 }
 

@@ -4,16 +4,17 @@ sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd'))
 import numpy as np, torch
 from esr_hip import _lib, act
 dev = 'cuda'
-B, H, W = 32, 148, 148
+B, H, W = [int(v) for v in os.environ.get("SHAPE", "32,148,148").split(",")]
+SPLIT = os.environ.get("SPLIT", "split") == "split"          # split (bf16 hi+lo, 3 MFMAs) | bf16 (one plane)
 cin, cout = int(sys.argv[1]) if len(sys.argv) > 1 else 128, int(sys.argv[2]) if len(sys.argv) > 2 else 32
 torch.manual_seed(0)
-buf = act.ActBuf(B, 24, H, W, dev)
+buf = act.ActBuf(B, 24, H, W, dev, split=SPLIT)
 buf.hi[:, :, 1:-1, 1:-1].copy_((torch.randn(B, 24, H, W, 8, device=dev) * 0.5).to(torch.bfloat16).view(torch.int16))
-buf.lo[:, :, 1:-1, 1:-1].copy_((torch.randn(B, 24, H, W, 8, device=dev) * 0.002).to(torch.bfloat16).view(torch.int16))
+if buf.lo is not None: buf.lo[:, :, 1:-1, 1:-1].copy_((torch.randn(B, 24, H, W, 8, device=dev) * 0.002).to(torch.bfloat16).view(torch.int16))
 w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
 bias = torch.randn(cout, device=dev) * 0.1
-pc = act.PackedConv(w, bias, 0).get()
-obuf = act.ActBuf(B, 8, H, W, dev)
+pc = act.PackedConv(w, bias, 0, split=SPLIT).get()
+obuf = act.ActBuf(B, 8, H, W, dev, split=SPLIT)
 out = buf.view(cin // 8, (cout + 7) // 8) if cin + cout <= 192 else obuf.view()
 res1 = buf.view(0, 8) if cout == 64 else None
 def run():
