@@ -359,24 +359,38 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
     const int lg = (sf & (sf - 1)) == 0 ? __builtin_ctz(sf) : -1;
     float* const hp = tile + sf * rows * qpitch;
     {
-        // each wave walks window rows (64 lanes along a row: coalesced); SB rows' loads are in flight together
-        constexpr int SB = 8;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        for (int c0 = 0; c0 < cols; c0 += 64) {
-            const int c = c0 + lane;
-            const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
-            const int xs = clampi(Xb + c, 0, Wh - 1);
-            for (int r0 = wv; r0 < rows; r0 += 4 * SB) {
-                float tmp[SB];
+        // the window [rows][cols] as 16-byte vectors of 4 columns starting at a multiple of 4 (rows of a contiguous fp32 image whose width is a
+        // multiple of 4 are 16-byte aligned); vectors that stick out of the image row, or an unaligned image, take four clamped scalar loads.
+        // SB vectors per thread are in flight together; each lands as four LDS words in the de-interleaved planes.
+        constexpr int SB = 4;
+        const int Xa = (Xb >> 2) << 2;                       // floor to a multiple of 4 (arithmetic shift: also for negative Xb)
+        const int nvec = (Xb + cols - Xa + 3) >> 2;
+        const bool vec_ok = (Wh & 3) == 0 && (((size_t)src) & 15) == 0;
+        for (int e0 = threadIdx.x; e0 < rows * nvec; e0 += 256 * SB) {
+            float4 tmp[SB];
 #pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int r = r0 + 4 * u;
-                    tmp[u] = (r < rows && c < cols) ? src[(long long)clampi(Yb + r, 0, Hh - 1) * Wh + xs] : 0.f;
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + u * 256;
+                tmp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < rows * nvec) {
+                    const int r = e / nvec, x = Xa + 4 * (e - r * nvec);
+                    const float* rowp = src + (long long)clampi(Yb + r, 0, Hh - 1) * Wh;
+                    if (vec_ok && x >= 0 && x + 3 < Wh) tmp[u] = *(const float4*)(rowp + x);
+                    else tmp[u] = make_float4(rowp[clampi(x, 0, Wh - 1)], rowp[clampi(x + 1, 0, Wh - 1)], rowp[clampi(x + 2, 0, Wh - 1)], rowp[clampi(x + 3, 0, Wh - 1)]);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int r = r0 + 4 * u;
-                    if (r < rows && c < cols) tile[(ph * rows + r) * qpitch + q] = tmp[u];
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + u * 256;
+                if (e >= rows * nvec) continue;
+                const int r = e / nvec, c0 = Xa + 4 * (e - r * nvec) - Xb;
+                const float v[4] = {tmp[u].x, tmp[u].y, tmp[u].z, tmp[u].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = c0 + t;
+                    if (c < 0 || c >= cols) continue;
+                    const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+                    tile[(ph * rows + r) * qpitch + q] = v[t];
                 }
             }
         }
@@ -461,21 +475,30 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
         if (TWO) v2[e] = u2;
     }
     __syncthreads();
-    const int xo = xo0 + (threadIdx.x & 63);
-    float gval[UT_Y / 4];                      // the tile's g values first: four independent loads in flight instead of one per iteration
+    // horizontal pass: a thread owns 4 consecutive output columns of one row (16 rows x 16 quads = the 256 threads): g comes in and the
+    // result goes out as 16-byte vectors when the rows are 16-byte aligned (else element by element)
+    static_assert(UT_Y * (UT_X / 4) == 256, "one quad of output columns per thread");
+    const int ry = threadIdx.x / (UT_X / 4), xo = xo0 + 4 * (threadIdx.x % (UT_X / 4));
+    const int yq = yo0 + ry;
+    if (xo >= Wo || yq >= Ho) return;
+    const int Y = yq + crop;
+    const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
+    const float* gp = mode >= 1 ? g + (bc * Hh + Y) * (long long)Wh + xo + crop : nullptr;
+    const bool full = xo + 3 < Wo;
+    const bool vec_g = full && mode >= 1 && ((((size_t)gp) & 15) == 0);
+    const bool vec_o = full && (((size_t)(out + idx)) & 15) == 0 && (mode != 3 || (((size_t)(out2 + idx)) & 15) == 0);
+    float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec_g) { const float4 t = *(const float4*)gp; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
+    else if (mode >= 1) {
 #pragma unroll
-    for (int q = 0; q < UT_Y / 4; ++q) {
-        const int yq = yo0 + (threadIdx.x >> 6) + 4 * q;
-        gval[q] = (mode >= 1 && xo < Wo && yq < Ho) ? g[(bc * Hh + yq + crop) * (long long)Wh + xo + crop] : 0.f;
+        for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[t] = gp[t];
     }
+    const float* r1 = v1 + ry * wc;
+    const float* r2 = v2 + ry * wc;
+    float res[4], res2[4];
 #pragma unroll
-    for (int q = 0; q < UT_Y / 4; ++q) {
-        const int ry = (threadIdx.x >> 6) + 4 * q;
-        const int yq = yo0 + ry;
-        if (xo >= Wo || yq >= Ho) continue;
-        const int Y = yq + crop, X = xo + crop;
-        const float* r1 = v1 + ry * wc;
-        const float* r2 = v2 + ry * wc;
+    for (int t = 0; t < 4; ++t) {
+        const int X = xo + t + crop;
         float u1 = 0.f, u2 = 0.f;
         int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
         int jl = (X + b0 - p - pre) / sf - jb;
@@ -490,13 +513,22 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
                 u1 = fmaf(th[b], r1[-jb], u1);
                 if (TWO) u2 = fmaf(th[b], r2[-jb], u2);
             }
-        const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
-        float r;
-        if (mode == 0) r = u1;
-        else if (mode == 1) r = gval[q] + u1;
-        else if (mode == 2) r = u1 + tanhf(gval[q] - u2) * range;
-        else { r = u1; out2[idx] = gval[q] - u2; }
-        out[idx] = r;
+        res2[t] = 0.f;
+        if (mode == 0) res[t] = u1;
+        else if (mode == 1) res[t] = gv[t] + u1;
+        else if (mode == 2) res[t] = u1 + tanhf(gv[t] - u2) * range;
+        else { res[t] = u1; res2[t] = gv[t] - u2; }
+    }
+    if (vec_o) {
+        *(float4*)(out + idx) = make_float4(res[0], res[1], res[2], res[3]);
+        if (mode == 3) *(float4*)(out2 + idx) = make_float4(res2[0], res2[1], res2[2], res2[3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (xo + t < Wo) {
+                out[idx + t] = res[t];
+                if (mode == 3) out2[idx + t] = res2[t];
+            }
     }
 }
 
