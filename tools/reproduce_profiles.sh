@@ -15,6 +15,7 @@ if [ "$PREC" = c3 ]; then
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/stats" -- python bench.py --workload c3 --steps 6 --warmup 4 > "$OUT/stats.log" 2>&1
   python tools/summarise_step_trace.py --trace "$OUT/stats" --tag "$TAG" --steps 4
   python bench.py --workload c3 --steps 10 --warmup 3 | tee "profiles/${TAG}_bench.json.log"
+  cp profiles/${TAG}_* gpurun_out/        # (gpurun merges only gpurun_out/ back: copy the summaries there too)
   exit 0
 fi
 B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --precision $PREC"
@@ -25,3 +26,4 @@ python tools/summarise_profiles.py --tag "$TAG" --stats "$(dirname "$(find "$OUT
     --fetch "$(dirname "$(find "$OUT/fetch" -name '*_counter_collection.csv' | head -1)")" \
     --write "$(dirname "$(find "$OUT/write" -name '*_counter_collection.csv' | head -1)")"
 python bench.py --steps 10 --warmup 3 --precision "$PREC" | tee "profiles/${TAG}_bench.json.log"
+cp profiles/${TAG}_* gpurun_out/

@@ -49,7 +49,19 @@ def main():
         fo.write('kernel,launches_per_step,avg_us,ms_per_step,percent_of_kernel_time\n')
         for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             fo.write('"%s",%.1f,%.1f,%.3f,%.1f\n' % (k, n / a.steps, t / n / 1e3, t / 1e6 / a.steps, 100 * t / 1e6 / a.steps / busy))
-    print(open(out).read()[:3000])
+        # who owns the time: the library's kernels, the critic's convolutions (MIOpen / CK), and torch's element-wise / reduction / copy glue
+        groups = collections.OrderedDict((g, 0) for g in ('esr_hip conv / wgrad / pack / CEM', 'MIOpen + CK convolutions', 'MIOpen batch norm',
+                                                            'layout transposes', 'torch element-wise / reductions / copies', 'other'))
+        for k, (n, t) in per.items():
+            if re.match(r'(conv3x3_|pack_|cem_|act_|unpack_|grad_|pixel_|soft_hist|zero_)', k): g = 'esr_hip conv / wgrad / pack / CEM'
+            elif 'igemm' in k or 'grouped_conv' in k or 'Conv' in k or 'gemm' in k.lower() or 'Cijk' in k: g = 'MIOpen + CK convolutions'
+            elif 'BatchNorm' in k: g = 'MIOpen batch norm'
+            elif 'transpose' in k: g = 'layout transposes'
+            elif k.startswith('at::') or 'elementwise' in k or 'reduce' in k or 'SubTensor' in k: g = 'torch element-wise / reductions / copies'
+            else: g = 'other'
+            groups[g] += t
+        fo.write('# by owner (ms per step):' + '; '.join(' %s %.2f' % (g, t / 1e6 / a.steps) for g, t in groups.items()) + '\n')
+    print(open(out).read()[:6000])
 
 
 if __name__ == '__main__':
