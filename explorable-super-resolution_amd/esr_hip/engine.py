@@ -438,8 +438,11 @@ class RRDBEngine:
         G_g = galloc(B, 1, H, W)
         A.pack_nchw(dg, G_g.view(), 0, net.out_nc)
         G_hr0 = galloc(B, 8, H, W)
-        GZ_hr = galloc(B, 1, H, W) if (has_lat and lat) else None
-        GZ_lr = galloc(B, 1, h, w) if has_lat else None
+        # the latent's own gradient is only computed when the input asks for one (Z search); a training step — Z is a noise input — skips
+        # those launches (one 192 -> lat data-gradient conv per RDB plus the HR ones: ~1.5 ms of the configs[2] step)
+        zgrad = need_dx and lat
+        GZ_hr = galloc(B, 1, H, W) if (has_lat and zgrad) else None
+        GZ_lr = galloc(B, 1, h, w) if (has_lat and need_dx) else None
         wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W, keep=(G_g,))
         dgrad('hr1', G_g.view(), G_hr0, 0, 8, H, W, mask=(bufs['hr0'], 0, 8))
         if GZ_hr is not None:
@@ -498,7 +501,7 @@ class RRDBEngine:
         wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w, keep=(G_trunk,))
         dgrad('lr_conv', G_trunk.view(), G_first, 0, 8, h, w)
         zfirst = True
-        if lat:
+        if zgrad:
             dgrad_z('lr_conv', G_trunk.view(), GZ_lr, h, w, 1.0, first=True)
             zfirst = False
         dout = G_first                        # holds d(input of RRDB 0) in groups 0:8 when the loop is done
@@ -516,7 +519,7 @@ class RRDBEngine:
                     conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
                          mask_src=X.view(8 + 4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
                     wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
-                if lat:
+                if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
                     conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
                     zfirst = False
@@ -529,7 +532,7 @@ class RRDBEngine:
                 G_cur = G_next
             if f16_bwd and os.environ.get('ESR_GRAD_RENORM', '1') != '0':
                 # d(input of RRDB r) is complete and not yet recorded anywhere: renormalise it (and the latent gradient accumulated so far)
-                scaler.rescale(B, [G_cur.view(0, 8)] + ([GZ_lr.view()] if lat and not zfirst else []), 10)
+                scaler.rescale(B, [G_cur.view(0, 8)] + ([GZ_lr.view()] if zgrad and not zfirst else []), 10)
                 gscale = scaler.current
                 wg.gscale = gscale
             dout = G_cur

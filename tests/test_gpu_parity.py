@@ -54,6 +54,25 @@ def test_conv3x3_matches_torch_cpu(cin, cout, H, W, slope):
     assert rel_l2(yb.numpy(), ref.numpy()) < 1.5e-2
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W', [(32, 64, 32, 52, 52),      # configs[2] per-GPU shape: 256 tiles of 7 x 52, two-stage kernel, 8 DMA slots per plane
+                                            (6, 96, 32, 148, 148),     # configs[1] geometry, > 320 tiles: one-stage kernel, two workgroups per CU, 9 slots
+                                            (3, 64, 64, 148, 148),     # the same tiles on the two-stage kernel (180 tiles), 64 output channels
+                                            (5, 32, 32, 61, 200),      # tiles of 1 x 200 pixels + pitch: the widest a tile gets
+                                            (7, 40, 24, 5, 7)])        # an image smaller than a tile, ragged channel counts
+def test_conv3x3_tile_geometries(B, cin, cout, H, W):
+    """Every wave copies exactly its share of the tile's 1-KiB slots and weight fragments (dma_share in esr_conv.hip) and the two-stage kernels
+    wait on a run-time count: sweep the tile geometries that change those shares, in both operand modes, against an fp64 convolution."""
+    from esr_hip import act as A
+    x = seeded_uniform((B, cin, H, W), B + cin + W, -1.0, 1.0)
+    w = seeded_uniform((cout, cin, 3, 3), cin * 5 + cout, -1.0, 1.0) * float(np.sqrt(2.0 / (9 * cin)))
+    b = seeded_uniform((cout,), cout + 3, -0.1, 0.1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1), 0.2).numpy()
+    y = A.conv3x3_nchw(x.to(DEV), w.to(DEV), b.to(DEV), 0.2, split=True).cpu().numpy()
+    assert rel_l2(y, ref) < 5e-5 and rel_max(y, ref) < 1e-4
+    yb = A.conv3x3_nchw(x.to(DEV), w.to(DEV), b.to(DEV), 0.2, split=False).cpu().numpy()
+    assert rel_l2(yb, ref) < 1.5e-2
+
+
 F2_CASES = [('cubic_x4', 4, None, None), ('cubic_x2', 2, None, None), ('cubic_x3', 3, None, None), ('aniso_x4', 4, aniso_gaussian_kernel(), 0.1)]
 
 
