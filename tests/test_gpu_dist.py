@@ -1,0 +1,104 @@
+"""GPU test (-m gpu) of the data-parallel training path on REAL device tensors: two ranks (processes) share the one GPU of the test box and
+exchange through the gloo backend (RCCL refuses two ranks on one device; gloo all-reduces / broadcasts device tensors through the host).  What
+runs on every rank is exactly what runs under torchrun on N GPUs: rank-0 weights broadcast at construction (weight packs invalidated), a batch
+shard per rank through the HIP generator forward / backward, the bucketed all-reduce IN PLACE on the flat buffer the batched weight-gradient
+launch wrote, Adam.  Checked: both ranks hold bit-identical gradients and weights afterwards, and the averaged gradient equals the gradient of
+the same step run by one process on the whole batch (the L1 loss is a mean, the shards have equal sizes)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle.check_golden import rel_l2
+from oracle.weights import seeded_uniform
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NB, PER_RANK = 2, 2
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, 'explorable-super-resolution_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _batch(world):
+    n = PER_RANK * world
+    return seeded_uniform((n, 3, 24, 28), 301), seeded_uniform((n, 3, 96, 112), 302)
+
+
+def _step(seed, lr, hr):
+    """One SRRaGANModel generator step (two calls: without a discriminator the first one is idle, as in the reference) on the given shard."""
+    _paths()
+    import models
+    from test_host_api import _opt
+    opt = _opt(nb=NB, lat=0, cem=True, is_train=True)
+    opt['gpu_ids'] = [0]
+    torch.manual_seed(seed)                      # rank-dependent initial weights: the constructor's broadcast has to make them rank 0's
+    m = models.create_model(opt)
+    for _ in range(2):
+        m.feed_data({'LR': lr, 'HR': hr})
+        m.optimize_parameters()
+    names = [k for k, v in m.netG.named_parameters() if v.requires_grad]
+    got = dict(m.netG.named_parameters())
+    grads = {k: got[k].grad.detach().cpu().numpy().copy() for k in names}
+    weights = {k: got[k].detach().cpu().numpy().copy() for k in names}
+    return m, names, grads, weights
+
+
+def _worker(rank, world, port, q):
+    try:
+        _paths()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+        torch.cuda.set_device(0)
+        from esr_hip import dist as D
+        D.init_from_env(backend='gloo')
+        lr, hr = _batch(world)
+        lo, hi = D.shard_range(lr.size(0))
+        m, names, grads, weights = _step(rank, lr[lo:hi], hr[lo:hi])
+        pick = [names[0], names[len(names) // 2], names[-2]]
+        q.put((rank, (lo, hi), {k: grads[k] for k in pick}, {k: weights[k] for k in pick},
+               float(sum(float(np.abs(g).sum()) for g in grads.values())), int(m.grad_reducer.in_place), len(m.grad_reducer.buckets),
+               float(m.get_current_log()['l_g_pix'])))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                       # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, 'error', traceback.format_exc() + repr(e)))
+
+
+def test_two_ranks_on_one_gpu_average_the_generator_gradients_in_place():
+    world = 2
+    lr, hr = _batch(world)
+    _, names, g_full, _ = _step(0, lr, hr)       # one process, the whole batch, rank 0's initial weights
+    torch.cuda.synchronize()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    for r in res:
+        assert r[1] != 'error', r[2]
+    (_, sh0, g0, w0, n0, inplace0, nb0, l0), (_, sh1, g1, w1, n1, inplace1, nb1, l1) = res
+    assert sh0 == (0, PER_RANK) and sh1 == (PER_RANK, 2 * PER_RANK)
+    assert inplace0 == nb0 >= 1 and inplace1 == nb1          # every bucket was reduced in place on the flat weight-gradient buffer
+    assert n0 == n1
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]) and np.array_equal(w0[k], w1[k]), k          # bit-identical after the all-reduce / after Adam
+        ref = g_full[k]
+        gmax = max(float(np.abs(v).max()) for v in g_full.values())
+        if np.abs(ref).max() < 1e-5 * gmax:          # analytically zero gradients (last bias under the CEM) hold rounding noise on both sides
+            assert np.abs(g0[k]).max() < 1e-4 * gmax
+        else:
+            # mean of the two shards' gradients == gradient of the whole-batch mean loss; the contraction order differs, the bar is the
+            # fp32-class 1e-3 of the weight-gradient tests
+            assert rel_l2(g0[k], ref) < 1e-3, (k, rel_l2(g0[k], ref))
+    assert l0 != l1                                            # the ranks really saw different shards
