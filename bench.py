@@ -163,7 +163,7 @@ def main(argv=None):
     if needs_self_launch(args.gpus, os.environ):
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get('ESR_BENCH_SHARE_GPU') != '1':
             raise SystemExit('bench.py --gpus %d: this node exposes %d GPU(s)' % (args.gpus, have))
         env = dict(os.environ)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # RCCL needs dmabuf IPC on this driver
@@ -185,13 +185,20 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit('bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d: pass --gpus %d (or start it as a plain '
                          'process, it launches its own ranks)' % (args.gpus, world, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # ESR_BENCH_SHARE_GPU=1 (tests only): the ranks share the GPUs there are and talk through gloo — RCCL refuses two ranks on one device.
+    # It exercises this file's multi-rank logic on a one-GPU box; its numbers mean nothing.
+    share = os.environ.get('ESR_BENCH_SHARE_GPU') == '1'
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if share:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -203,10 +210,10 @@ def main(argv=None):
         """(max over ranks, per-rank list) of a duration in seconds"""
         if dist is None:
             return dt, [dt]
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per = [float(a.item()) for a in allt]
+        t = torch.zeros(world, device=dev, dtype=torch.float64)       # one slot per rank, summed: an all-gather that every backend has for device tensors
+        t[rank] = dt
+        dist.all_reduce(t)
+        per = [float(v) for v in t.tolist()]
         return max(per), per
 
     if args.workload == 'c3':

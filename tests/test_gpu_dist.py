@@ -102,3 +102,37 @@ def test_two_ranks_on_one_gpu_average_the_generator_gradients_in_place():
             # fp32-class 1e-3 of the weight-gradient tests
             assert rel_l2(g0[k], ref) < 1e-3, (k, rel_l2(g0[k], ref))
     assert l0 != l1                                            # the ranks really saw different shards
+
+
+def _run_bench(extra, timeout):
+    import json
+    import subprocess
+    env = dict(os.environ, ESR_BENCH_SHARE_GPU='1', ESR_D_MIOPEN_FIND='0', OMP_NUM_THREADS='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'] + extra, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]                    # rank 0 prints ONE json line
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_two_ranks_and_reports_the_whole_job():
+    """`python bench.py --gpus 2` started as a plain process (the way the driver starts N = 1): it re-executes itself under torch.distributed.run,
+    every rank times its own shard between barriers, rank 0 reports the max over ranks and the aggregate.  ESR_BENCH_SHARE_GPU lets the two
+    ranks share this box's one GPU (gloo instead of RCCL); the logic is the one the 8-GPU run uses, the numbers are not a measurement."""
+    d = _run_bench(['--batch', '4', '--no-cpu-baseline', '--no-alt-precision'], 900)
+    assert d['n_gpus'] == 2 and d['world_size_seen'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert len(d['ms_per_step_per_rank']) == 2 and abs(max(d['ms_per_step_per_rank']) - d['ms_per_step']) < 1e-6
+    assert abs(d['value'] - 2 * 4 * 512 * 512 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']        # aggregate over both ranks
+    assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1
+
+
+def test_bench_training_step_workload_on_two_ranks():
+    """configs[2] through bench.py on two ranks: generator + critic step per rank, both gradient sets all-reduced (in place for the generator)."""
+    d = _run_bench(['--workload', 'c3'], 1500)
+    assert d['n_gpus'] == 2 and d['world_size_seen'] == 2
+    assert set(d['phases_ms']) >= {'G_forward', 'D_step', 'G_losses_and_backward', 'G_allreduce_and_Adam'}
+    assert all(np.isfinite(v) for v in d['losses'].values()), d['losses']
+    assert abs(d['value'] - 2 * 32 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
