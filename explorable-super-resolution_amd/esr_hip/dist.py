@@ -151,3 +151,16 @@ def all_reduce_mean_scalar(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item()) / world_size()
+
+
+def gather_scalars(t):
+    """Every rank's copy of a small 1-D tensor of device scalars, as a [world, k] tensor on the same device (row r = rank r's values): the
+    GAN bookkeeping that gates generator steps must come out the same on every rank, or the ranks disagree about which collectives come
+    next.  One all-reduce of a one-row-per-rank buffer (every backend has that for device tensors).  Identity ([1, k]) when not distributed."""
+    t = t.detach().reshape(1, -1)
+    if not is_distributed():
+        return t
+    buf = torch.zeros(world_size(), t.size(1), dtype=t.dtype, device=t.device)
+    buf[rank()] = t[0]
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf

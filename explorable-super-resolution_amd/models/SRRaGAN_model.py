@@ -350,8 +350,10 @@ class SRRaGANModel(BaseModel):
                         all(v[1] > np.log(train_opt['min_D_prob_ratio_4_G']) for v in log['D_logits_diff'][-n:]) and \
                         all(v[1] > train_opt['min_mean_D_correct'] for v in log['Correctly_distinguished'][-n:])
                 if self.D_verification == 'current' and self.generator_step:
-                    cur = logits_diff.cpu().numpy()         # a host read, as in the reference: this mode gates G on the current batch
-                    self.generator_step = bool(np.all(cur > 0) and np.mean(cur) > np.log(train_opt['min_D_prob_ratio_4_G']))
+                    # a host read, as in the reference: this mode gates G on the current batch — the GLOBAL batch under data parallelism (all
+                    # ranks must take the same decision: the generator's all-reduce is only entered by ranks that do a G step)
+                    stats = esr_dist.gather_scalars(torch.stack([logits_diff.min(), logits_diff.mean()])).cpu().numpy()
+                    self.generator_step = bool(stats[:, 0].min() > 0 and stats[:, 1].mean() > np.log(train_opt['min_D_prob_ratio_4_G']))
                 if G_grads_retained and not self.generator_step:
                     self.fake_H = self.fake_H.detach()     # nobody will back-propagate into G this time
                 (l_d_total / (acc_D * dual_steps)).backward()
@@ -365,8 +367,10 @@ class SRRaGANModel(BaseModel):
                     if train_opt['gan_type'] == 'wgan-gp':
                         self._pending_logs.append(('l_d_gp', st, [l_d_gp.detach()]))
                     diffs = torch.cat([d.reshape(-1) for d in self._d_acc['D_logits_diff']])
-                    self._pending_logs.append(('D_logits_diff', st, [diffs.mean()]))
-                    self._pending_logs.append(('Correctly_distinguished', st, [(diffs > 0).float().mean()]))
+                    # these two gate later generator steps (D_verification = 'past'): every rank logs the mean over ALL ranks' shards
+                    gate = esr_dist.gather_scalars(torch.stack([diffs.mean(), (diffs > 0).float().mean()])).mean(0)
+                    self._pending_logs.append(('D_logits_diff', st, [gate[0]]))
+                    self._pending_logs.append(('Correctly_distinguished', st, [gate[1]]))
                 self._tick('D_step')
             # ---- G step (:418-499)
             if self.generator_step:

@@ -47,7 +47,7 @@ def _worker_allreduce(rank, world, port, q):
     red = D.GradBucketAllReducer(params, bucket_mb=0.0005)      # tiny buckets: several collectives
     red()
     q.put((rank, [float(p.grad.flatten()[0]) for p in params], [float(p.data.flatten()[0]) for p in params], len(red.buckets),
-           D.shard_range(7), D.all_reduce_mean_scalar(float(rank))))
+           D.shard_range(7), D.all_reduce_mean_scalar(float(rank)), D.gather_scalars(torch.tensor([rank + 1.0, 10.0 * rank])).tolist()))
     dist.destroy_process_group()
 
 
@@ -59,7 +59,8 @@ def test_grad_bucket_allreduce_and_sharding():
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in range(world))
     [p.join(timeout=60) for p in procs]
-    (r0, g0, w0, nb0, s0, m0), (r1, g1, w1, nb1, s1, m1) = res
+    (r0, g0, w0, nb0, s0, m0, gs0), (r1, g1, w1, nb1, s1, m1, gs1) = res
+    assert gs0 == gs1 == [[1.0, 0.0], [2.0, 10.0]]                   # every rank sees every rank's bookkeeping scalars, in rank order
     assert g0 == g1 and w0 == w1                                     # identical gradients and weights on every rank
     expect = [1.5 * (i + 1) for i in range(len(g0))]
     expect[1] = 0.5 * 2                                              # only rank 0 had a gradient for parameter 1: (2*1 + 0)/2

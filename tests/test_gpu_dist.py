@@ -199,3 +199,54 @@ def test_sharded_z_search_on_the_real_generator_matches_one_process():
     assert np.median(d) < 1e-4 and np.mean(d > 1e-2) < 0.02, (float(np.median(d)), float(np.mean(d > 1e-2)))
     np.testing.assert_allclose(res[0][2], loss_ref, rtol=1e-3)
     np.testing.assert_allclose(res[1][2], loss_ref, rtol=1e-3)
+
+
+def _worker_gan(rank, world, port, q):
+    try:
+        _paths()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', ESR_D_MIOPEN_FIND='0')
+        torch.cuda.set_device(0)
+        from esr_hip import dist as D
+        D.init_from_env(backend='gloo')
+        import models
+        from tools.bench_paths import make_opt
+        opt = make_opt(True, lat=3, nb=1, with_D=True)
+        opt['train']['D_verification'] = 'current'            # G steps gated on the CURRENT batch's critic statistics (reference :392-400)
+        opt['train']['min_D_prob_ratio_4_G'] = 1.0
+        torch.manual_seed(rank)
+        m = models.create_model(opt)
+        g = torch.Generator().manual_seed(50 + rank)          # a different shard per rank: local statistics would disagree
+        decisions = []
+        for it in range(4):
+            m.step = it
+            m.feed_data({'LR': torch.rand(2, 3, 52, 52, generator=g), 'HR': torch.rand(2, 3, 208, 208, generator=g)})
+            m.optimize_parameters()
+            decisions.append(bool(m.generator_step))
+        log = m.get_current_log()
+        w = [p for n, p in m.netG.named_parameters() if 'Filter_OP' not in n][0]     # (requires_grad is toggled per step by the gating)
+        q.put((rank, decisions, float(log['D_logits_diff']), float(log['Correctly_distinguished']), float(w.detach().abs().sum())))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, 'error', traceback.format_exc() + repr(e)))
+
+
+def test_ranks_take_the_same_generator_step_decisions_from_global_critic_statistics():
+    """configs[2] with the reference's D-verification gating on two ranks: the statistics that decide whether a generator step happens
+    (per-sample critic logit differences of the current batch; their logged means for the 'past' mode) are made global before they are used —
+    ranks deciding differently would enter different collectives.  Four G + D steps on different shards: same decisions, same logged
+    statistics, same generator weights on both ranks, no hang."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gan, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
+    assert res[0][1] == res[1][1] and len(res[0][1]) == 4
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    assert res[0][4] == res[1][4]
