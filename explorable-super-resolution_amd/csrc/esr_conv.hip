@@ -75,7 +75,9 @@ constexpr bool wreg_of(int npw) { return ESR_WREG != 0 && npw == 1; }
 // 19 % fewer shader cycles per chunk for the split 32-channel kernel (4806 -> 3893) at a 15 % lower shader clock (1.79 -> 1.53 GHz) —
 // 27.9 -> 26.2 us per launch; 72.5 -> 72.5 us for the split 64-channel kernel; bf16 13.3 -> 14.8 and 36.1 -> 30.1 us; whole training step
 // 47.7 -> 47.3 ms (split), 24.5 -> 25.8 ms (bf16) — while the two-stage kernel with the exact, balanced copies of dma_share() alone runs that
-// step in 45.6 ms.  The chip gives the saved cycles back as clock, so it is not the default.
+// step in 45.6 ms.  With a ring of THREE stages where they fit (the producers one chunk further ahead, nobody waits at the barrier): split
+// 26.6 / 82.0 us (vs 26.6 / 70.9 two-stage), bf16 15.6 / 31.1 us (vs 14.4 / 37.6), step 46.1 vs 43.7 ms split, 23.4 vs 23.3 ms bf16.
+// The chip gives the saved cycles back as clock, so it is not the default.
 #ifndef ESR_PC
 #define ESR_PC 0
 #endif
@@ -111,6 +113,7 @@ struct ConvArgs {
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
+    int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -409,8 +412,8 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
-//   NST == 3: the same two LDS stages with EIGHT waves: waves 4-7 ("producers") only issue the DMA of chunk c+1 and wait for it, waves 0-3
-//             ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
+//   NST == 3: a ring of two or three LDS stages (what fits) with EIGHT waves: waves 4-7 ("producers") only issue the DMA of the chunks ahead and
+//             wait for the next one, waves 0-3 ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
 //             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
 //             placed), so only a second wave on the same SIMD can multiply meanwhile.
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     static_assert(!(PC && WREG), "the weights-in-registers experiment has no producer/consumer form");
     constexpr int NWI = WREG ? 0 : 9 * MT * NPW;                   // weight fragments staged in LDS per chunk
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    float* const s_bias = (float*)(smem + NSTAGES * stage_bytes);
+    const int nstg = PC ? a.pc_stages : NSTAGES;
+    float* const s_bias = (float*)(smem + nstg * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
@@ -478,13 +482,20 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
         dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks);
     }
-    auto produce = [&](const int cp) {          // (producer waves) all copies of chunk cp into its stage, landed when this returns
+    // (producer waves) issue all copies of chunk cp into its ring stage; returns how many this wave issued
+    auto produce = [&](const int cp) {
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
-        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (cp & 1) * stage_bytes, plane_bytes, !PARTLO || cp < a.lo_chunks);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool xl = !PARTLO || cp < a.lo_chunks;
+        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (cp % nstg) * stage_bytes, plane_bytes, xl);
+        return dma_count<NPL>(share, xl);
     };
     if (PC) {
-        if (producer) produce(0);
+        if (producer) {
+            produce(0);
+            int ahead = 0;
+            if (nstg == 3 && a.ncp > 1) ahead = produce(1);
+            wait_vm_upto(ahead);                // chunk 0 has landed; chunk 1 may still be in flight
+        }
         __syncthreads();
     }
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
@@ -492,14 +503,17 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
     auto step = [&](auto XLO_T, const int cp) {
         constexpr bool xlo = decltype(XLO_T)::value;
-        const int st = NST >= 2 ? (cp & 1) : 0;
+        const int st = PC ? cp % nstg : (NST >= 2 ? (cp & 1) : 0);
         const unsigned char* const sb = sb0 + st * stage_bytes;
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
         if constexpr (PC) {
-            // stage (cp+1)&1 was last read in iteration cp-1, closed by that iteration's barrier
+            // the stage refilled now was last read in iteration cp-1, closed by that iteration's barrier; at THIS iteration's barrier chunk
+            // cp+1 must have landed (with three stages chunk cp+2, just issued, stays in flight)
             if (producer) {
-                if (cp + 1 < a.ncp) produce(cp + 1);
+                int ahead = 0;
+                if (cp + nstg - 1 < a.ncp) ahead = produce(cp + nstg - 1);
+                wait_vm_upto(nstg == 3 ? ahead : 0);
             } else {
                 ESR_TR(); ESR_TR(); ESR_TR();
                 chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr);
@@ -820,10 +834,13 @@ template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
     ESR_ALLOW_160K_LDS(k);
-    const size_t lds = (NST == 1 ? 1 : 2) * ((size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024) + (size_t)MT * 32 * 4;
+    const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
+    ConvArgs b = a;
+    b.pc_stages = (NST == 3 && 3 * stage + (size_t)MT * 32 * 4 <= 160 * 1024) ? 3 : 2;
+    const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : 2)) * stage + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
