@@ -794,7 +794,20 @@ struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
 // Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
 // halo-traffic term, under the LDS budget that keeps `nwg` workgroups resident per CU.
+TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg);
+// the search walks up to W column splits: remember the last few geometries per thread (a forward pass repeats three or four of them 351 times)
 TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
+    struct Entry { int H, W, npl, mt, nwg; TileCfg cfg; };
+    static thread_local Entry cache[8];
+    static thread_local int next = 0;
+    for (const Entry& e : cache)
+        if (e.H == H && e.W == W && e.npl == npl && e.mt == mt && e.nwg == nwg && e.cfg.P) return e.cfg;
+    Entry& e = cache[next];
+    next = (next + 1) % 8;
+    e = Entry{H, W, npl, mt, nwg, pick_tile_search(H, W, npl, mt, nwg)};
+    return e.cfg;
+}
+TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
     const int R = r_of(mt), MAXS = maxs_of(mt);
     TileCfg best{};
     double best_cost = -1;
