@@ -379,6 +379,9 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     log = model.get_current_log()
     split_ms = {k: v / args.steps for k, v in getattr(model, 'timing', {}).items()}
     flop_g = 3 * 32 * 52 * 52 * 2 * 18316944 * (B / 32)        # fwd + dgrad + wgrad of G (lat 3), SURVEY §8(d)
+    # layer-granular bytes of the same three passes (49,268 + 15,728 elements per LR pixel for RRDB-23 x4 lat 3), at the bytes
+    # per element the precision stores (one 16-bit plane, or hi + lo)
+    bytes_g = 3 * B * 52 * 52 * (49268 + 15728) * (4 if precision in ('split', 'mixed') else 2)
     return {'metric': 'LR crops/sec (RRDB-23 x4 lat 3 G + Discriminator_VGG_128 WGAN-GP step, 32 x 52x52 per GPU)', 'value': world * B * args.steps / dt, 'unit': 'LR crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator %s on MIOpen' % ('bf16 autocast' if d_bf16 else 'fp32'), 'data': 'synthetic',
@@ -388,7 +391,9 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
             'phases_ms': split_ms, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
             'roofline': {'bound': 'mfma', 'kernel': 'generator convs (forward + data gradient + weight gradient)', 'achieved': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 1e12,
                          'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 2.5e15, 'traffic': None,
-                         'note': 'MFMA issue rate of the generator over the WHOLE step time (D, optimizers and all-reduce included in the denominator)'}}
+                         'generator_algorithmic_bytes_per_step': bytes_g, 'generator_hbm_frac_of_step': bytes_g / (dt / args.steps) / 8.0e12,
+                         'note': 'MFMA issue rate (and, beside it, the layer-granular HBM bytes) of the generator over the WHOLE step time: D, optimizers '
+                                 'and all-reduce are in the denominator; per-owner GPU time of a step: profiles/*_c3_*_step_kernels.csv'}}
 
 
 if __name__ == '__main__':
