@@ -335,6 +335,12 @@ struct WgradArgs {
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
 };
+#ifdef ESR_TRACE
+// debug build only (make trace): per-workgroup phase stamps of the weight-gradient kernels, 64 slots per workgroup — [0] HW_ID, [1] stamps used,
+// [2..] s_memtime at (tile start, copies issued, copies landed, barrier passed, MFMAs done) of the first 11 tiles, [62] / [63] wall clock
+// (100 MHz) at start / end; set with esr_debug_trace_wgrad(), read by tools/experiments/trace_wgrad.py
+__device__ unsigned long long* g_wtrace = nullptr;
+#endif
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -451,12 +457,23 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
     // NST == 1: one stage, two workgroups per CU cover each other's DMA waits (same trade as the conv kernel; selected by the host).
     int tile = slice;
     int cur = 0;
+#ifdef ESR_TRACE
+    unsigned long long* const tr = g_wtrace ? g_wtrace + (size_t)blockIdx.x * 64 : nullptr;
+    int tslot = 2;
+    if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[62] = wall_clock64(); }
+#define ESR_WTR() do { if (tr && tid == 0 && tslot < 57) tr[tslot++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESR_WTR() do { } while (0)
+#endif
     if (NST == 2 && tile < ntiles) ESR_WG_ISSUE(tile, lds0);
     for (; tile < ntiles; tile += a.nslices) {
         const int nxt = tile + a.nslices;
+        ESR_WTR();
         if (NST == 1) {
             ESR_WG_ISSUE(tile, lds0);
+            ESR_WTR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ESR_WTR();
         } else if (nxt < ntiles) {
             ESR_WG_ISSUE(nxt, lds0 + (cur ^ 1) * STAGE);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NY) : "memory");     // everything but the copies just issued
@@ -464,6 +481,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        ESR_WTR();
         const unsigned char* const sx = smem + cur * STAGE + xs_off;
         const unsigned char* const sy = smem + cur * STAGE + ys_off;
         // ---- MFMAs: wave handles rows wave, wave+4; a row of 32 pixels = two K steps of 16
@@ -493,9 +511,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                 }
             }
         }
+        ESR_WTR();
         __syncthreads();
         if (NST == 2) cur ^= 1;
     }
+#ifdef ESR_TRACE
+    if (tr && tid == 0) { tr[1] = tslot; tr[63] = wall_clock64(); }
+#endif
     // ---- reduce the 4 waves through LDS (two passes of at most 5 taps: 4 x 5 x 4 KiB = 80 KiB).  A workgroup that owns its
     // (input tile, output tile) alone (nslices == 1) adds straight into dW / db; otherwise its partial sums go to the workspace.
     float* const red = (float*)smem;                             // [wave][tap in pass][16][64]
@@ -543,6 +565,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 }
 
 #undef ESR_WG_ISSUE
+#undef ESR_WTR
 
 template <int NPL, int NST, int FMT>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
@@ -700,6 +723,9 @@ static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
 
 }  // namespace
 
+#ifdef ESR_TRACE
+extern "C" void esr_debug_trace_wgrad(void* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace), &buf, sizeof(buf)); }
+#endif
 extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
     const int64_t n = wgrad_partial_floats(wgrad_plan(d));
