@@ -176,6 +176,19 @@ class SRRaGANModel(BaseModel):
         if init_Fnet:
             raise NotImplementedError('init_Fnet: the VGG feature extractor needs torchvision')
         self.load()
+        if self.is_train:
+            # what the reference does after loading (:209-218): once the critic counts as verified, G trains at D's learning rate and the
+            # optimal-Z search runs train.Num_Z_iterations[-1] iterations
+            self.D_verified, self.verified_D_saved = bool(self.D_verified), bool(self.verified_D_saved)
+            if self.D_exists:
+                for group in self.optimizer_D.param_groups:
+                    group['lr'] = self.lr_D
+                if self.verified_D_saved:
+                    self.lr_G = 1 * self.lr_D
+                    if self.optimalZ_loss_type is not None:
+                        self.Z_optimizer.max_iters = train_opt['Num_Z_iterations'][-1]
+            for group in self.optimizer_G.param_groups:
+                group['lr'] = self.lr_G
         if self.is_train and opt['gc_freeze'] is not False:
             # A training step allocates thousands of short-lived Python objects (launch descriptors, autograd nodes): CPython's cyclic collector
             # then runs several times per step, and its full passes walk every module / parameter / buffer object of the two networks — measured
@@ -356,7 +369,10 @@ class SRRaGANModel(BaseModel):
                     self.generator_step = bool(stats[:, 0].min() > 0 and stats[:, 1].mean() > np.log(train_opt['min_D_prob_ratio_4_G']))
                 if G_grads_retained and not self.generator_step:
                     self.fake_H = self.fake_H.detach()     # nobody will back-propagate into G this time
-                (l_d_total / (acc_D * dual_steps)).backward()
+                # pred_d_real / l_d_real are computed on the first dual pass only and re-used by the second one: their graph has to survive the
+                # first backward (the reference retains it whenever gan_type is 'wgan-gp' or a G step follows, :400; retaining it only while
+                # another dual pass will back-propagate through it is the same computation without holding the buffers longer)
+                (l_d_total / (acc_D * dual_steps)).backward(retain_graph=not last_dual)
                 if last_acc_D and last_dual:
                     self.grad_reducer_D()                  # RCCL all-reduce (mean) of the D gradients
                     self.optimizer_D.step()

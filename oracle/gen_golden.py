@@ -326,7 +326,7 @@ def gen_F6():
     np.savez_compressed(os.path.join(GOLDEN, 'c2_rrdb23_probe.npz'), **out)
 
 
-def _ref_opt(is_train, nb=1, lat=3, gan=False, batch=2, root='/tmp/esr_ref_f7'):
+def _ref_opt(is_train, nb=1, lat=3, gan=False, batch=2, root='/tmp/esr_ref_f7', train_extra=None):
     """Options of the reference's model wrapper (codes/options/train/train_explorable_SR.json, reduced to what SRRaGANModel reads)."""
     from options.options import dict_to_nonedict
     os.makedirs(os.path.join(root, 'models'), exist_ok=True)
@@ -335,6 +335,7 @@ def _ref_opt(is_train, nb=1, lat=3, gan=False, batch=2, root='/tmp/esr_ref_f7'):
              'grad_accumulation_steps_G': 1, 'grad_accumulation_steps_D': 1, 'D_verification': None, 'D_update_ratio': 1, 'D_init_iters': 0}
     if gan:
         train.update({'gan_type': 'wgan-gp', 'gan_weight': 1, 'gp_weight': 10})
+    train.update(train_extra or {})
     return dict_to_nonedict({
         'name': 'f7', 'model': 'srragan', 'scale': 4, 'gpu_ids': None, 'range': [0, 1], 'is_train': is_train,
         'path': {'root': root, 'models': os.path.join(root, 'models'), 'log': root, 'experiments_root': root, 'val_images': root},
@@ -449,7 +450,61 @@ def gen_F7():
     np.savez_compressed(os.path.join(GOLDEN, 'callers_f7.npz'), **out)
 
 
-ALL = {'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10, 'F11': gen_F11}
+def gen_F12():
+    """The optimal-Z dual pass of the training step (SRRaGAN_model.py:314-338, the reference's own train_explorable_SR.json: wgan-gp +
+    optimalZ_loss_type 'l1', weight 100): once the generator has stepped, every call runs twice — first on Z found by a 10-iteration
+    Z_optimizer('l1') search through the frozen generator, then on the assigned Z — and the D backward of the first pass must leave the graph of
+    pred_d_real alive for the second (:400).  Calls 0 (D only), 1 (D + G; one pass), 2 (D + G, two passes): critic losses, gradient norms of D
+    and G after call 2, l_g_optimalZ."""
+    import contextlib
+    import io
+    import models
+    out = {}
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    with quiet:
+        m = models.create_model(_ref_opt(True, gan=True, train_extra={'optimalZ_loss_type': 'l1', 'optimalZ_loss_weight': 100, 'Num_Z_iterations': [4]}))
+    fill_formula_weights(m.netG, gain=0.5)
+    fill_formula_weights(m.netD, gain=1.0)
+    data = _train_batch()
+    gp = [p for n, p in m.netG.named_parameters() if p.requires_grad]
+    dp = list(m.netD.parameters())
+    draws = {'pt': [], 'z': []}
+    zm = m.Z_optimizer.Z_model
+    orig_rand, orig_unif = zm.Randomize_Z, m.random_pt.uniform_
+
+    def rec_rand(*a, **kw):                 # the search starts from a fresh xavier-uniform Z (Z_optimization.py:654-655): record the draw
+        orig_rand(*a, **kw)
+        draws['z'].append(zm.Z.data.clone().numpy())
+
+    def rec_unif(*a, **kw):                 # one draw of interpolation points per dual pass (:366)
+        r = orig_unif(*a, **kw)
+        draws['pt'].append(m.random_pt.detach().clone().numpy())
+        return r
+    zm.Randomize_Z, m.random_pt.uniform_ = rec_rand, rec_unif
+    for call in range(3):
+        torch.manual_seed(4321 + call)
+        draws['pt'], draws['z'] = [], []
+        m.feed_data({k: v.clone() for k, v in data.items()})
+        with quiet:
+            m.optimize_parameters()
+        log = m.get_current_log()
+        out['call%d/random_pts' % call] = np.stack(draws['pt'])                     # [passes, B, 1, 1, 1]
+        if draws['z']:
+            out['call%d/initial_pre_tanh_Z' % call] = np.stack(draws['z'])[0]
+        out['call%d/D_grad_norms' % call] = _norms(dp)
+        for k in ('l_d_real', 'l_d_fake', 'l_d_gp', 'D_real', 'D_fake', 'D_logits_diff'):
+            out['call%d/%s' % (call, k)] = np.array(log[k])
+        if call:
+            out['call%d/G_grad_norms' % call] = _norms(gp)
+            for k in ('l_g_gan', 'l_g_pix', 'l_g_range', 'l_g_optimalZ'):
+                if k in log:
+                    out['call%d/%s' % (call, k)] = np.array(log[k])
+        print('dual call', call, {k: v for k, v in log.items()})
+    out['optimal_Z_digest'] = _param_digest(zm.Z.detach())
+    np.savez_compressed(os.path.join(GOLDEN, 'callers_dual.npz'), **out)
+
+
+ALL = {'F12': gen_F12, 'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10, 'F11': gen_F11}
 
 if __name__ == '__main__':
     _refshim.install()
