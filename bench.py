@@ -71,6 +71,11 @@ def needs_self_launch(gpus, environ):
     return gpus > 1 and 'WORLD_SIZE' not in environ
 
 
+def select_backend(environ):
+    """'nccl' (= RCCL over xGMI) always; 'gloo' only under the test-only switch ESR_BENCH_SHARE_GPU=1 (several ranks on one GPU)."""
+    return 'gloo' if environ.get('ESR_BENCH_SHARE_GPU') == '1' else 'nccl'
+
+
 # ---------------------------------------------------------------------------------------------------------------- workload pieces
 def build_model(device, nb=NB):
     import torch
@@ -88,10 +93,22 @@ def build_model(device, nb=NB):
     return cem, G.to(device).eval()
 
 
+def cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(G, cem):
-    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on ONE 128x128 image of the same
-    workload: RRDB-23 x4 + CEM eval = 1/32 of a step.  Thread counts 8/16/32/64 (capped by the cores this process may use) are each
-    timed (1 warm-up + 2 runs) and the best is reported with its thread count: oversubscribed torch CPU convolutions are slower."""
+    """the oracle (CPU restatement of the reference path, torch fp32 on the host cores) on ONE 128x128 image of the
+    same workload (RRDB-23 x4 + CEM eval = 1/32 of a step) and on configs[0] (RRDB-3, 1x3x32x32).  Thread counts 8/16/32/64 (capped by the
+    cores this process may use) are each tried once after a warm-up (oversubscribed torch CPU convolutions are slower); at the best count
+    the figure is the MEDIAN of 3 further runs.  CPU model string and core counts are part of the record."""
+    import statistics
     import torch
     from oracle import cem_oracle as co
     from oracle import rrdb_oracle as ro
@@ -102,28 +119,43 @@ def cpu_baseline(G, cem):
     x = torch.rand(1, 3, LR_SIZE, LR_SIZE, generator=g)
     keep = {}
 
-    def run():
+    def run(xin=x, state=sd, nb=NB):
         with torch.no_grad():
-            xp = torch.nn.functional.pad(x, (taps.margins_LR,) * 4, mode='replicate')
-            gen = ro.rrdb_forward(sd, xp, NB, SF, 0, prefix='generated_image_model.model')
+            xp = torch.nn.functional.pad(xin, (taps.margins_LR,) * 4, mode='replicate')
+            gen = ro.rrdb_forward(state, xp, nb, SF, 0, prefix='generated_image_model.model')
             keep['gen'] = gen
             return co.cem_combine(xp, gen, taps, crop=True)
+
+    def clock(fn, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t0)
+        return ts, out
     sweep = {}
-    y = None
     for nt in sorted({min(n, avail) for n in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         run()
-        ts = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            y = run()
-            ts.append(time.perf_counter() - t0)
-        sweep[nt] = min(ts)
+        sweep[nt] = clock(run, 1)[0][0]
     best = min(sweep, key=sweep.get)
-    t = sweep[best]
+    torch.set_num_threads(best)
+    ts, y = clock(run, 3)
+    t = statistics.median(ts)
+    gen = keep['gen']
+    # configs[0]: RRDB-3 x4 + CEM on 1x3x32x32 (the reference's own CPU-runnable case), same thread count, random weights of that shape
+    _, G3 = build_model('cpu', nb=3)
+    sd3 = {k: v.detach() for k, v in G3.state_dict().items()}
+    x3 = torch.rand(1, 3, 32, 32, generator=g)
+    run(x3, sd3, 3)
+    t3 = statistics.median(clock(lambda: run(x3, sd3, 3), 5)[0])
     return {'value': (SF * LR_SIZE) ** 2 / t, 'unit': 'HR pixels/s', 'cores': best, 'kind': 'port',
-            'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval), best of 2 runs at the best thread count, %.2f s each' % t,
-            'thread_sweep_s': {str(k): round(v, 3) for k, v in sweep.items()}, 'cores_available': avail}, x, y, keep['gen']
+            'sample': '1 of the 32 images of a step (1x3x128x128 -> 512x512, RRDB-23 x4 + CEM eval): 1 warm-up, median of 3 runs at the best '
+                      'thread count, %.2f s each' % t,
+            'runs_s': [round(v, 3) for v in ts], 'thread_sweep_s': {str(k): round(v, 3) for k, v in sweep.items()}, 'cores_available': avail,
+            'cpu_model': cpu_model_string(), 'logical_cpus': os.cpu_count(),
+            'configs0': {'workload': 'configs[0]: RRDB-3 x4 + CEM, 1x3x32x32 -> 128x128', 'ms': t3 * 1e3, 'value': (SF * 32) ** 2 / t3, 'unit': 'HR pixels/s',
+                         'sample': 'median of 5 runs, %d threads' % best}}, x, y, gen
 
 
 def newest_pmc(precision):
@@ -195,10 +227,27 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if share:
+        if select_backend(os.environ) == 'gloo':
             dist.init_process_group(backend='gloo')
         else:
             dist.init_process_group(backend='nccl', device_id=dev)
+
+    def rank_info():
+        """What this rank runs on — lets whoever reads the line confirm N distinct GPUs and the RCCL backend."""
+        prop = torch.cuda.get_device_properties(dev)
+        info = {'rank': rank, 'device_index': dev_index, 'device': prop.name, 'gcn_arch': getattr(prop, 'gcnArchName', None),
+                'pci_bus_id': '%04x:%02x:%02x' % (getattr(prop, 'pci_domain_id', 0), getattr(prop, 'pci_bus_id', 0), getattr(prop, 'pci_device_id', 0)),
+                'uuid': str(getattr(prop, 'uuid', '')), 'backend': dist.get_backend() if dist is not None else None}
+        if dist is not None and info['backend'] == 'nccl':
+            try:
+                info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                     # the version query is informational only
+                info['rccl_version'] = 'unavailable: %s' % e
+        if dist is None:
+            return [info]
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        return infos
 
     def sync():
         torch.cuda.synchronize()
@@ -220,7 +269,10 @@ def main(argv=None):
         out = run_c3(args, dev, rank, world, dist, sync, max_over_ranks)
     else:
         out = run_c2(args, dev, rank, world, dist, sync, max_over_ranks)
+    infos = rank_info()
     if rank == 0:
+        out['ranks'] = infos
+        out['distinct_gpus'] = len({(i['pci_bus_id'], i['uuid']) for i in infos})
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

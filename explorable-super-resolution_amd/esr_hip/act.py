@@ -506,28 +506,37 @@ def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, devi
     return dw, db
 
 
-_WGB = {}        # per device: (descriptor bytes, workspace tensor, plan) of the last batched weight-gradient launch
+_WGB = {}        # fallback cache for callers without an engine: {device index: [(descriptor bytes, workspace tensor, plan), ...]}
+_WGB_KEEP = 4    # descriptor sets kept per cache (a dual pass / gradient accumulation alternates between a few)
 
 
-def conv3x3_wgrad_batch(descs, device):
+def conv3x3_wgrad_batch(descs, device, cache=None):
     """All recorded layers' weight gradients in one launch (esr_conv3x3_wgrad_batch_upload / _run).  The caller keeps every dy / x buffer
     alive and unmodified until this returns (the launch is enqueued behind the kernels that produced them).  The descriptor table is
-    uploaded only when it differs from the previous call's: with pooled gradient buffers and the allocator handing back the same dW
-    storage, a steady-state training step re-runs the table that is already on the device (no host->device copy)."""
+    uploaded only when it differs from the ones already on the device: with pooled gradient buffers and the allocator handing back the same
+    dW storage, a steady-state training step re-runs a table that is already there (no host->device copy).  `cache`: the owner's dict (one
+    per engine, so that two models — or two streams — never share a table a launch in flight may still be reading); each distinct descriptor
+    set gets its OWN workspace, a small LRU of them is kept."""
     if not descs:
         return
     arr = (_lib.WgradDesc * len(descs))(*descs)
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     raw = bytes(arr)
-    cached = _WGB.get(key)
-    if cached is None or cached[0] != raw:
+    entries = (_WGB if cache is None else cache).setdefault(key, [])
+    hit = next((e for e in entries if e[0] == raw), None)
+    if hit is None:
         need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, len(descs))
         check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
-        ws = cached[1] if (cached is not None and cached[1].numel() >= need) else torch.empty(int(need), dtype=torch.uint8, device=device)
+        ws = torch.empty(int(need), dtype=torch.uint8, device=device)
         plan = _lib.WgradBatchPlan()
         check(_lib.lib.esr_conv3x3_wgrad_batch_upload(arr, len(descs), ws.data_ptr(), ws.numel(), C.byref(plan), stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
-        cached = _WGB[key] = (raw, ws, plan)
-    check(_lib.lib.esr_conv3x3_wgrad_batch_run(cached[1].data_ptr(), C.byref(cached[2]), stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
+        hit = (raw, ws, plan)
+        entries.insert(0, hit)
+        del entries[_WGB_KEEP:]
+    elif entries[0] is not hit:
+        entries.remove(hit)
+        entries.insert(0, hit)
+    check(_lib.lib.esr_conv3x3_wgrad_batch_run(hit[1].data_ptr(), C.byref(hit[2]), stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
 
 
 _WS = {}

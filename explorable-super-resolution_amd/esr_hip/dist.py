@@ -66,7 +66,9 @@ def broadcast_parameters(module, src=0):
 
 def _flat_view(grads):
     """One 1-D tensor aliasing all of `grads` when they tile a single contiguous range of one storage in order (the engine's batched
-    weight-gradient launch writes every layer's dW / db into one flat buffer and hands out views of it), else None."""
+    weight-gradient launch writes every layer's dW / db into one flat buffer and hands out views of it), else None.  The returned view
+    spans EXACTLY the given tensors — each must start where the previous one ends — so reducing / scaling it in place never touches a
+    neighbour in the same buffer that belongs to somebody else (a parameter outside this reducer, another bucket)."""
     g0 = grads[0]
     if any(g is None or not g.is_contiguous() or g.dtype != g0.dtype or g.device != g0.device for g in grads):
         return None

@@ -41,6 +41,8 @@ class RRDBEngine:
         self._gpool, self._gpool_key = {}, None
         self._pack_batch = A.PackBatch()
         self._packs_fp = None
+        self._pack_sets = 0  # bumped whenever a pack dict is created or dropped: part of the fingerprint (ids of dicts get recycled)
+        self._wgb = {}       # this engine's uploaded weight-gradient descriptor tables (A.conv3x3_wgrad_batch)
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
@@ -55,6 +57,8 @@ class RRDBEngine:
             self._packed_t = None
             self._packed_rdb_t = None
             self._bufs = {}
+            self._packs_fp = None
+            self._pack_sets += 1
 
     # ------------------------------------------------------------------ weights
     def invalidate(self):
@@ -101,7 +105,7 @@ class RRDBEngine:
         Steady state is one tuple comparison: the (storage, version) fingerprint of the parameters and the identity of the pack set; the
         per-pack staleness keys are only consulted when that fingerprint moved."""
         dicts = (self._packed, self._packed_t, self._packed_rdb_t)
-        fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(id(d) for d in dicts), self.generation)
+        fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(d is not None for d in dicts), self._pack_sets, self.generation)
         if fp == self._packs_fp:
             return
         packs = [p for d in dicts if d for p in d.values()]
@@ -153,6 +157,7 @@ class RRDBEngine:
                 else:
                     d[name] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name))
             self._packed = d
+            self._pack_sets += 1
         self._refresh_packs()
         return self._packed
 
@@ -171,6 +176,7 @@ class RRDBEngine:
                 if lat:
                     d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice='latent')
             self._packed_t = d
+            self._pack_sets += 1
         self._refresh_packs()
         return self._packed_t
 
@@ -197,6 +203,7 @@ class RRDBEngine:
                     if lat:
                         d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_wfmt(True))
             self._packed_rdb_t = d
+            self._pack_sets += 1
         self._refresh_packs()
         return self._packed_rdb_t
 
@@ -627,7 +634,7 @@ class WGrad:
 
     def result(self):
         if self.enabled and self.descs:
-            A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device)
+            A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device, cache=self.engine._wgb)
             for (tdw, tdb), (dw, db), rows in self.permuted:
                 dw.index_copy_(0, rows, tdw)
                 db.index_copy_(0, rows, tdb)

@@ -127,7 +127,21 @@ def _worker_flat(rank, world, port, q):
     red = D.GradBucketAllReducer(params, bucket_mb=0.001)        # 2 buckets: each one a contiguous slice of the flat buffer
     ptrs = [p.grad.data_ptr() for p in params]
     red()
-    q.put((rank, red.in_place, len(red.buckets), flat.clone().numpy(), ptrs == [p.grad.data_ptr() for p in params]))
+    first = (red.in_place, len(red.buckets), flat.clone().numpy(), ptrs == [p.grad.data_ptr() for p in params])
+    # (ii) a reducer over a SUBSET of the parameters whose gradients share the flat buffer (the middle two of four), after a second
+    # backward pass accumulated into the same views (gradient accumulation: AccumulateGrad adds in place): only the subset's range of the
+    # buffer may change
+    flat2 = torch.ones(sum(p.numel() for p in params), dtype=torch.float32) * (rank + 1)
+    off = 0
+    for p in params:
+        p.grad = flat2[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    for p in params:
+        p.grad.add_(torch.full_like(p, 2.0 * (rank + 1)))          # accumulation step 2, in place
+    sub = D.GradBucketAllReducer(params[1:3], bucket_mb=32.0)
+    sub()
+    lo, hi = params[0].numel(), params[0].numel() + params[1].numel() + params[2].numel()
+    q.put((rank,) + first + (sub.in_place, flat2.clone().numpy(), lo, hi))
     dist.destroy_process_group()
 
 
@@ -139,6 +153,10 @@ def test_grad_buckets_reduce_in_place_out_of_the_flat_gradient_buffer():
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in range(world))
     [p.join(timeout=60) for p in procs]
-    for rank, in_place, nb, flat, same_storage in res:
+    for rank, in_place, nb, flat, same_storage, sub_in_place, flat2, lo, hi in res:
         assert nb >= 2 and in_place == nb and same_storage          # every bucket reduced in place: no gather / scatter copies
         assert np.allclose(flat, np.arange(flat.size) * 1.5)        # mean of (1x, 2x)
+        own = 3.0 * (rank + 1)                                      # this rank's accumulated gradient (1 + 2) * (rank + 1)
+        assert sub_in_place == 1
+        assert np.allclose(flat2[lo:hi], 4.5)                       # the subset: mean of 3 and 6, in place
+        assert np.allclose(flat2[:lo], own) and np.allclose(flat2[hi:], own)     # its neighbours in the same buffer: untouched

@@ -324,6 +324,11 @@ def test_bench_launches_its_own_ranks_for_several_gpus():
     a = bench.parse_args(['--gpus', '4'])
     assert a.gpus == 4 and a.workload == 'c2' and a.precision is None
     assert bench.free_port() > 1024
+    # RCCL ('nccl') is the backend of every multi-GPU run; gloo only under the test-only switch that puts several ranks on one GPU
+    assert bench.select_backend({}) == 'nccl' and bench.select_backend({'ESR_BENCH_SHARE_GPU': '0'}) == 'nccl'
+    assert bench.select_backend({'ESR_BENCH_SHARE_GPU': '1'}) == 'gloo'
+    src = open(bench.__file__).read()
+    assert "init_process_group(backend='nccl', device_id=dev)" in src and "'HSA_ENABLE_IPC_MODE_LEGACY', '0'" in src
 
 
 @pytest.mark.parametrize('code', ['SVDinNormedOut_structure_tensor', 'structure_tensor'])
