@@ -46,7 +46,70 @@ class PackDesc(C.Structure):
                 ('mtiles', C.c_int32), ('transposed', C.c_int32), ('split', C.c_int32), ('scale', C.c_float), ('wpack', C.c_void_p)]
 
 
+# ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
+OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
+    OP_PACK_BATCH_RUN, OP_ZERO = range(1, 11)
+
+
+class CmdPackNchw(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('src_batch_stride', C.c_int64), ('B', C.c_int32), ('C', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+                ('c0', C.c_int32), ('nc', C.c_int32), ('pad', C.c_int32), ('down', C.c_int32), ('dst', ActView)]
+
+
+class CmdUnpackGradNchw(C.Structure):
+    _fields_ = [('G', ActView), ('dst', C.c_void_p), ('dst_batch_stride', C.c_int64), ('B', C.c_int32), ('C', C.c_int32), ('h', C.c_int32),
+                ('w', C.c_int32), ('c0', C.c_int32), ('nc', C.c_int32), ('pad', C.c_int32), ('down', C.c_int32), ('accumulate', C.c_int32)]
+
+
+class CmdActCombine(C.Structure):
+    _fields_ = [('A', ActView), ('alpha', C.c_float), ('Bv', ActView), ('beta', C.c_float), ('s', C.c_int32), ('mask', ActView),
+                ('mask_slope', C.c_float), ('out', ActView), ('B', C.c_int32)]
+
+
+class CmdPixelUnshuffle(C.Structure):
+    _fields_ = [('src', ActView), ('r', C.c_int32), ('dst', ActView), ('B', C.c_int32)]
+
+
+class CmdGradAbsmax(C.Structure):
+    _fields_ = [('v', ActView), ('B', C.c_int32), ('slot', C.c_void_p)]
+
+
+class CmdGradScale(C.Structure):
+    _fields_ = [('src', ActView), ('dst', ActView), ('B', C.c_int32), ('slot', C.c_void_p), ('exp', C.c_int32), ('scale_in', C.c_void_p),
+                ('scale_den', C.c_void_p), ('scale_out', C.c_void_p)]
+
+
+class CmdWgradBatchRun(C.Structure):
+    _fields_ = [('workspace', C.c_void_p), ('plan', WgradBatchPlan)]
+
+
+class CmdPackBatchRun(C.Structure):
+    _fields_ = [('workspace', C.c_void_p), ('n', C.c_int32), ('nblocks', C.c_int64)]
+
+
+class CmdZero(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('n16', C.c_int64)]
+
+
+class CmdUnion(C.Union):
+    _fields_ = [('conv', Conv3x3Desc), ('pack_nchw', CmdPackNchw), ('unpack_grad_nchw', CmdUnpackGradNchw), ('act_combine', CmdActCombine),
+                ('pixel_unshuffle', CmdPixelUnshuffle), ('grad_absmax', CmdGradAbsmax), ('grad_scale', CmdGradScale),
+                ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero)]
+
+
+class Cmd(C.Structure):
+    """esr_cmd (include/esr_hip.h)."""
+    _fields_ = [('op', C.c_int32), ('reserved', C.c_int32), ('u', CmdUnion)]
+
+
+CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW: 'unpack_grad_nchw', OP_ACT_COMBINE: 'act_combine',
+              OP_PIXEL_UNSHUFFLE: 'pixel_unshuffle', OP_GRAD_ABSMAX: 'grad_absmax', OP_GRAD_SCALE: 'grad_scale',
+              OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero'}
+
+
 _SIGS = {
+    'esr_run': (C.c_int, [C.POINTER(Cmd), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    'esr_cmd_bytes': (C.c_int64, []),
     'esr_version': (C.c_int, []),
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
     'esr_pixel_unshuffle': (C.c_int, [C.POINTER(ActView), C.c_int, C.POINTER(ActView), C.c_int, C.c_void_p]),
@@ -121,6 +184,8 @@ def load_library():
             raise EsrError('%s does not export %s (stale build?)' % (path, name))
         f.restype = res
         f.argtypes = args
+    if h.esr_cmd_bytes() != C.sizeof(Cmd):
+        raise EsrError('%s: esr_cmd is %d bytes in the library, %d in this binding (stale build?)' % (path, h.esr_cmd_bytes(), C.sizeof(Cmd)))
     _lib = h
     return h
 

@@ -41,6 +41,103 @@ def one_stream(fn):
     return wrapped
 
 
+# ------------------------------------------------------------------------------------------------ launch lists (esr_run)
+class Recorder:
+    """Collects the launches of one pass instead of issuing them (esr_cmd, include/esr_hip.h): while a Recorder is active on this thread
+    (`recording`), the wrappers below append their argument blocks to it.  finish() turns the collection into a Plan: ctypes arrays of
+    esr_cmd that Plan.run replays with one esr_run call per segment.  `externals` {name: tensor} are the tensors whose addresses change
+    from call to call (the pass's NCHW inputs / outputs): raw-pointer arguments that fall inside one of them are re-written before every
+    replay; everything else a command points to (activation / gradient buffers, weight packs) must stay alive and in place for the
+    plan's life — the caller keeps those objects with the plan (`keep`).  host(fn): work that is not a library launch (event records,
+    torch ops) at this position of the sequence; it splits the list into segments and is called as fn(ctx) on replay."""
+
+    def __init__(self, externals):
+        self.ext = [(name, t.data_ptr(), t.numel() * t.element_size()) for name, t in externals.items()]
+        self.items = []
+        self.keep = []
+
+    def emit(self, op, st, refs=()):
+        if not self.items or self.items[-1][0] != 'cmds':
+            self.items.append(('cmds', []))
+        self.items[-1][1].append((op, st, refs))
+
+    def host(self, fn):
+        self.items.append(('host', fn))
+
+    def _external_of(self, ptr):
+        for name, base, nbytes in self.ext:
+            if ptr is not None and base <= ptr < base + max(nbytes, 1):
+                return name, ptr - base
+        return None
+
+    def finish(self):
+        plan = Plan()
+        plan.keep = self.keep
+        for kind, payload in self.items:
+            if kind == 'host':
+                plan.items.append(payload)
+                continue
+            arr = (_lib.Cmd * len(payload))()
+            for i, (op, st, refs) in enumerate(payload):
+                arr[i].op = op
+                C.memmove(C.addressof(arr[i].u), C.addressof(st), C.sizeof(st))
+                member = getattr(arr[i].u, _lib.CMD_MEMBER[op])
+                for field in refs:
+                    hit = self._external_of(getattr(member, field))
+                    if hit is not None:
+                        plan.patches.append((member, field, hit[0], hit[1]))
+            plan.items.append(arr)
+            plan.n_cmds += len(payload)
+        return plan
+
+
+class Plan:
+    def __init__(self):
+        self.items, self.patches, self.keep, self.n_cmds = [], [], [], 0
+        self._failed = C.c_int(-1)
+
+    def run(self, externals, ctx=None):
+        for member, field, name, off in self.patches:
+            setattr(member, field, externals[name].data_ptr() + off)
+        s = stream_ptr()
+        for item in self.items:
+            if callable(item):
+                item(ctx)
+                continue
+            rc = _lib.lib.esr_run(item, len(item), C.byref(self._failed), s)
+            if rc != 0:
+                op = item[self._failed.value].op if 0 <= self._failed.value < len(item) else -1
+                check(rc, 'esr_run: command %d (%s)' % (self._failed.value, _lib.CMD_MEMBER.get(op, '?')))
+
+
+class recording:
+    """with recording(recorder): ... — the library wrappers of this module collect into `recorder` instead of launching."""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    def __enter__(self):
+        assert getattr(_tls, 'rec', None) is None, 'launch-list recording does not nest'
+        _tls.rec = self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        _tls.rec = None
+
+
+def _rec():
+    return getattr(_tls, 'rec', None)
+
+
+def host_op(fn):
+    """Run fn(ctx) at this position of the launch sequence: now (ctx = None) when launching directly, on every replay when recording."""
+    rec = _rec()
+    if rec is None:
+        fn(None)
+    else:
+        rec.host(fn)
+
+
 # operand formats ("split" arguments throughout): True / 1 = bf16 hi+lo planes (fp32-class), False / 0 = bf16, 'f16' = one fp16 plane,
 # 'f16x2' = fp16 hi+lo activation planes with single-plane fp16 weights, 'f16x3' = fp16 hi+lo activations AND weights
 def fmt_code(split):
@@ -115,6 +212,10 @@ def pack_nchw(src, dst_view, c0, nc, pad=0, down=1, hw=None, batch_stride=0, cha
     B = src.shape[0]
     Cc = src.shape[1] if channels is None else channels
     h, w = (src.shape[2], src.shape[3]) if hw is None else hw
+    rec = _rec()
+    if rec is not None:
+        rec.emit(_lib.OP_PACK_NCHW, _lib.CmdPackNchw(src.data_ptr(), batch_stride, B, Cc, h, w, c0, nc, pad, down, dst_view), ('src',))
+        return
     check(_lib.lib.esr_pack_nchw(src.data_ptr(), batch_stride, B, Cc, h, w, c0, nc, pad, down, C.byref(dst_view), stream_ptr()),
           'esr_pack_nchw')
 
@@ -338,6 +439,12 @@ _launch_parity = 0
 ALTERNATE_ORDER = os.environ.get('ESR_ALTERNATE_ORDER', '1') != '0'
 
 
+def reset_launch_parity():
+    """Start of a pass: the alternating tile order restarts, so that a recorded pass and a directly launched one make the same choices."""
+    global _launch_parity
+    _launch_parity = 0
+
+
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
             out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0,
             pixel_shuffle=0, ps_rowgroup0=0):
@@ -369,16 +476,29 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
     d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
     d.in1_lo_groups = in1_lo_groups
     d.pixel_shuffle, d.ps_rowgroup0 = pixel_shuffle, ps_rowgroup0
+    rec = _rec()
+    if rec is not None:
+        rec.emit(_lib.OP_CONV3X3, d, ('out_nchw',))
+        return
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
 
 
 def pixel_unshuffle(src, r, dst, B):
     """dst[g*r^2 + s][y][x] = src[g][r*y + s//r][r*x + s%r]  (esr_pixel_unshuffle): adjoint of the conv kernel's pixel-shuffle store."""
+    rec = _rec()
+    if rec is not None:
+        rec.emit(_lib.OP_PIXEL_UNSHUFFLE, _lib.CmdPixelUnshuffle(src, r, dst, B))
+        return
     check(_lib.lib.esr_pixel_unshuffle(C.byref(src), r, C.byref(dst), B, stream_ptr()), 'esr_pixel_unshuffle')
 
 
 def act_combine(out, B, A_=None, alpha=1.0, Bv=None, beta=1.0, s=1, mask=None, mask_slope=0.2):
     """out = alpha*A_ + beta*sumpool_s(Bv), optionally * LeakyReLU'(mask)  (esr_act_combine)."""
+    rec = _rec()
+    if rec is not None:
+        nv = lambda v: v if v is not None else NO_VIEW
+        rec.emit(_lib.OP_ACT_COMBINE, _lib.CmdActCombine(nv(A_), alpha, nv(Bv), beta, s, nv(mask), mask_slope, out, B))
+        return
     ref = lambda v: C.byref(v) if v is not None else None
     check(_lib.lib.esr_act_combine(ref(A_), alpha, ref(Bv), beta, s, ref(mask), mask_slope, C.byref(out), B, stream_ptr()), 'esr_act_combine')
 
@@ -406,6 +526,14 @@ class GradScaler:
         """Bring max|hi| of views[0] into [2^(exp-1), 2^exp), scale the other views by the same factor, advance `current`."""
         assert self.i < self.n
         slot = self._ptr(self.slots, self.i)
+        rec = _rec()
+        if rec is not None:
+            rec.emit(_lib.OP_GRAD_ABSMAX, _lib.CmdGradAbsmax(views[0], B, slot))
+            for j, v in enumerate(views):
+                rec.emit(_lib.OP_GRAD_SCALE, _lib.CmdGradScale(v, v, B, slot, exp, self._ptr(self.scales, self.i), None,
+                                                               self._ptr(self.scales, self.i + 1) if j == 0 else None))
+            self.i += 1
+            return
         check(_lib.lib.esr_grad_absmax(C.byref(views[0]), B, slot, stream_ptr()), 'esr_grad_absmax')
         for j, v in enumerate(views):
             check(_lib.lib.esr_grad_scale(C.byref(v), C.byref(v), B, slot, exp, self._ptr(self.scales, self.i), None,
@@ -414,6 +542,10 @@ class GradScaler:
 
     def rescaled_copy(self, B, src, dst, scale_then):
         """dst = src * (current / scale_then): bring a buffer produced under an earlier scale to the current one."""
+        rec = _rec()
+        if rec is not None:
+            rec.emit(_lib.OP_GRAD_SCALE, _lib.CmdGradScale(src, dst, B, None, 0, self._ptr(self.scales, self.i), scale_then.data_ptr(), None))
+            return
         check(_lib.lib.esr_grad_scale(C.byref(src), C.byref(dst), B, None, 0, self._ptr(self.scales, self.i), scale_then.data_ptr(), None,
                                       stream_ptr()), 'esr_grad_scale')
 
@@ -423,6 +555,11 @@ def unpack_grad_nchw(G, dst, C_, h, w, c0, nc, pad=0, down=1, accumulate=False, 
     laid out [B][C_][h][w] (image b at dst + b*batch_stride floats; 0 = C_*h*w)."""
     require_gpu(dst, 'gradient')
     assert dst.dtype == torch.float32 and dst.is_contiguous()
+    rec = _rec()
+    if rec is not None:
+        rec.emit(_lib.OP_UNPACK_GRAD_NCHW, _lib.CmdUnpackGradNchw(G, dst.data_ptr(), batch_stride, dst.shape[0], C_, h, w, c0, nc, pad, down,
+                                                                  1 if accumulate else 0), ('dst',))
+        return
     check(_lib.lib.esr_unpack_grad_nchw(C.byref(G), dst.data_ptr(), batch_stride, dst.shape[0], C_, h, w, c0, nc, pad, down,
                                         1 if accumulate else 0, stream_ptr()), 'esr_unpack_grad_nchw')
 

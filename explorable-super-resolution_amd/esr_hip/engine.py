@@ -19,6 +19,9 @@ import weakref
 
 import torch
 
+import ctypes as C
+
+from . import _lib
 from . import act as A
 from ._lib import EsrError
 
@@ -43,6 +46,10 @@ class RRDBEngine:
         self._packs_fp = None
         self._pack_sets = 0  # bumped whenever a pack dict is created or dropped: part of the fingerprint (ids of dicts get recycled)
         self._wgb = {}       # this engine's uploaded weight-gradient descriptor tables (A.conv3x3_wgrad_batch)
+        # launch lists (esr_run): a pass over a cached buffer set is recorded once and replayed with one C call per segment afterwards;
+        # ESR_PLANS=0 issues every launch from Python instead (the recording path itself, used by the tests as the reference)
+        self.use_plans = os.environ.get('ESR_PLANS', '1') != '0'
+        self._ptr_fp, self._ptr_epoch = None, 0   # parameter storages the recorded descriptors point into; epoch moves when any changes
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
@@ -108,6 +115,9 @@ class RRDBEngine:
         fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(d is not None for d in dicts), self._pack_sets, self.generation)
         if fp == self._packs_fp:
             return
+        ptrs = tuple(a for a, _ in fp[0])
+        if ptrs != self._ptr_fp:              # a parameter moved (load into new storage, .to()): biases are read in place by the kernels
+            self._ptr_fp, self._ptr_epoch = ptrs, self._ptr_epoch + 1
         packs = [p for d in dicts if d for p in d.values()]
         if any(p.stale() for p in packs):
             self._pack_batch.run(packs)
@@ -218,7 +228,9 @@ class RRDBEngine:
             busy = cached.get('_busy')
             if not keep or busy is None or busy() is None:
                 return self._lease(cached) if keep else cached
-            return self._lease(self._new_buffers(B, h, w, dev, keep))
+            fresh = self._new_buffers(B, h, w, dev, keep)
+            fresh['_ephemeral'] = True        # lives for one pass: not worth recording a launch list for
+            return self._lease(fresh)
         if len(self._bufs) > 2:
             self._bufs.clear()
         d = self._new_buffers(B, h, w, dev, keep)
@@ -255,6 +267,7 @@ class RRDBEngine:
             ups.append(A.ActBuf(B, 8, s * h, s * w, dev, sp))
         d['ups'] = ups
         d['hr0'] = A.ActBuf(B, 8, sf * h, sf * w, dev, sp)
+        d['_plans'] = {}                      # recorded launch lists over this buffer set (shared by its leased copies)
         return d
 
     # ------------------------------------------------------------------ forward
@@ -274,6 +287,9 @@ class RRDBEngine:
             raise EsrError('expected %d input channels (latent %d x sf^2 + 3), got %d' % (lat1 * sf * sf + 3, lat1, x.shape[1]))
         return sf, has_lat, lat1
 
+    def _plan_key(self, kind, *what):
+        return (kind,) + what + (self.split, self._ptr_epoch, self._pack_sets)
+
     @A.one_stream
     def run_forward(self, x, pad=0, keep=False):
         """Returns (g, bufs).  keep=True keeps one buffer per RDB so that `bufs` holds every activation the backward needs."""
@@ -283,11 +299,32 @@ class RRDBEngine:
             x = x.float().contiguous()
         sf, has_lat, lat1 = self._check(x)
         B, Ct, h0, w0 = x.shape
+        self.packed()                         # weight packs refreshed here, outside any recording: replays assume current packs
+        bufs = self._buffers(B, h0 + 2 * pad, w0 + 2 * pad, x.device, keep)
+        g = torch.empty(B, net.out_nc, sf * (h0 + 2 * pad), sf * (w0 + 2 * pad), dtype=torch.float32, device=x.device)
+        if not self.use_plans or bufs.get('_ephemeral') or A._rec() is not None:
+            self._forward_launches(x, pad, keep, bufs, g)
+            return g, bufs
+        key = self._plan_key('fwd', tuple(x.shape), pad, keep)
+        plan = bufs['_plans'].get(key)
+        if plan is None:
+            rec = A.Recorder({'x': x, 'g': g})
+            with A.recording(rec):
+                self._forward_launches(x, pad, keep, bufs, g)
+            plan = bufs['_plans'][key] = rec.finish()
+        plan.run({'x': x, 'g': g})
+        return g, bufs
+
+    def _forward_launches(self, x, pad, keep, bufs, g):
+        """The launch sequence of one forward pass over `bufs` into `g` (issued directly, or collected by an active A.Recorder)."""
+        net = self.net
+        sf, has_lat, lat1 = self._check(x)
+        B, Ct, h0, w0 = x.shape
         pk = self.packed()
         h, w = h0 + 2 * pad, w0 + 2 * pad
         H, W = sf * h, sf * w
-        bufs = self._buffers(B, h, w, x.device, keep)
         conv = A.conv3x3
+        A.reset_launch_parity()
 
         # ---- input packing (+ replicate pad, + latent bilinear /sf)
         A.pack_nchw(x, bufs['xin'].view(), c0=Ct - 3, nc=3, pad=pad)
@@ -302,8 +339,7 @@ class RRDBEngine:
                 zhr = bufs['zhr'].view()
         zall = zlr if net._lat_all_layers else None
 
-        if self._ev:
-            self._ev[0].record()
+        A.host_op(lambda ctx: self._ev and self._ev[0].record())
         rdb = bufs['rdb']
         nrdb = 3 * net.nb
 
@@ -352,11 +388,8 @@ class RRDBEngine:
                 conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view())
             src = bufs['ups'][j]
         conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view())
-        g = torch.empty(B, net.out_nc, H, W, dtype=torch.float32, device=x.device)
         conv(pk['hr1'], bufs['hr0'].view(), B, H, W, net.out_nc, in0=zhr, out_nchw=g)
-        if self._ev:
-            self._ev[1].record()
-        return g, bufs
+        A.host_op(lambda ctx: self._ev and self._ev[1].record())
 
     # ------------------------------------------------------------------ backward
     @A.one_stream
@@ -368,6 +401,39 @@ class RRDBEngine:
         if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
+        dg = dg.detach()
+        dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
+        self.packed_t()                       # weight packs refreshed outside any recording
+        if self.net.nb:
+            self.packed_rdb_t()
+        # the launch-list path covers the passes whose only non-library work is allocating dx and the flat dW buffer; 'mixed' (device-side
+        # gradient scales read by torch ops in between) and pixel-shuffle networks (index_copy_ of permuted rows) launch directly
+        planned = self.use_plans and self._bwd_split != 'mixed' and not self._pshuf and not bufs.get('_ephemeral') and A._rec() is None \
+            and '_plans' in bufs
+        if not planned:
+            return self._backward_launches(x_shape, pad, bufs, dg, need_dx, need_dw)
+        B, Ct, h0, w0 = x_shape
+        dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dg.device) if need_dx else None
+        ext = {'dg': dg}
+        if dx is not None:
+            ext['dx'] = dx
+        key = self._plan_key('bwd', tuple(x_shape), pad, bool(need_dx), bool(need_dw))
+        entry = bufs['_plans'].get(key)
+        if entry is None:
+            wg = WGrad(self, need_dw, B)
+            rec = A.Recorder(ext)
+            with A.recording(rec):
+                _, grads = self._backward_launches(x_shape, pad, bufs, dg, need_dx, need_dw, dx=dx, wg=wg, pool={}, keep=rec.keep)
+            entry = bufs['_plans'][key] = (rec.finish(), wg)
+        else:
+            grads = entry[1].rebind()
+        entry[0].run(ext)
+        return dx, grads
+
+    def _backward_launches(self, x_shape, pad, bufs, dg, need_dx, need_dw, dx=None, wg=None, pool=None, keep=None):
+        """The launch sequence of one backward pass (issued directly, or collected by an active A.Recorder — then `dx`, the weight-gradient
+        collector `wg`, a private gradient-buffer `pool` and the list `keep` that receives every buffer the recorded commands point to are
+        supplied by the caller)."""
         net, sp = self.net, self._bwd_split
         sf = net.upscale
         has_lat = net.latent_input is not None and net.num_latent_channels > 0
@@ -379,8 +445,7 @@ class RRDBEngine:
         dev = dg.device
         pt = self.packed_t()
         conv = A.conv3x3
-        dg = dg.detach()
-        dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
+        A.reset_launch_parity()
         f16_bwd = sp == 'mixed'
         gscale = None                 # device scalar: the power of two the gradients in flight are currently scaled by
         if f16_bwd:
@@ -396,18 +461,21 @@ class RRDBEngine:
             gscale = scaler.current
             dg = dg * gscale
         hi_only = dict(in1_lo_groups=-1) if f16_bwd else {}       # dense-block convs multiply hi planes only (see run_forward)
-        wg = WGrad(self, need_dw, B, hi_only=f16_bwd)
+        if wg is None:
+            wg = WGrad(self, need_dw, B, hi_only=f16_bwd)
         wg.gscale = gscale
         # gradient buffers come from a per-engine pool and go back to it when this pass is over: their zero borders (which the conv
         # kernels rely on and no producer ever writes) survive, so a steady-state step does no buffer memsets at all.  Everything
         # runs on one stream, so the next pass may reuse them as soon as its kernels are enqueued behind this one's.
         pool_key = (B, h, w, str(dev), sp)
-        if self._gpool_key != pool_key:
-            self._gpool, self._gpool_key = {}, pool_key
+        if pool is None:
+            if self._gpool_key != pool_key:
+                self._gpool, self._gpool_key = {}, pool_key
+            pool = self._gpool
         taken = []
 
         def galloc(Bb, ncg, Hh, Ww):
-            free = self._gpool.setdefault((ncg, Hh, Ww), [])
+            free = pool.setdefault((ncg, Hh, Ww), [])
             buf = free.pop() if free else A.ActBuf(Bb, ncg, Hh, Ww, dev, sp)
             taken.append(buf)
             return buf
@@ -551,9 +619,9 @@ class RRDBEngine:
             scaler.rescaled_copy(B, G_trunk.view(), G_short.view(), gscale_trunk)
         A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_short.view(), beta=1.0, s=1)
         wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w, keep=(G_fea,))
-        dx = None
         if need_dx:
-            dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dev)
+            if dx is None:
+                dx = torch.zeros(B, Ct, h0, w0, dtype=torch.float32, device=dev)
             G_x = galloc(B, 1, h, w)
             conv(pt['fea', 'm0'], G_fea.view(), B, h, w, 3, out=G_x.view(), use_bias=False)
             A.unpack_grad_nchw(G_x.view(), dx, Ct, h0, w0, c0=Ct - 3, nc=3, pad=pad)
@@ -571,8 +639,11 @@ class RRDBEngine:
                 A.unpack_grad_nchw(GZ_hr.view(), dz, lat1, sf * h0, sf * w0, c0=0, nc=lat1, pad=sf * pad)
                 dx[:, :lat1 * sf * sf].add_(dz.div_(gscale_hr))
         grads = wg.result()                   # the batched weight-gradient launch is enqueued here, before the buffers are recycled
-        for buf in taken:
-            self._gpool[buf.ncg, buf.H, buf.W].append(buf)
+        if keep is not None:                  # recorded: the launch list owns its gradient buffers
+            keep.extend(taken)
+        else:
+            for buf in reversed(taken):       # reversed: the next pass pops them in the same order, i.e. builds the same descriptors
+                pool[buf.ncg, buf.H, buf.W].append(buf)
         return dx, grads
 
 
@@ -605,6 +676,8 @@ class WGrad:
                 self.offsets[name] = n
                 n += c.weight.numel() + c.weight.shape[0]
             self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(self.mods.values())).weight.device)
+            self._sizes = [k for c in self.mods.values() for k in (c.weight.numel(), c.weight.shape[0])]
+            self._params = [(c.weight, c.bias) for c in self.mods.values()]
 
     def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=(), rows=None):
         """rows: dy's channels are a permutation of the layer's output channels (pixel-shuffle convs): dy channel i is output channel rows[i]."""
@@ -634,6 +707,22 @@ class WGrad:
 
     def result(self):
         if self.enabled and self.descs:
+            rec = A._rec()
+            if rec is not None:
+                # recorded pass: the descriptor table goes to the device now, its launch into the list; rebind() serves the replays
+                self._arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
+                self._flat_ptr = self.flat.data_ptr()
+                need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self._arr, len(self.descs))
+                _lib.check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.flat.device)
+                self._upload()
+                rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(self._ws.data_ptr(), self._plan))
+                rec.keep.extend(self.keep)
+                rec.keep.append(self._ws)
+                assert not self.permuted and not self.scaled
+                self._n, self._dev = self.flat.numel(), self.flat.device
+                grads, self.descs, self.keep, self.flat, self.grads = self.grads, [], [], None, None      # hold no reference to a step's gradients
+                return grads
             A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device, cache=self.engine._wgb)
             for (tdw, tdb), (dw, db), rows in self.permuted:
                 dw.index_copy_(0, rows, tdw)
@@ -649,3 +738,31 @@ class WGrad:
                 self.flat[o:o + n].div_(g)
             self.descs, self.keep = [], []
         return self.grads
+
+    def _upload(self):
+        self._plan = _lib.WgradBatchPlan()
+        _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_upload(self._arr, len(self._arr), self._ws.data_ptr(), self._ws.numel(), C.byref(self._plan),
+                                                           A.stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
+
+    def rebind(self):
+        """Replay of a recorded pass: a fresh zeroed flat buffer (its views become the parameters' .grad), the descriptor table re-pointed
+        (and re-uploaded) only if the allocator did not hand back the same storage.  Returns {param: grad}."""
+        if not self.enabled:
+            return None
+        flat = torch.zeros(self._n, dtype=torch.float32, device=self._dev)
+        delta = flat.data_ptr() - self._flat_ptr
+        if delta:
+            for d in self._arr:
+                d.dw += delta
+                d.db += delta
+            self._flat_ptr += delta
+            before = bytes(self._plan)
+            self._upload()
+            assert bytes(self._plan) == before      # same shapes -> same launch geometry: the recorded command stays valid
+        parts = flat.split(self._sizes)
+        grads = {}
+        for i, (w, b) in enumerate(self._params):
+            grads[w] = parts[2 * i].view(w.shape)
+            if b is not None:
+                grads[b] = parts[2 * i + 1]
+        return grads

@@ -491,6 +491,8 @@ def gen_F12():
         out['call%d/random_pts' % call] = np.stack(draws['pt'])                     # [passes, B, 1, 1, 1]
         if draws['z']:
             out['call%d/initial_pre_tanh_Z' % call] = np.stack(draws['z'])[0]
+            out['call%d/z_search_losses' % call] = np.array(m.Z_optimizer.loss_values, dtype=np.float64)
+            out['call%d/optimal_Z_sub' % call] = zm.Return_Detached_Z()[:, :, ::16, ::16].numpy().copy()
         out['call%d/D_grad_norms' % call] = _norms(dp)
         for k in ('l_d_real', 'l_d_fake', 'l_d_gp', 'D_real', 'D_fake', 'D_logits_diff'):
             out['call%d/%s' % (call, k)] = np.array(log[k])

@@ -1,0 +1,103 @@
+"""GPU tests (-m gpu) of the launch lists (esr_cmd / esr_run, include/esr_hip.h): a pass of the generator recorded once and replayed with
+one C-ABI call must produce bit-identical results to the same launches issued one FFI call at a time (ESR_PLANS=0 path: the recording
+code itself), across replays with NEW input / output tensors (the patched pointers), in inference and in training (dx and every dW)."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle.weights import fill_formula_weights, seeded_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def make_net(nb=2, lat=3, sf=4, precision='split'):
+    import models.modules.architecture as arch
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+    fill_formula_weights(net, gain=0.5)
+    net = net.cuda()
+    net.set_precision(precision)
+    return net
+
+
+def inputs(B, lat, sf, h, w, seed):
+    return seeded_uniform((B, 3 + lat * sf * sf, h, w), seed).cuda()
+
+
+@pytest.mark.parametrize('precision', ['split', 'bf16', 'mixed'])
+def test_replayed_forward_is_bit_identical_to_direct_launches(precision):
+    net = make_net(precision=precision)
+    eng = net.engine
+    xs = [inputs(2, 3, 4, 20, 24, 70 + i) for i in range(3)]
+    with torch.no_grad():
+        eng.use_plans = False
+        ref = [net(x, pad=2).clone() for x in xs]
+        eng.use_plans = True
+        got = [net(x, pad=2) for x in xs]           # call 0 records, calls 1-2 replay into new output tensors from new inputs
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
+    plans = [p for b in eng._bufs.values() for p in b['_plans'].values()]
+    assert len(plans) == 1 and plans[0].n_cmds >= 3 + 15 * 2 + 5      # one list for the whole pass, not one per call
+    assert len({g.data_ptr() for g in got}) == 3
+
+
+@pytest.mark.parametrize('precision', ['split', 'bf16'])
+def test_replayed_training_pass_is_bit_identical_to_direct_launches(precision):
+    def run(use_plans):
+        net = make_net(precision=precision)
+        net.engine.use_plans = use_plans
+        outs = []
+        for i in range(3):
+            x = inputs(2, 3, 4, 16, 20, 80 + i).requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            (y * seeded_uniform(tuple(y.shape), 90 + i).cuda()).sum().backward()
+            outs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+            del y                                    # frees the saved buffer set: the next forward reuses it (and its recorded lists)
+        return net, outs
+    _, ref = run(False)
+    net, got = run(True)
+    for (y0, dx0, dw0), (y1, dx1, dw1) in zip(ref, got):
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
+    kinds = sorted(k[0] for b in net.engine._bufs.values() for k in b['_plans'])
+    assert kinds == ['bwd', 'fwd']                   # one list per pass kind, recorded on the first step and replayed on the other two
+
+
+def test_replay_follows_weight_updates_and_gradient_accumulation():
+    """The lists point at the weight PACKS, which are refreshed before every replay; .grad accumulation over two backward passes must add
+    into the first pass's gradients (each pass gets its own flat dW buffer)."""
+    net = make_net(nb=1)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    ref = make_net(nb=1)
+    ref.engine.use_plans = False
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=1e-3)
+    for i in range(3):
+        for n_, o_ in ((net, opt), (ref, opt_ref)):
+            o_.zero_grad()
+            for j in range(2):                       # two accumulation passes per step
+                x = inputs(1, 3, 4, 12, 12, 100 + 2 * i + j)
+                n_(x).square().mean().backward()
+            o_.step()
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert torch.equal(a, b) and torch.equal(a.grad, b.grad)
+
+
+def test_esr_run_reports_the_failing_command():
+    from esr_hip import _lib
+    cmds = (_lib.Cmd * 2)()
+    cmds[0].op = _lib.OP_ZERO
+    buf = torch.ones(64, dtype=torch.int32, device='cuda')
+    cmds[0].u.zero.p, cmds[0].u.zero.n16 = buf.data_ptr(), 4
+    cmds[1].op = 99
+    failed = C.c_int(-7)
+    rc = _lib.lib.esr_run(cmds, 2, C.byref(failed), None)
+    assert rc == _lib.ESR_E_ARG and failed.value == 1
+    torch.cuda.synchronize()
+    assert int(buf[:16].abs().sum()) == 0 and int(buf[16:].sum()) == 48        # command 0 ran, the list stopped at command 1
+    assert _lib.lib.esr_run(cmds, 1, C.byref(failed), None) == 0 and failed.value == -1
+    assert _lib.lib.esr_run(None, 3, None, None) == _lib.ESR_E_ARG
