@@ -46,6 +46,11 @@ class PackDesc(C.Structure):
                 ('mtiles', C.c_int32), ('transposed', C.c_int32), ('split', C.c_int32), ('scale', C.c_float), ('wpack', C.c_void_p)]
 
 
+class AdamTensor(C.Structure):
+    """esr_adam_tensor (include/esr_hip.h)."""
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
+
+
 # ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
 OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
     OP_PACK_BATCH_RUN, OP_ZERO = range(1, 11)
@@ -108,6 +113,9 @@ CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW
 
 
 _SIGS = {
+    'esr_adam_workspace_bytes': (C.c_int64, [C.POINTER(AdamTensor), C.c_int]),
+    'esr_adam_upload': (C.c_int64, [C.POINTER(AdamTensor), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'esr_adam_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'esr_run': (C.c_int, [C.POINTER(Cmd), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     'esr_cmd_bytes': (C.c_int64, []),
     'esr_version': (C.c_int, []),

@@ -310,6 +310,12 @@ class PackedConv:
         self._wd = wd                             # keeps a converted copy alive until the pack has run
         return [(wd, self.kmap, self.ncg_in, self.mmap, self.mtiles, 1 if self.transposed else 0, 1.0, self.wpack.data_ptr())]
 
+    @property
+    def needs_after_pack(self):
+        """False when after_pack() has nothing to do besides staleness bookkeeping (the batched re-pack skips it then): no bias to copy —
+        the kernel reads the parameter's own storage, whose address the engine's pointer epoch watches."""
+        return not (self.bias_p is None or self.transposed or self._bias_shared)
+
     def after_pack(self):
         if self.bias_p is not None and not self.transposed and not self._bias_shared:
             if self.rows is not None:
@@ -341,17 +347,24 @@ class PackBatch:
 
     def __init__(self):
         self.pack_ids, self.wptrs, self.ws, self.n, self.nblocks = None, None, None, 0, 0
+        self.epoch, self.npacks, self.post = None, 0, []
 
-    def run(self, packs):
+    def run(self, packs, epoch=None):
         """Steady state of a training step (same packs, same weight storages, new values): one esr_pack_batch_run — the per-pack job lists are
-        rebuilt only when a pack or a weight pointer changed."""
-        ids = tuple(id(pk) for pk in packs)
-        wptrs = tuple(w.data_ptr() for pk in packs for w in pk.weights())
-        if ids != self.pack_ids or wptrs != self.wptrs:
+        rebuilt only when a pack or a weight pointer changed.  `epoch`: the caller's token for "same pack objects, same parameter storages"
+        (the engine's pointer epoch and pack-set counter); without it the pack ids and weight pointers are compared."""
+        if epoch is not None:
+            same = epoch == self.epoch and len(packs) == self.npacks and self.wptrs is not None
+        else:
+            ids = tuple(id(pk) for pk in packs)
+            wptrs = tuple(w.data_ptr() for pk in packs for w in pk.weights())
+            same = ids == self.pack_ids and wptrs == self.wptrs
+        if not same:
             jobs = []
             for pk in packs:
                 pk.prepare()
                 jobs += [j + (fmt_code(pk.split),) for j in pk.jobs()]
+            wptrs = tuple(w.data_ptr() for pk in packs for w in pk.weights())
             if any(j[0].dtype != torch.float32 or not j[0].is_contiguous() for j in jobs):
                 wptrs = None            # a converted copy is packed: it must be refreshed every time, no fast path
             arr = (_lib.PackDesc * len(jobs))()
@@ -365,9 +378,11 @@ class PackBatch:
             nb = _lib.lib.esr_pack_batch_upload(arr, len(jobs), self.ws.data_ptr(), self.ws.numel(), stream_ptr())
             check(min(nb, 0), 'esr_pack_batch_upload')
             self.n, self.nblocks = len(jobs), int(nb)
-            self.pack_ids, self.wptrs = ids, wptrs
+            self.pack_ids, self.wptrs, self.epoch, self.npacks = tuple(id(pk) for pk in packs), wptrs, epoch, len(packs)
+            # packs with work of their own after the launch (a bias copy: permuted rows / a bias that is not the parameter itself)
+            self.post = [pk for pk in packs if getattr(pk, 'needs_after_pack', True)]
         check(_lib.lib.esr_pack_batch_run(self.ws.data_ptr(), self.n, self.nblocks, stream_ptr()), 'esr_pack_batch_run')
-        for pk in packs:
+        for pk in (self.post if same else packs):      # after a rebuild every pack re-reads its parameter pointers (shared biases)
             pk.after_pack()
 
 
@@ -422,6 +437,8 @@ class PackedSum:
             self._wd.append(wd)
             out.append((wd, kmap, wd.shape[0] // 8, mmap, self.mtiles, 1, scale, self.wpack.data_ptr() + (g0 // 2) * self.chunk_bytes))
         return out
+
+    needs_after_pack = False
 
     def after_pack(self):
         self._key = self.key()

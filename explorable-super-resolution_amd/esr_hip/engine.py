@@ -37,6 +37,7 @@ class RRDBEngine:
         if os.environ.get('ESR_DEFAULT_PRECISION'):        # experiments / whole-suite checks of a non-default mode
             self.split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[os.environ['ESR_DEFAULT_PRECISION']]
         self._convs_cache = None
+        self._params_cache, self._params_probe = None, None
         self._packed = None
         self._packed_t = None
         self._packed_rdb_t = None
@@ -45,6 +46,7 @@ class RRDBEngine:
         self._pack_batch = A.PackBatch()
         self._packs_fp = None
         self._pack_sets = 0  # bumped whenever a pack dict is created or dropped: part of the fingerprint (ids of dicts get recycled)
+        self._pack_gen = [0, 0, 0]   # the value of _pack_sets when the forward / data-gradient / dense-block data-gradient dict was made
         self._wgb = {}       # this engine's uploaded weight-gradient descriptor tables (A.conv3x3_wgrad_batch)
         # launch lists (esr_run): a pass over a cached buffer set is recorded once and replayed with one C call per segment afterwards;
         # ESR_PLANS=0 issues every launch from Python instead (the recording path itself, used by the tests as the reference)
@@ -85,8 +87,15 @@ class RRDBEngine:
         return self._convs_cache
 
     def parameters(self):
-        """The generator's parameters in execution order, without walking the module tree (700 of them, every forward)."""
-        return [p for _, c, _ in self._convs() for p in (c.weight, c.bias) if p is not None]
+        """The generator's parameters in execution order, without walking the module tree (700 of them, every forward).  The list is
+        rebuilt only when a module's parameter object was replaced (rare: nn.Module.to() keeps the objects, assigning a new nn.Parameter
+        does not) — checked through the conv modules' identity-stable (weight, bias) attributes of the first and last layer."""
+        convs = self._convs()
+        probe = (convs[0][1].weight, convs[-1][1].weight)
+        if self._params_cache is None or self._params_probe[0] is not probe[0] or self._params_probe[1] is not probe[1]:
+            self._params_cache = [p for _, c, _ in convs for p in (c.weight, c.bias) if p is not None]
+            self._params_probe = probe
+        return self._params_cache
 
     def _walk_convs(self):
         net = self.net
@@ -118,9 +127,11 @@ class RRDBEngine:
         ptrs = tuple(a for a, _ in fp[0])
         if ptrs != self._ptr_fp:              # a parameter moved (load into new storage, .to()): biases are read in place by the kernels
             self._ptr_fp, self._ptr_epoch = ptrs, self._ptr_epoch + 1
+        # something changed (a training step changes every parameter): ONE launch re-packs everything.  No per-pack staleness test — with
+        # ~800 packs that bookkeeping cost more host time than the launch does on the device.
         packs = [p for d in dicts if d for p in d.values()]
-        if any(p.stale() for p in packs):
-            self._pack_batch.run(packs)
+        if packs:
+            self._pack_batch.run(packs, epoch=(self._ptr_epoch, self._pack_sets))
         self._packs_fp = fp
 
     @property
@@ -168,6 +179,7 @@ class RRDBEngine:
                     d[name] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name))
             self._packed = d
             self._pack_sets += 1
+            self._pack_gen[0] = self._pack_sets
         self._refresh_packs()
         return self._packed
 
@@ -187,6 +199,7 @@ class RRDBEngine:
                     d[name, 'z'] = A.PackedConv(c.weight, None, lat, split=self._bwd_wfmt(False), transposed=True, m_slice='latent')
             self._packed_t = d
             self._pack_sets += 1
+            self._pack_gen[1] = self._pack_sets
         self._refresh_packs()
         return self._packed_t
 
@@ -214,6 +227,7 @@ class RRDBEngine:
                         d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_wfmt(True))
             self._packed_rdb_t = d
             self._pack_sets += 1
+            self._pack_gen[2] = self._pack_sets
         self._refresh_packs()
         return self._packed_rdb_t
 
@@ -288,7 +302,9 @@ class RRDBEngine:
         return sf, has_lat, lat1
 
     def _plan_key(self, kind, *what):
-        return (kind,) + what + (self.split, self._ptr_epoch, self._pack_sets)
+        # a forward list points into the forward packs only: creating the data-gradient packs later (first backward) leaves it valid
+        packs = self._pack_gen[0] if kind == 'fwd' else tuple(self._pack_gen)
+        return (kind,) + what + (self.split, self._ptr_epoch, packs)
 
     @A.one_stream
     def run_forward(self, x, pad=0, keep=False):

@@ -1,0 +1,67 @@
+"""torch.optim.Adam's update (what the reference steps both networks with, codes/models/SRRaGAN_model.py:147-160) as ONE kernel launch over
+all tensors of a parameter group (esr_adam_*, csrc/esr_optim.hip).  Same state layout as torch.optim.Adam ('step', 'exp_avg', 'exp_avg_sq'
+per parameter), so schedulers, state_dict() and checkpoints written by either implementation load into the other."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .act import require_gpu, stream_ptr
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError('invalid Adam hyper-parameters')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}           # group index -> (pointer fingerprint, workspace tensor, n tensors, n chunks)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            grads = []
+            for p in ps:
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                grads.append(g)
+                st = self.state[p]
+                if not st:
+                    require_gpu(p, 'parameter')
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise _lib.EsrError('esr_hip.optim.Adam steps contiguous fp32 parameters')
+                    st['step'] = torch.zeros((), dtype=torch.float32)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # every tensor that has a gradient steps together; a parameter that sat out earlier steps would need its own bias corrections
+            t = float(self.state[ps[0]]['step'])
+            if float(self.state[ps[-1]]['step']) != t:
+                raise _lib.EsrError('parameters of one group have stepped a different number of times: put them into separate groups')
+            t += 1
+            fp = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(ps, grads))
+            tab = self._tables.get(gi)
+            if tab is None or tab[0] != fp:
+                arr = (_lib.AdamTensor * len(ps))()
+                for a, p, g in zip(arr, ps, grads):
+                    st = self.state[p]
+                    a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+                need = _lib.lib.esr_adam_workspace_bytes(arr, len(ps))
+                _lib.check(min(need, 0), 'esr_adam_workspace_bytes')
+                ws = tab[1] if (tab is not None and tab[1].numel() >= need) else torch.empty(int(need), dtype=torch.uint8, device=ps[0].device)
+                nchunks = _lib.lib.esr_adam_upload(arr, len(ps), ws.data_ptr(), ws.numel(), stream_ptr())
+                _lib.check(min(nchunks, 0), 'esr_adam_upload')
+                tab = self._tables[gi] = (fp, ws, len(ps), int(nchunks))
+            b1, b2 = group['betas']
+            _lib.check(_lib.lib.esr_adam_run(tab[1].data_ptr(), tab[2], tab[3], float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
+                                             1 - b1 ** t, math.sqrt(1 - b2 ** t), stream_ptr()), 'esr_adam_run')
+            for p in ps:
+                self.state[p]['step'].fill_(t)
+        return loss

@@ -22,6 +22,7 @@ import torch.nn as nn
 import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
+from esr_hip import optim as esr_optim
 from models.modules.loss import CreateRangeLoss, FilterLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
 
@@ -153,14 +154,16 @@ class SRRaGANModel(BaseModel):
             # (torch's fused Adam was measured on this part: 7.1 ms per step for the generator's 702 tensors against 1.4 ms for the default
             # foreach implementation — not used)
             fused = dict(fused=True) if train_opt['fused_adam'] else {}
-            self.optimizer_G = torch.optim.Adam(optim_params, lr=self.lr_G, weight_decay=wd_G,
-                                                betas=(train_opt['beta1_G'] or 0.9, train_opt['beta2_G'] if train_opt['beta2_G'] is not None else 0.999), **fused)
+            # esr_hip.optim.Adam: torch.optim.Adam's update for all 702 tensors as one kernel launch (train.torch_adam: true selects torch's)
+            Adam = torch.optim.Adam if (train_opt['torch_adam'] or fused or self.device.type != 'cuda') else esr_optim.Adam
+            self.optimizer_G = Adam(optim_params, lr=self.lr_G, weight_decay=wd_G,
+                                    betas=(train_opt['beta1_G'] or 0.9, train_opt['beta2_G'] if train_opt['beta2_G'] is not None else 0.999), **fused)
             self.optimizers.append(self.optimizer_G)
             self.grad_reducer = esr_dist.GradBucketAllReducer(optim_params)
             if self.D_exists:
                 wd_D = train_opt['weight_decay_D'] if train_opt['weight_decay_D'] else 0
-                self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=self.lr_D, weight_decay=wd_D,
-                                                    betas=(train_opt['beta1_D'] or 0.9, train_opt['beta2_D'] if train_opt['beta2_D'] is not None else 0.999), **fused)
+                self.optimizer_D = Adam(self.netD.parameters(), lr=self.lr_D, weight_decay=wd_D,
+                                        betas=(train_opt['beta1_D'] or 0.9, train_opt['beta2_D'] if train_opt['beta2_D'] is not None else 0.999), **fused)
                 self.optimizers.append(self.optimizer_D)
                 self.grad_reducer_D = esr_dist.GradBucketAllReducer(list(self.netD.parameters()))
             if train_opt['lr_scheme'] == 'MultiStepLR':

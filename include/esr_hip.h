@@ -316,6 +316,21 @@ typedef struct {
 int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);
 int64_t esr_cmd_bytes(void);       /* sizeof(esr_cmd): lets a binding check its struct layout */
 
+/* ---- Adam over many tensors in one launch ----
+ * The reference steps both networks with torch.optim.Adam (codes/models/SRRaGAN_model.py:147-160: lr, betas, weight decay from the options);
+ * torch's multi-tensor implementation costs ~4 ms of host time per step for the generator's 702 tensors.  Same update rule, same fp32
+ * operation order (torch/optim/adam.py, no amsgrad / maximize):
+ *     g += weight_decay * p;  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g;
+ *     p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with bias_correction1 = 1 - beta1^t and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller for step t.
+ * `tensors` is a HOST array; _upload writes it (plus a work table) into caller-owned device `workspace` (>= _workspace_bytes), blocks until
+ * the copy is done and returns the chunk count to pass to _run (>= 0) or ESR_E_*; it is repeated only when a pointer changes. */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } esr_adam_tensor;
+int64_t esr_adam_workspace_bytes(const esr_adam_tensor* tensors, int n);
+int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
+int esr_adam_run(const void* workspace, int n, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float bias_correction1, float bias_correction2_sqrt, esr_stream_t stream);
+
 int esr_version(void);
 
 #ifdef __cplusplus

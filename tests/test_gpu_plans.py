@@ -65,7 +65,7 @@ def test_replayed_training_pass_is_bit_identical_to_direct_launches(precision):
         assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
         assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
     kinds = sorted(k[0] for b in net.engine._bufs.values() for k in b['_plans'])
-    assert kinds == ['bwd', 'fwd']                   # one list per pass kind, recorded on the first step and replayed on the other two
+    assert kinds == ['bwd', 'fwd'], kinds                   # one list per pass kind, recorded on the first step and replayed on the other two
 
 
 def test_replay_follows_weight_updates_and_gradient_accumulation():
@@ -101,3 +101,39 @@ def test_esr_run_reports_the_failing_command():
     assert int(buf[:16].abs().sum()) == 0 and int(buf[16:].sum()) == 48        # command 0 ran, the list stopped at command 1
     assert _lib.lib.esr_run(cmds, 1, C.byref(failed), None) == 0 and failed.value == -1
     assert _lib.lib.esr_run(None, 3, None, None) == _lib.ESR_E_ARG
+
+
+@pytest.mark.parametrize('weight_decay', [0.0, 1e-2])
+def test_multi_tensor_adam_matches_torch_adam(weight_decay):
+    """esr_hip.optim.Adam (one launch for all tensors) against torch.optim.Adam, which the reference uses (SRRaGAN_model.py:147-160): same
+    parameters after 6 steps with a learning-rate change in between, gradients as views of one flat buffer (the engine's layout) whose
+    address changes between steps; state_dict round trip into torch's optimizer."""
+    from esr_hip.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(64, 51, 3, 3), (64,), (32, 67, 3, 3), (32,), (3, 64, 3, 3), (3,), (5001,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = Adam(pa, lr=1e-2, betas=(0.9, 0.99), weight_decay=weight_decay)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), weight_decay=weight_decay)
+    sched_a = torch.optim.lr_scheduler.MultiStepLR(oa, [3], 0.5)
+    sched_b = torch.optim.lr_scheduler.MultiStepLR(ob, [3], 0.5)
+    n = sum(p.numel() for p in pa)
+    hold = []
+    for it in range(6):
+        flat = torch.randn(n, device='cuda') * (10.0 ** -(it % 3))
+        hold.append(flat)                                   # keeps the old buffers allocated: every step sees new gradient addresses
+        off = 0
+        for p, q in zip(pa, pb):
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            q.grad = p.grad.clone()
+            off += p.numel()
+        oa.step(); ob.step(); sched_a.step(); sched_b.step()
+        for p, q in zip(pa, pb):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()), it
+    assert oa.param_groups[0]['lr'] == ob.param_groups[0]['lr'] == 5e-3
+    for p, q in zip(pa, pb):
+        assert float(oa.state[p]['step']) == float(ob.state[q]['step']) == 6
+        torch.testing.assert_close(oa.state[p]['exp_avg_sq'], ob.state[q]['exp_avg_sq'], rtol=1e-5, atol=1e-12)
+    oc = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), weight_decay=weight_decay)
+    oc.load_state_dict(oa.state_dict())                     # same state layout: checkpoints are interchangeable
+    assert float(oc.state[pb[0]]['step']) == 6
