@@ -41,11 +41,15 @@ class Adam(torch.optim.Optimizer):
                     st['step'] = torch.zeros((), dtype=torch.float32)
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            # every tensor that has a gradient steps together; a parameter that sat out earlier steps would need its own bias corrections
-            t = float(self.state[ps[0]]['step'])
-            if float(self.state[ps[-1]]['step']) != t:
-                raise _lib.EsrError('parameters of one group have stepped a different number of times: put them into separate groups')
-            t += 1
+            # every tensor that has a gradient steps together (a parameter that sat out earlier steps would need its own bias
+            # corrections): the group's tensors SHARE one 'step' tensor object, re-established after load_state_dict's deep copies
+            first = self.state[ps[0]]['step']
+            if self.state[ps[-1]]['step'] is not first:
+                if any(float(self.state[p]['step']) != float(first) for p in ps):
+                    raise _lib.EsrError('parameters of one group have stepped a different number of times: put them into separate groups')
+                for p in ps:
+                    self.state[p]['step'] = first
+            t = float(first) + 1
             fp = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(ps, grads))
             tab = self._tables.get(gi)
             if tab is None or tab[0] != fp:
@@ -62,6 +66,5 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group['betas']
             _lib.check(_lib.lib.esr_adam_run(tab[1].data_ptr(), tab[2], tab[3], float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
                                              1 - b1 ** t, math.sqrt(1 - b2 ** t), stream_ptr()), 'esr_adam_run')
-            for p in ps:
-                self.state[p]['step'].fill_(t)
+            first.fill_(t)
         return loss
