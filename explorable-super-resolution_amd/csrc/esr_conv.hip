@@ -114,6 +114,8 @@ struct ConvArgs {
     float resin_scale;              // beta1 / alpha
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
     int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
+    int nslices;                    // cout / 64 when cout > 64, else 1
+    long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -417,7 +419,18 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 //             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
 //             placed), so only a second wave on the same SIMD can multiply meanwhile.
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
-__global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
+    // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
+    // same staged input.  All workgroups of all slices are in flight together: a 512-channel layer on an 8x8 map is one launch of
+    // 32 x 8 workgroups instead of eight launches of 32.  (Everything below is uniform: the shifts are scalar adds; slice 0 adds zero.)
+    ConvArgs a = a_in;
+    {
+        const long long sl = blockIdx.y;
+        a.wpack += sl * a.wslice;
+        if (a.bias) a.bias += sl * 64;
+        auto shift = [&](DView& v) { if (v.hi) { v.hi += sl * 8 * v.cs; if (v.lo) v.lo += sl * 8 * v.cs; } };
+        shift(a.out); shift(a.out2); shift(a.res1); shift(a.res2); shift(a.mask);
+    }
     // PARTLO: only the first a.lo_chunks chunks of the input carry a lo plane (a dense block's trunk input), the rest are single-plane
     // intermediates; and the output's lo plane is optional.  Non-PARTLO kernels treat every chunk alike.
     static_assert(!PARTLO || NPL == 2, "partial lo needs hi+lo activations");
@@ -847,13 +860,14 @@ template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
     ESR_ALLOW_160K_LDS(k);
+    const int nslices = a.wslice ? a.nslices : 1;
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
     ConvArgs b = a;
     b.pc_stages = (NST == 3 && 3 * stage + (size_t)MT * 32 * 4 <= 160 * 1024) ? 3 : 2;
     const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : 2)) * stage + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -862,7 +876,7 @@ template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B * (a.wslice ? a.nslices : 1);
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool small = ntiles <= 320;
 #if ESR_PC
@@ -993,8 +1007,12 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
         (d->res1.hi && d->res1.fmt != d->in1.fmt) || (d->res2.hi && d->res2.fmt != d->in1.fmt))
         return ESR_E_ARG;      // (mask_src may be in either format: only its sign and zero-ness are read, and those bits coincide)
     if (d->in0.hi && ((d->in0.lo != nullptr) != split)) return ESR_E_ARG;
-    const int mt = (d->cout + 31) / 32;
-    if (mt > 2) return ESR_E_UNSUPPORTED;   // callers split wider outputs into 64-channel launches
+    // cout > 64: output slices of 64 channels in ONE launch (grid y); the caller packs the weights of slice s (rows 64 s .. 64 s + 63) as a
+    // 64-row pack at byte offset s * esr_conv_wpack_bytes(groups, 64, fmt) of `wpack`; bias, out, out2, res1, res2 and mask_src are
+    // indexed by absolute output channel
+    const int nslices = d->cout > 64 ? d->cout / 64 : 1;
+    if (d->cout > 64 && (d->cout % 64 || d->out_nchw || d->pixel_shuffle > 1 || !d->out.hi)) return ESR_E_UNSUPPORTED;
+    const int mt = nslices > 1 ? 2 : (d->cout + 31) / 32;
     const int ps = d->pixel_shuffle > 1 ? d->pixel_shuffle : 0;
     if (ps) {
         if (!d->out.hi || d->out_nchw || d->out2.hi || d->res1.hi || d->res2.hi || d->mask_src.hi || d->cout % 8) return ESR_E_UNSUPPORTED;
@@ -1013,7 +1031,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.Win_p = d->in1.W + 2;
     a.wpack = (const uint4*)d->wpack;
     a.bias = d->bias;
-    a.cout = d->cout;
+    a.cout = nslices > 1 ? 64 : d->cout;
+    a.nslices = nslices;
     a.B = d->B;
     a.H = d->H;
     a.W = d->W;
@@ -1046,7 +1065,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     int epi = 0;
     if (d->res1.hi) epi |= EPI_RES1;
     // residual 1 == a channel-group slice of this conv's own main input, linear epilogue: take it from the staged LDS tile
-    if (d->res1.hi && d->act_slope == 1.f && d->alpha != 0.f && ups == 1 && !d->mask_src.hi && !d->out_nchw &&
+    if (nslices == 1 && d->res1.hi && d->act_slope == 1.f && d->alpha != 0.f && ups == 1 && !d->mask_src.hi && !d->out_nchw &&
         d->res1.batch_stride == d->in1.batch_stride && d->res1.cg_stride == d->in1.cg_stride && ((d->res1.lo != nullptr) == split) &&
         d->in1_lo_groups >= 0) {
         const long long unit = (long long)d->in1.cg_stride * 16;
@@ -1067,6 +1086,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     int wpl = d->weight_planes;
     if (wpl == 0) wpl = f16 ? 1 : npl;
     if (wpl < 1 || wpl > npl || (!f16 && wpl != npl)) return ESR_E_ARG;
+    a.wslice = nslices > 1 ? (long long)a.ncp * 9 * 2 * wpl * 64 : 0;
     // which leading chunks of the concatenated input carry a lo plane
     a.lo_chunks = a.ncp;
     bool partlo = false;

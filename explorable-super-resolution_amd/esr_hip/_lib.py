@@ -46,6 +46,13 @@ class PackDesc(C.Structure):
                 ('mtiles', C.c_int32), ('transposed', C.c_int32), ('split', C.c_int32), ('scale', C.c_float), ('wpack', C.c_void_p)]
 
 
+class BnDesc(C.Structure):
+    """esr_bn_desc (include/esr_hip.h)."""
+    _fields_ = [('y', ActView), ('dz', ActView), ('u', ActView), ('out0', ActView), ('out1', ActView), ('B', C.c_int32), ('groups', C.c_int32),
+                ('C', C.c_int32), ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p),
+                ('sums2', C.c_void_p), ('sums3', C.c_void_p), ('slope', C.c_float), ('const_stats', C.c_int32), ('s2d', C.c_int32)]
+
+
 class AdamTensor(C.Structure):
     """esr_adam_tensor (include/esr_hip.h)."""
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
@@ -113,6 +120,11 @@ CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW
 
 
 _SIGS = {
+    'esr_bn_reduce': (C.c_int, [C.POINTER(BnDesc), C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_bn_apply': (C.c_int, [C.POINTER(BnDesc), C.c_int, C.c_void_p]),
+    'esr_bn_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'esr_bn_param_grads': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'esr_adam_workspace_bytes': (C.c_int64, [C.POINTER(AdamTensor), C.c_int]),
     'esr_adam_upload': (C.c_int64, [C.POINTER(AdamTensor), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'esr_adam_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

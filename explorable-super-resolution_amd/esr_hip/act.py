@@ -288,13 +288,15 @@ class PackedConv:
     def prepare(self):
         w = self.weight
         require_gpu(w, 'conv weight')
-        if self.wpack is None:
+        if getattr(self, 'kmap', None) is None:
             dev = w.device
             self.kmap, self.mmap = self._maps(dev)
             if self.rows is not None:
                 self._rows_t = torch.tensor(self.rows, dtype=torch.long, device=dev)
             nbytes = _lib.lib.esr_conv_wpack_bytes(self.ncg_in, self.mtiles * 32, fmt_code(self.split))
-            self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if self.wpack is None:
+                self.wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            assert self.wpack.numel() == nbytes      # a caller-supplied destination (one slice of a multi-slice pack, esr_hip/critic.py)
             bp = self.bias_p
             if bp is not None and not self.transposed and self.rows is None and bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == self.mtiles * 32:
                 self.bias, self._bias_shared = bp.detach(), True        # the kernel reads the parameter itself: always current

@@ -23,6 +23,8 @@ import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
 from esr_hip import optim as esr_optim
+from esr_hip.critic import CriticEngine, critic_forward
+from esr_hip._lib import EsrError
 from models.modules.loss import CreateRangeLoss, FilterLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
 
@@ -66,6 +68,7 @@ class SRRaGANModel(BaseModel):
         self.generator_changed = True
         self.generator_started_learning = False
         self.optimalZ_loss_type = None
+        self.D_engine = None
         self.timing = None               # set to {} to accumulate per-phase GPU milliseconds of optimize_parameters (bench.py --workload c3)
         if self.is_train:
             if train_opt['feature_weight'] is not None:
@@ -105,6 +108,18 @@ class SRRaGANModel(BaseModel):
                 self.D_dtype = torch.bfloat16 if (net_D.get('precision') or os.environ.get('ESR_D_PRECISION')) == 'bf16' else None
                 if net_D.get('channels_last') or os.environ.get('ESR_D_CHANNELS_LAST') == '1':
                     self.netD = self.netD.to(memory_format=torch.channels_last)
+                # network_D.engine: 'hip' (default where the kernels cover the architecture: conv 3x3 s1 / 4x4 s2 + BatchNorm + LeakyReLU
+                # blocks, Linear classifier) runs the critic, its backward and the penalty's double backward on the library's kernels;
+                # 'stock' keeps the nn.Module on MIOpen.  Asking for 'hip' on an architecture outside that set raises.
+                want = net_D.get('engine') or os.environ.get('ESR_D_ENGINE') or 'auto'
+                if want not in ('auto', 'hip', 'stock'):
+                    raise NotImplementedError("network_D.engine = %r: 'hip', 'stock' or 'auto'" % (want,))
+                if want != 'stock' and self.device.type == 'cuda':
+                    try:
+                        self.D_engine = CriticEngine(self.netD)
+                    except EsrError:
+                        if want == 'hip':
+                            raise
                 # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (configs[2] shapes, bf16 critic: 30.7 -> 20.0 ms per
                 # D step; costs tens of seconds of search the first time a shape is seen, so it is opt-in)
                 find = bool(net_D.get('miopen_find'))
@@ -273,7 +288,12 @@ class SRRaGANModel(BaseModel):
         return torch.rand(batch_size, 1, 1, 1, device=self.device)
 
     def _D(self, x):
-        """The critic's logits in fp32 (under bf16 autocast when network_D.precision = 'bf16')."""
+        """The critic's logits in fp32: on the library's kernels (esr_hip/critic.py; 'bf16' operands when network_D.precision = 'bf16', the
+        fp32-class 'split' otherwise), or — network_D.engine = 'stock', or an architecture the kernels do not cover — the nn.Module on
+        MIOpen (under bf16 autocast for 'bf16')."""
+        if self.D_engine is not None:
+            self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
+            return critic_forward(self.D_engine, x)
         if self.D_dtype is None:
             return self.netD(x)
         with torch.autocast(device_type='cuda', dtype=self.D_dtype):

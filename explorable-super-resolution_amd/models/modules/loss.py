@@ -71,8 +71,10 @@ class GradientPenaltyLoss(nn.Module):
         self.device = device
 
     def forward(self, interp, interp_crit):
-        grad_interp = torch.autograd.grad(outputs=interp_crit, inputs=interp, grad_outputs=torch.ones_like(interp_crit),
-                                          create_graph=True, retain_graph=True, only_inputs=True)[0]
+        from esr_hip.critic import input_grad_only
+        with input_grad_only():       # (a hint to the HIP critic's nodes; stock modules ignore it)
+            grad_interp = torch.autograd.grad(outputs=interp_crit, inputs=interp, grad_outputs=torch.ones_like(interp_crit),
+                                              create_graph=True, retain_graph=True, only_inputs=True)[0]
         norms = grad_interp.reshape(grad_interp.size(0), -1).norm(2, dim=1)
         return ((norms - 1) ** 2).mean()
 

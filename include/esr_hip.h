@@ -82,7 +82,9 @@ typedef struct {
     int32_t upsample;        /* 1, 2 or 3 */
     const void* wpack;       /* weights packed by esr_pack_conv_weights for (in0.ncg + in1.ncg) groups */
     const float* bias;       /* [mtiles*32] fp32, zero padded; NULL = no bias */
-    int32_t cout;            /* real output channels */
+    int32_t cout;            /* real output channels: <= 64, or a multiple of 64 — then the launch covers cout/64 output slices at once and `wpack`
+                              * holds one 64-row pack per slice, slice s at byte offset s * esr_conv_wpack_bytes(in0.ncg + in1.ncg, 64, fmt)
+                              * (no out_nchw / pixel_shuffle with slices) */
     int32_t B, H, W;         /* output interior size (= input size * upsample) */
     float act_slope;         /* 1.0f: identity; 0.2f: LeakyReLU(0.2) */
     float alpha;
@@ -330,6 +332,46 @@ int64_t esr_adam_workspace_bytes(const esr_adam_tensor* tensors, int n);
 int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
 int esr_adam_run(const void* workspace, int n, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float bias_correction1, float bias_correction2_sqrt, esr_stream_t stream);
+
+/* ---- the critic's glue: BatchNorm2d (training mode) + LeakyReLU, its gradient and the gradient of its gradient ----
+ * Reference: Discriminator_VGG_128 (codes/models/modules/architecture.py:446-508): conv_block = nn.Conv2d -> nn.BatchNorm2d(affine, batch
+ * statistics while training; block.py:25-35,129-146) -> LeakyReLU(0.2); the WGAN-GP penalty (codes/models/modules/loss.py:260-279)
+ * differentiates the critic's input gradient, i.e. back-propagates through the BACKWARD of every one of these layers.  All three levels
+ * are closed-form single-pass kernels on the conv kernels' activation layout (csrc/esr_critic.hip states the formulas):
+ *   esr_bn_reduce mode 0 : sums[g][c] = (sum y, sum y^2)                                  esr_bn_finalize: mean, rstd, scale, shift, running stats
+ *   esr_bn_apply  mode 0 : out0 = lrelu(scale*y + shift)                                  (torch: F.batch_norm(training=True) + leaky_relu)
+ *   esr_bn_reduce mode 1 : sums[g][c] = (sum dyb, sum dyb*xhat),  dyb = dz * lrelu'       esr_bn_param_grads: dgamma, dbeta
+ *   esr_bn_apply  mode 1 : out0 = d loss / d y                                            (autograd of the above)
+ *   esr_bn_reduce mode 2 : sums[g][c] = (sum u, sum u*xhat, sum u*dyb)                    (u: cotangent of mode 1's result)
+ *   esr_bn_apply  mode 2 : out0 = cotangent of dz, out1 = cotangent of y                  (torch: batchnorm_double_backward) + g_gamma via
+ *                                                                                          esr_bn_param_grads
+ * groups: the B images are `groups` runs of B/groups consecutive images, each normalised with its OWN batch statistics (the critic's
+ * separate calls on the real, fake and interpolated batches executed as one launch); all per-channel arrays are [groups][C] except gamma /
+ * beta / running_* ([C]).  scale == NULL: no normalisation (the first conv block has none) — then const_stats must be 1.  const_stats: the
+ * affine map does not depend on y (eval-mode BatchNorm with running statistics, or no norm).  s2d: dz (modes 1, 2), out0 of mode 0 and out0 of
+ * mode 2 are stored space-to-depth: logical pixel (y, x) of group cg at pixel (y/2, x/2) of group 4*cg + 2*(y&1) + (x&1) of a view with
+ * H/2 x W/2 pixels — the input layout in which the next block's 4x4 stride-2 conv is a 3x3 stride-1 conv over 4x the channels.
+ * `sums` targets must be zeroed by the caller (the kernels add); sums2 / sums3: completed results of mode 1 / mode 2. */
+typedef struct {
+    esr_act_view y;          /* the conv's output (pre-normalisation); defines B x C x H x W */
+    esr_act_view dz, u;      /* gradient w.r.t. the activated output (modes 1, 2); cotangent of mode 1's result (mode 2) */
+    esr_act_view out0, out1;
+    int32_t B, groups, C;
+    const float* scale; const float* shift; const float* mean; const float* rstd;      /* [groups][C] */
+    const float* gamma;      /* [C] or NULL (ones) */
+    const double* sums2; const double* sums3;
+    float slope;             /* LeakyReLU negative slope; 1.0f = no activation */
+    int32_t const_stats, s2d;
+} esr_bn_desc;
+int esr_bn_reduce(const esr_bn_desc* d, int mode, double* sums, esr_stream_t stream);
+int esr_bn_apply(const esr_bn_desc* d, int mode, esr_stream_t stream);
+/* mean / rstd / scale (= gamma*rstd) / shift (= beta - scale*mean) from mode-0 sums, group by group IN ORDER; running_mean / running_var
+ * (may be NULL) are updated once per group as nn.BatchNorm2d does per call: r = (1-momentum)*r + momentum*stat, variance unbiased. */
+int esr_bn_finalize(const double* sums, int groups, int C, int64_t n_per_group, float eps, float momentum, const float* gamma, const float* beta,
+                    float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, esr_stream_t stream);
+/* dgamma[c] = sum_g sums2[g][c][1], dbeta[c] = sum_g sums2[g][c][0]; g_gamma (double backward; needs sums3, rstd) — any output may be NULL */
+int esr_bn_param_grads(const double* sums2, const double* sums3, const float* rstd, int groups, int C, int64_t n_per_group, float* dgamma, float* dbeta,
+                       float* g_gamma, esr_stream_t stream);
 
 int esr_version(void);
 

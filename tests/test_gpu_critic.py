@@ -1,0 +1,144 @@
+"""GPU tests (-m gpu) of the critic on the library's kernels (esr_hip/critic.py, csrc/esr_critic.hip) against the SAME nn.Module executed
+by torch (fp32, MIOpen) — which tests/test_gpu_callers_f7.py pins to the reference's Discriminator_VGG_128: logits, first-order gradients
+(parameters and input) and the WGAN-GP step's parameter gradients, which differentiate through the backward pass."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.weights import fill_formula_weights, seeded_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def make_D(size=64, gain=1.0):
+    import models.modules.architecture as arch
+    torch.manual_seed(0)
+    netD = arch.Discriminator_VGG_128(in_nc=3, base_nf=64, norm_type='batch', act_type='leakyrelu', mode='CNA', input_patch_size=size)
+    fill_formula_weights(netD, gain=gain)
+    return netD.cuda().train()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_strided_and_sliced_convs_match_torch():
+    """One 4x4 stride-2 block (space-to-depth + embedded 3x3) and one wide 3x3 block (output slices) against F.conv2d in float64."""
+    from esr_hip import critic as K
+    netD = make_D()
+    eng = K.CriticEngine(netD, 'split')
+    eng.refresh()
+    x = seeded_uniform((3, 3, 32, 48), 5).cuda()
+    t = K._PackIn.apply(x, 2)
+    with torch.no_grad():
+        L0, L1, L2 = eng.layers[:3]
+        y0 = eng.conv_fwd(L0, t)
+        ref0 = torch.nn.functional.conv2d(x.double(), L0.conv.weight.double(), L0.conv.bias.double(), padding=1)
+        got0 = K._UnpackOut.apply(y0, 64)
+        assert rel(got0, ref0) < 1e-4
+        z0 = K._BNAct.apply(eng, L0, y0, None, None, True, True)                       # LeakyReLU, stored space-to-depth
+        y1 = eng.conv_fwd(L1, z0)
+        a0 = torch.nn.functional.leaky_relu(got0.double(), 0.2)
+        ref1 = torch.nn.functional.conv2d(a0, L1.conv.weight.double(), L1.conv.bias.double(), stride=2, padding=1)
+        got1 = K._UnpackOut.apply(y1, 64)
+        assert got1.shape == ref1.shape and rel(got1, ref1) < 1e-4
+        z1 = K._BNAct.apply(eng, L1, y1, L1.bn.weight, L1.bn.bias, False, True)        # BatchNorm (batch statistics) + LeakyReLU
+        bn = torch.nn.functional.batch_norm(got1.double(), None, None, L1.bn.weight.double(), L1.bn.bias.double(), training=True, eps=L1.bn.eps)
+        a1 = torch.nn.functional.leaky_relu(bn, 0.2)
+        assert rel(K._UnpackOut.apply(z1, 64), a1) < 1e-4
+        y2 = eng.conv_fwd(L2, z1)                                                     # 64 -> 128: two output slices in one launch
+        ref2 = torch.nn.functional.conv2d(a1, L2.conv.weight.double(), L2.conv.bias.double(), padding=1)
+        assert rel(K._UnpackOut.apply(y2, 128), ref2) < 1e-4
+
+
+def stock_losses(netD, real, fake, pt, gp_w=10.0):
+    pr, pf = netD(real), netD(fake)
+    interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
+    crit = netD(interp)
+    g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
+    gp = gp_w * ((g.reshape(g.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
+    return pr, pf, gp, g
+
+
+@pytest.mark.parametrize('size,batch', [(64, 4), (128, 2)])
+def test_critic_matches_the_torch_module_to_second_order(size, batch):
+    from esr_hip import critic as K
+    netD = make_D(size)
+    eng = K.CriticEngine(netD, 'split')
+    real, fake = seeded_uniform((batch, 3, size, size), 11).cuda(), seeded_uniform((batch, 3, size, size), 12).cuda()
+    pt = seeded_uniform((batch, 1, 1, 1), 13).cuda()
+    params = list(netD.parameters())
+    run_stock = lambda x: netD(x)
+    run_hip = lambda x: K.critic_forward(eng, x)
+
+    def step(run):
+        for p in params:
+            p.grad = None
+        for m in netD.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        pr, pf = run(real), run(fake)
+        interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
+        crit = run(interp)
+        with K.input_grad_only():
+            g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
+        gp = 10.0 * ((g.reshape(g.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
+        loss = pf.mean() - pr.mean() + gp
+        loss.backward()
+        return (pr.detach().clone(), pf.detach().clone(), g.detach().clone(), gp.detach().clone(), [p.grad.clone() for p in params],
+                netD.features[3].running_mean.clone(), netD.features[3].running_var.clone())
+    ref = step(run_stock)
+    got = step(run_hip)
+    assert rel(got[0], ref[0]) < 1e-3 and rel(got[1], ref[1]) < 1e-3                  # logits
+    assert rel(got[2], ref[2]) < 2e-3                                                 # d critic / d input (first-order backward)
+    assert abs(float(got[3]) - float(ref[3])) < 2e-3 * abs(float(ref[3]))            # the penalty
+    worst = 0.0
+    scale = max(float(g.norm()) for g in ref[4])
+    for (name, _), a, b in zip(netD.named_parameters(), got[4], ref[4]):
+        err = float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-3 * scale)
+        worst = max(worst, err)
+        assert err < 5e-3, (name, err, float(b.norm()))
+    torch.testing.assert_close(got[5], ref[5], rtol=1e-3, atol=1e-5)                  # running statistics: three calls, in order
+    torch.testing.assert_close(got[6], ref[6], rtol=1e-3, atol=1e-6)
+    print('worst parameter-gradient error (incl. the double backward): %.2e' % worst)
+
+
+def test_critic_first_order_input_gradient_for_the_generator_step():
+    """The GAN term of the G step: d(-mean critic(fake)) / d fake with the critic's parameters frozen (SRRaGAN_model.py:462-472)."""
+    from esr_hip import critic as K
+    netD = make_D(64)
+    eng = K.CriticEngine(netD, 'split')
+    for p in netD.parameters():
+        p.requires_grad_(False)
+    fake = seeded_uniform((4, 3, 64, 64), 21).cuda()
+    fa, fb = fake.clone().requires_grad_(True), fake.clone().requires_grad_(True)
+    (-netD(fa).mean()).backward()
+    (-K.critic_forward(eng, fb).mean()).backward()
+    assert rel(fb.grad, fa.grad) < 2e-3
+
+
+def test_critic_eval_mode_uses_running_statistics():
+    from esr_hip import critic as K
+    netD = make_D(64)
+    eng = K.CriticEngine(netD, 'split')
+    x = seeded_uniform((2, 3, 64, 64), 31).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            netD(seeded_uniform((4, 3, 64, 64), 32).cuda())          # move the running statistics away from (0, 1)
+        netD.eval()
+        assert rel(K.critic_forward(eng, x), netD(x)) < 1e-3
+
+
+def test_bf16_critic_tracks_the_fp32_class_one():
+    from esr_hip import critic as K
+    netD = make_D(64)
+    eng = K.CriticEngine(netD, 'split')
+    x = seeded_uniform((4, 3, 64, 64), 41).cuda()
+    with torch.no_grad():
+        a = K.critic_forward(eng, x)
+        for m in netD.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        eng.set_precision('bf16')
+        b = K.critic_forward(eng, x)
+    assert rel(b, a) < 5e-2
