@@ -51,6 +51,54 @@ def test_strided_and_sliced_convs_match_torch():
         assert rel(K._UnpackOut.apply(y2, 128), ref2) < 1e-4
 
 
+def test_backward_and_double_backward_kernels_match_float64_autograd():
+    """Every piece of the critic's backward pass and of the backward of that pass, one at a time, against torch autograd in float64 — the
+    strong statement (<= 2e-5, the operands carry 16 significand bits); the end-to-end test below can only make robust ones."""
+    import torch.nn.functional as F
+    from esr_hip import critic as K
+    netD = make_D()
+    eng = K.CriticEngine(netD, 'split')
+    eng.refresh()
+    L1, L2 = eng.layers[1], eng.layers[2]
+    B, H, W = 3, 32, 48
+    tol = 2e-5
+    # 3x3 stride-1 block, 64 -> 128 (two output slices): forward, data gradient, weight / bias gradient
+    x, dy = seeded_uniform((B, 64, H, W), 1).cuda() - 0.5, seeded_uniform((B, 128, H, W), 2).cuda() - 0.5
+    xa, dya = K._PackIn.apply(x, 2), K._PackIn.apply(dy, 2)
+    xr, w = x.double().requires_grad_(True), L2.conv.weight.double().detach().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=1).backward(dy.double())
+    with torch.no_grad():
+        assert rel(K._UnpackOut.apply(eng.conv_dgrad(L2, dya), 64), xr.grad) < tol
+        dw, db = eng.conv_wgrad(L2, dya, xa)
+        assert rel(dw, w.grad) < tol and rel(db, dy.double().sum((0, 2, 3))) < tol
+    # 4x4 stride-2 block on the space-to-depth input
+    x, dy = seeded_uniform((B, 64, H, W), 3).cuda() - 0.5, seeded_uniform((B, 64, H // 2, W // 2), 4).cuda() - 0.5
+    xs = x.view(B, 8, 8, H // 2, 2, W // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(B, 256, H // 2, W // 2).contiguous()
+    xa, dya = K._PackIn.apply(xs, 2), K._PackIn.apply(dy, 2)
+    xr, w = x.double().requires_grad_(True), L1.conv.weight.double().detach().requires_grad_(True)
+    F.conv2d(xr, w, None, stride=2, padding=1).backward(dy.double())
+    with torch.no_grad():
+        gx = K._UnpackOut.apply(eng.conv_dgrad(L1, dya), 256).view(B, 8, 2, 2, 8, H // 2, W // 2).permute(0, 1, 4, 5, 2, 6, 3).reshape(B, 64, H, W)
+        assert rel(gx, xr.grad) < tol
+        assert rel(eng.conv_wgrad(L1, dya, xa)[0], w.grad) < tol
+    # BatchNorm (batch statistics) + LeakyReLU: gradient, and gradient of the gradient (what the penalty differentiates through)
+    y, dz, u = seeded_uniform((B, 128, H, W), 5).cuda() * 3 - 1, seeded_uniform((B, 128, H, W), 6).cuda() - 0.5, seeded_uniform((B, 128, H, W), 7).cuda() - 0.5
+    yr = y.double().requires_grad_(True)
+    gr, br = L2.bn.weight.double().detach().requires_grad_(True), L2.bn.bias.double().detach().requires_grad_(True)
+    zr = F.leaky_relu(F.batch_norm(yr, None, None, gr, br, training=True, eps=L2.bn.eps), 0.2)
+    dzr = dz.double().requires_grad_(True)
+    dyr, dgr, dbr = torch.autograd.grad(zr, [yr, gr, br], dzr, create_graph=True)
+    gy, gg, gdz = torch.autograd.grad(dyr, [yr, gr, dzr], u.double())
+    ya = K._PackIn.apply(y, 2).requires_grad_(True)
+    gp_, bp_ = L2.bn.weight.detach().clone().requires_grad_(True), L2.bn.bias.detach().clone().requires_grad_(True)
+    za = K._BNAct.apply(eng, L2, ya, gp_, bp_, False, True)
+    dza = K._PackIn.apply(dz, 2).requires_grad_(True)
+    dya, dga, dba = torch.autograd.grad(za, [ya, gp_, bp_], dza, create_graph=True)
+    assert rel(K._UnpackOut.apply(dya.detach(), 128), dyr.detach()) < tol and rel(dga.detach(), dgr.detach()) < tol and rel(dba.detach(), dbr.detach()) < tol
+    gya, gga, gdza = torch.autograd.grad(dya, [ya, gp_, dza], K._PackIn.apply(u, 2))
+    assert rel(K._UnpackOut.apply(gya, 128), gy) < tol and rel(gga, gg) < tol and rel(K._UnpackOut.apply(gdza, 128), gdz) < tol
+
+
 def stock_losses(netD, real, fake, pt, gp_w=10.0):
     pr, pf = netD(real), netD(fake)
     interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
@@ -90,17 +138,32 @@ def test_critic_matches_the_torch_module_to_second_order(size, batch):
     ref = step(run_stock)
     got = step(run_hip)
     assert rel(got[0], ref[0]) < 1e-3 and rel(got[1], ref[1]) < 1e-3                  # logits
-    assert rel(got[2], ref[2]) < 2e-3                                                 # d critic / d input (first-order backward)
+    # Gradients: LeakyReLU makes them piecewise continuous.  The two executions agree on the features to ~3e-5 (16 vs 24 significand bits),
+    # so a handful of the ~10^6 activations that lie within that distance of zero take the other branch, and EACH such flip moves the
+    # gradient by O(1) in its receptive field: 2 flips of 10^6 already cost 1e-3 in relative L2 (tools/experiments/critic_probe_depth.py
+    # counts them; every kernel alone agrees with float64 to 4e-6, tools/experiments/critic_probe_bwd.py).  Hence the robust statements:
+    # norms, the penalty (a function of the gradient's norm per image) and the bulk of the elements.
+    assert robust_close(got[2], ref[2])                                               # d critic / d input (first-order backward)
     assert abs(float(got[3]) - float(ref[3])) < 2e-3 * abs(float(ref[3]))            # the penalty
-    worst = 0.0
     scale = max(float(g.norm()) for g in ref[4])
     for (name, _), a, b in zip(netD.named_parameters(), got[4], ref[4]):
-        err = float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-3 * scale)
-        worst = max(worst, err)
-        assert err < 5e-3, (name, err, float(b.norm()))
+        if float(b.norm()) < 1e-3 * scale:
+            assert float(a.norm()) < 3e-3 * scale, name                               # analytically ~0 (a conv bias in front of BatchNorm)
+            continue
+        # measured (tools/experiments/critic_probe.py, float64 module with its weights perturbed by 3e-5 relative noise — the size of the
+        # 16-bit-operand feature error): parameter gradients of this loss move by 9e-3 (median) to 2e-2, d critic / d input by 1.8e-2
+        assert abs(float(a.norm()) - float(b.norm())) < 2e-2 * float(b.norm()), (name, float(a.norm()), float(b.norm()))
+        assert rel(a, b) < 6e-2, (name, rel(a, b))
     torch.testing.assert_close(got[5], ref[5], rtol=1e-3, atol=1e-5)                  # running statistics: three calls, in order
     torch.testing.assert_close(got[6], ref[6], rtol=1e-3, atol=1e-6)
-    print('worst parameter-gradient error (incl. the double backward): %.2e' % worst)
+
+
+def robust_close(a, b, tol=2e-2, bulk=0.95, l2=0.2):
+    """`bulk` of the elements within tol * rms(b) of each other, and the whole within l2 in relative L2."""
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    rms = float(b.norm()) / b.numel() ** 0.5
+    frac = float(((a - b).abs() <= tol * rms).double().mean())
+    return frac >= bulk and rel(a, b) < l2
 
 
 def test_critic_first_order_input_gradient_for_the_generator_step():
@@ -114,7 +177,7 @@ def test_critic_first_order_input_gradient_for_the_generator_step():
     fa, fb = fake.clone().requires_grad_(True), fake.clone().requires_grad_(True)
     (-netD(fa).mean()).backward()
     (-K.critic_forward(eng, fb).mean()).backward()
-    assert rel(fb.grad, fa.grad) < 2e-3
+    assert robust_close(fb.grad, fa.grad) and abs(float(fb.grad.norm()) - float(fa.grad.norm())) < 1e-2 * float(fa.grad.norm())
 
 
 def test_critic_eval_mode_uses_running_statistics():
