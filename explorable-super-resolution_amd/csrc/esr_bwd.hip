@@ -334,6 +334,7 @@ struct WgradArgs {
     float* dw;
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
+    int tapmask[4];            // taps accumulated for main input tile i: tapmask[i & 3] (esr_wgrad_desc.tap_masks; 0x1FF = all)
 };
 #ifdef ESR_TRACE
 // debug build only (make trace): per-workgroup phase stamps of the weight-gradient kernels, 64 slots per workgroup — [0] HW_ID, [1] stamps used,
@@ -385,6 +386,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cit = group / a.mt, cot = group % a.mt;            // input-channel tile, output-channel tile
     const bool lat_tile = cit >= a.ncit_main;
+    const int tmask = lat_tile ? 0x1FF : a.tapmask[cit & 3];     // uniform
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     constexpr int STAGE = NPL * (WG_X_BYTES + WG_Y_BYTES);       // [X hi | X lo | dY hi | dY lo], 4 group planes each
     constexpr int NX = NPL * XSLOTS, NY = NPL * YSLOTS;          // DMA instructions per wave per tile: 12 + 8 (6 + 4 without lo)
@@ -499,6 +501,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                 }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
+                    if (!((tmask >> t) & 1)) continue;           // structurally zero block of the weights (uniform branch)
                     uint4 fb[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
@@ -673,6 +676,7 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     a.dw = d->dw;
     a.db = d->db;
     a.ws = ws;
+    for (int i = 0; i < 4; ++i) a.tapmask[i] = d->tap_masks[i] ? (d->tap_masks[i] & 0x1FF) : 0x1FF;
     return a;
 }
 

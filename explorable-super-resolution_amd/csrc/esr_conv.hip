@@ -115,6 +115,10 @@ struct ConvArgs {
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
     int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
     int nslices;                    // cout / 64 when cout > 64, else 1
+    // tap masks (TMASK kernels; esr_conv3x3_desc.tap_mask_k / tap_mask_m): structurally zero (tap, K chunk) / (tap, 32-row output tile) blocks
+    // of the weights are not multiplied — the 4x4 stride-2 convs of the critic run as 3x3 convs over the space-to-depth input, 16 of whose
+    // 36 (tap, parity) blocks are non-zero
+    int tmk[4], tmk_shift, tmm[4];
     long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
@@ -341,9 +345,9 @@ __device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const Con
 // The MFMAs of one chunk (2 channel groups x 9 taps) out of one LDS stage, with the fragment reads of tap t+1 interleaved between the
 // MFMAs of tap t (sched_barrier-pinned).  XLO: the chunk's activations have a lo plane.  Terms per product, in issue order:
 // Wlo*Xhi (if the weights have a lo plane), Whi*Xlo (if XLO), Whi*Xhi.
-template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP>
+template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP, bool TMASK = false>
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes,
-                                           u32x4 (&wa)[9 * MT], const uint4* wnext) {
+                                           u32x4 (&wa)[9 * MT], const uint4* wnext, const int (&tm)[MT]) {
     // wa / wnext (weights-in-registers kernels): wa holds this chunk's A fragments [tap][mtile]; once a tap's MFMAs are issued its slots are
     // refilled with the NEXT chunk's fragments from wnext (nullptr: last chunk) — in flight for the rest of this chunk's MFMA phase
     constexpr bool WREG = wreg_of(NPW);
@@ -394,7 +398,9 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
                 const int idx = ti + skip;                                    // index into the present-term list
                 const int term = (idx < has0) ? 0 : ((idx < has0 + has1) ? 1 : 2);
                 const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
-                if (WREG) acc[m][r] = mfma<FMT>(__builtin_bit_cast(uint4, wa[t * MT + m]), fb[cb][r][pb], acc[m][r]);
+                if (TMASK && !((tm[m] >> t) & 1)) {
+                    // (uniform) this tap's weights for M tile m are structurally zero
+                } else if (WREG) acc[m][r] = mfma<FMT>(__builtin_bit_cast(uint4, wa[t * MT + m]), fb[cb][r][pb], acc[m][r]);
                 else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
             }
             if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
@@ -418,7 +424,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 //             wait for the next one, waves 0-3 ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
 //             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
 //             placed), so only a second wave on the same SIMD can multiply meanwhile.
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, bool TMASK = false>
 __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
     // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
     // same staged input.  All workgroups of all slices are in flight together: a 512-channel layer on an 8x8 map is one launch of
@@ -478,6 +484,10 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
+    int tm_all[MT], tm_m[MT];                      // tap masks: all taps / this slice's M tiles (uniform)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { tm_all[m] = 0x1FF; tm_m[m] = TMASK ? a.tmm[(2 * (int)blockIdx.y + m) & 3] : 0x1FF; }
+    static_assert(!(TMASK && NST == 3), "no producer / consumer form of the tap-masked kernels");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
 #ifdef ESR_ABL_TERMS
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
                 wait_vm_upto(nstg == 3 ? ahead : 0);
             } else {
                 ESR_TR(); ESR_TR(); ESR_TR();
-                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr);
+                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr, tm_all);
                 if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
             }
             ESR_TR();
@@ -567,8 +577,11 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
 #pragma unroll
             for (int f = 0; f < 9 * MT; ++f) pin_frag(wa[f]);
         }
-        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa,
-                                                         (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr);
+        int tm[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) tm[m] = TMASK ? (a.tmk[(cp >> a.tmk_shift) & 3] & tm_m[m]) : 0x1FF;
+        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, TMASK>(acc, sa, sb, P, plane_bytes, wa,
+                                                                (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr, tm);
         if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
         ESR_TR();
         __syncthreads();
@@ -856,9 +869,9 @@ TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, bool TMASK = false>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMASK>;
     ESR_ALLOW_160K_LDS(k);
     const int nslices = a.wslice ? a.nslices : 1;
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
@@ -872,7 +885,7 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO>
+template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO, bool TMASK = false>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
@@ -880,12 +893,12 @@ int launch(const ConvArgs& a, hipStream_t s) {
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool small = ntiles <= 320;
 #if ESR_PC
-    if constexpr (!wreg_of(NPW)) {
+    if constexpr (!wreg_of(NPW) && !TMASK) {
         if (force == 3) return launch_nst<NPL, MT, EPI, 3, FMT, NPW, PARTLO>(a, s);
     }
 #endif
     const bool two = force ? force == 2 : small;
-    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO>(a, s);
+    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMASK>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMASK>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
@@ -1100,6 +1113,19 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     }
     if (split && d->out.hi && !d->out.lo) partlo = true;
     if (partlo && !f16) return ESR_E_UNSUPPORTED;                   // single-plane intermediates exist for the fp16 formats only
+    bool masked = false;
+    for (int i = 0; i < 4; ++i) {
+        a.tmk[i] = d->tap_mask_k[i] ? (d->tap_mask_k[i] & 0x1FF) : 0x1FF;
+        a.tmm[i] = d->tap_mask_m[i] ? (d->tap_mask_m[i] & 0x1FF) : 0x1FF;
+        masked = masked || a.tmk[i] != 0x1FF || a.tmm[i] != 0x1FF;
+    }
+    a.tmk_shift = d->tap_mask_k_shift;
+    if (masked) {
+        // the tap-masked kernels exist for the plain epilogue of the bf16 formats (what the critic launches)
+        if (epi != 0 || f16 || partlo || a.tmk_shift < 0 || a.tmk_shift > 8) return ESR_E_UNSUPPORTED;
+        if (split) return mt == 1 ? launch<2, 1, 0, 0, 2, false, true>(a, s) : launch<2, 2, 0, 0, 2, false, true>(a, s);
+        return mt == 1 ? launch<1, 1, 0, 0, 1, false, true>(a, s) : launch<1, 2, 0, 0, 1, false, true>(a, s);
+    }
     if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
     if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
     if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);

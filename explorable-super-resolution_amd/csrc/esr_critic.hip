@@ -13,7 +13,9 @@
 // A "group" is a run of B/groups consecutive images with its own batch statistics: several calls of the critic (real, fake, interpolated
 // batch) are executed as one launch while each keeps the statistics the reference's separate calls would give it.
 // s2d: the activation view is stored space-to-depth (factor 2): logical pixel (y, x) of channel group cg lives at pixel (y/2, x/2) of group
-// 4*cg + 2*(y&1) + (x&1) — the layout in which the following 4x4 stride-2 conv is a 3x3 stride-1 conv (esr_hip/critic.py).
+// 16*(cg/4) + 4*s + cg%4, s = 2*(y&1) + (x&1) — the layout in which the following 4x4 stride-2 conv is a 3x3 stride-1 conv (esr_hip/critic.py);
+// four consecutive groups (one 32-channel MFMA tile, two K chunks) share a parity, so that the zero blocks of that conv's weights are whole
+// (tap, chunk) / (tap, tile) blocks.  Kernels that produce a conv INPUT also write its one-pixel zero border (nobody else does).
 #include "esr_common.h"
 
 namespace {
@@ -28,7 +30,7 @@ static inline CView to_cview(const esr_act_view* v) {
 // offset of logical pixel (y, x) of group cg in image b;  S2D: see the header comment
 template <bool S2D>
 __device__ __forceinline__ long long voff(const CView& v, int b, int cg, int y, int x) {
-    if (S2D) return b * v.bs + (long long)(4 * cg + 2 * (y & 1) + (x & 1)) * v.cs + (long long)((y >> 1) + 1) * (v.W + 2) + ((x >> 1) + 1);
+    if (S2D) return b * v.bs + (long long)(16 * (cg >> 2) + 4 * (2 * (y & 1) + (x & 1)) + (cg & 3)) * v.cs + (long long)((y >> 1) + 1) * (v.W + 2) + ((x >> 1) + 1);
     return b * v.bs + (long long)cg * v.cs + (long long)(y + 1) * (v.W + 2) + (x + 1);
 }
 __device__ __forceinline__ void ld8(const CView& v, long long o, float* f) {
@@ -59,6 +61,18 @@ __device__ __forceinline__ void st8(const CView& v, long long o, const float* f)
     }
     v.hi[o] = make_uint4(vh[0] | (vh[1] << 16), vh[2] | (vh[3] << 16), vh[4] | (vh[5] << 16), vh[6] | (vh[7] << 16));
     if (v.lo) v.lo[o] = make_uint4(vl[0] | (vl[1] << 16), vl[2] | (vl[3] << 16), vl[4] | (vl[5] << 16), vl[6] | (vl[7] << 16));
+}
+
+// zero the border vectors adjacent to stored pixel (py, px) of the plane that offset `o` points into (py, px: 0-based interior coordinates of
+// the STORED plane of size Hs x Ws): the threads of the frame's neighbours cover the whole one-pixel border exactly once or twice
+__device__ __forceinline__ void zero_border(const CView& v, long long o, int py, int px, int Hs, int Ws) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const int P = v.W + 2;
+    auto put = [&](long long q) { v.hi[q] = z; if (v.lo) v.lo[q] = z; };
+    if (px == 0) put(o - 1);
+    if (px == Ws - 1) put(o + 1);
+    if (py == 0) { put(o - P); if (px == 0) put(o - P - 1); if (px == Ws - 1) put(o - P + 1); }
+    if (py == Hs - 1) { put(o + P); if (px == 0) put(o + P - 1); if (px == Ws - 1) put(o + P + 1); }
 }
 
 struct BnArgs {
@@ -180,9 +194,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
         o0[e] = ok ? m * gm * rs * uterm : 0.f;
         o1[e] = ok ? -gm * rs * rs * (xh * q + s2 * uterm + t2 * dterm) : 0.f;
     }
-    if (MODE == 0) st8(a.out0, voff<S2D>(a.out0, b, cg, yy, xx), o0);
-    else if (MODE == 1) st8(a.out0, voff<false>(a.out0, b, cg, yy, xx), o0);
-    else { st8(a.out0, voff<S2D>(a.out0, b, cg, yy, xx), o0); st8(a.out1, voff<false>(a.out1, b, cg, yy, xx), o1); }
+    // every result is the input of a conv (or weight-gradient) launch: write its zero border too
+    const long long os = voff<S2D>(a.out0, b, cg, yy, xx), op = voff<false>(MODE == 2 ? a.out1 : a.out0, b, cg, yy, xx);
+    if (MODE == 0 || MODE == 2) {
+        st8(a.out0, os, o0);
+        if (S2D) zero_border(a.out0, os, yy >> 1, xx >> 1, a.H / 2, a.W / 2);
+        else zero_border(a.out0, os, yy, xx, a.H, a.W);
+    }
+    if (MODE == 1) { st8(a.out0, op, o0); zero_border(a.out0, op, yy, xx, a.H, a.W); }
+    if (MODE == 2) { st8(a.out1, op, o1); zero_border(a.out1, op, yy, xx, a.H, a.W); }
 }
 
 // One thread per channel; the groups are processed in order (the running statistics see the calls in the order the reference makes them).

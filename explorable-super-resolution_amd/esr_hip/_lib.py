@@ -25,14 +25,15 @@ class Conv3x3Desc(C.Structure):
                 ('out', ActView), ('out2', ActView), ('out_nchw', C.c_void_p),
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
                 ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32),
-                ('pixel_shuffle', C.c_int32), ('ps_rowgroup0', C.c_int32)]
+                ('pixel_shuffle', C.c_int32), ('ps_rowgroup0', C.c_int32), ('tap_mask_k', C.c_int32 * 4), ('tap_mask_k_shift', C.c_int32),
+                ('tap_mask_m', C.c_int32 * 4)]
 
 
 class WgradDesc(C.Structure):
     """esr_wgrad_desc (include/esr_hip.h)."""
     _fields_ = [('dy', ActView), ('x', ActView), ('xlat', ActView), ('lat', C.c_int32), ('upsample', C.c_int32), ('cout', C.c_int32),
                 ('cin_main', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('alpha', C.c_float), ('dw', C.c_void_p),
-                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_floats', C.c_int64)]
+                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('tap_masks', C.c_int32 * 4)]
 
 
 class WgradBatchPlan(C.Structure):

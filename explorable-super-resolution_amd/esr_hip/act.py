@@ -466,7 +466,7 @@ def reset_launch_parity():
 
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
             out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0,
-            pixel_shuffle=0, ps_rowgroup0=0):
+            pixel_shuffle=0, ps_rowgroup0=0, tap_mask_k=None, tap_mask_k_shift=0, tap_mask_m=None):
     d = _lib.Conv3x3Desc()
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
@@ -495,6 +495,11 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
     d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
     d.in1_lo_groups = in1_lo_groups
     d.pixel_shuffle, d.ps_rowgroup0 = pixel_shuffle, ps_rowgroup0
+    if tap_mask_k is not None:
+        d.tap_mask_k[:] = tap_mask_k
+        d.tap_mask_k_shift = tap_mask_k_shift
+    if tap_mask_m is not None:
+        d.tap_mask_m[:] = tap_mask_m
     rec = _rec()
     if rec is not None:
         rec.emit(_lib.OP_CONV3X3, d, ('out_nchw',))
@@ -630,7 +635,7 @@ def conv3x3_dgrad_nchw(dy, weight, split=True):
     return dx
 
 
-def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device, out=None):
+def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device, out=None, tap_masks=None):
     """esr_wgrad_desc for one conv layer plus its zeroed outputs: returns (desc, dW [cout][cin][3][3], db [cout]).
     out = (dW, db): zeroed tensors to accumulate into (e.g. views of one flat buffer) instead of allocating two per layer."""
     cout, cin = wshape[0], wshape[1]
@@ -648,12 +653,14 @@ def wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device,
     d.B, d.H, d.W = B, H, W
     d.alpha = alpha
     d.dw, d.db = dw.data_ptr(), db.data_ptr()
+    if tap_masks is not None:
+        d.tap_masks[:] = tap_masks
     return d, dw, db
 
 
-def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device):
+def conv3x3_wgrad(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device, tap_masks=None):
     """Weight + bias gradient of one conv layer from act-layout operands (esr_conv3x3_wgrad): returns (dW [cout][cin][3][3], db [cout])."""
-    d, dw, db = wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device)
+    d, dw, db = wgrad_desc(dy, x_main, x_lat, lat, wshape, B, H, W, alpha, upsample, device, tap_masks=tap_masks)
     need = _lib.lib.esr_conv3x3_wgrad_workspace_floats(C.byref(d))
     check(min(need, 0), 'esr_conv3x3_wgrad_workspace_floats')
     ws = _wgrad_workspace(device, need)

@@ -40,7 +40,29 @@ class input_grad_only:
 
 # ------------------------------------------------------------------------------------------------ activation tensors
 def new_at(planes, B, ncg, H, W, device):
-    return torch.zeros(planes, B, ncg, H + 2, W + 2, 8, dtype=torch.bfloat16, device=device)
+    """Uninitialised: conv outputs and data gradients are only ever read at interior pixels; everything that becomes a conv (or weight-
+    gradient) INPUT is produced by pack_nchw or esr_bn_apply, which write the one-pixel zero border themselves."""
+    return torch.empty(planes, B, ncg, H + 2, W + 2, 8, dtype=torch.bfloat16, device=device)
+
+
+def _tap_masks():
+    """Per parity s = 2 py + px of the space-to-depth input: the taps (bit 3 ty + tx) of the embedded 3x3 weight that are non-zero — rows
+    ty in {1 - py, 2 - py}, columns tx in {1 - px, 2 - px} (module docstring: dy = 2 ty + py - 1) — and the same for the flipped taps of the
+    data-gradient pack (tap (2 - ty, 2 - tx))."""
+    fwd, flipped = [], []
+    for s in range(4):
+        py, px = s >> 1, s & 1
+        m = f = 0
+        for ty in (1 - py, 2 - py):
+            for tx in (1 - px, 2 - px):
+                m |= 1 << (3 * ty + tx)
+                f |= 1 << (3 * (2 - ty) + (2 - tx))
+        fwd.append(m)
+        flipped.append(f)
+    return fwd, flipped
+
+
+MASK_FWD, MASK_FLIPPED = _tap_masks()
 
 
 def view_of(t, cg0=0, ncg=None):
@@ -86,8 +108,8 @@ class CriticEngine:
                 raise EsrError('critic activation: LeakyReLU(0.2) after every conv block')
             i += 1
             L.cin, L.cout = conv.in_channels, conv.out_channels
-            if L.cout % 64 or (L.strided and L.cin % 8):
-                raise EsrError('critic widths: multiples of 64 output channels')
+            if L.cout % 64 or (L.strided and L.cin % 32):
+                raise EsrError('critic widths: multiples of 64 output channels (and of 32 input channels in front of a stride-2 conv)')
             L.index = len(self.layers)
             self.layers.append(L)
         if self.layers[0].strided or not getattr(netD, 'last_FC_layers', True):
@@ -109,14 +131,16 @@ class CriticEngine:
     @staticmethod
     def _embed_index(cout, cin, device):
         """Flat index into E [cout][4 cin][3][3] of every element of a 4x4 weight [cout][cin][4][4] (module docstring; channel order of
-        the space-to-depth input: (group g, parity s = 2 py + px, lane e) -> channel (4 g + s) * 8 + e, as esr_bn_apply stores it)."""
+        the space-to-depth input as esr_bn_apply stores it: group g, parity s = 2 py + px, lane e -> channel (16 (g // 4) + 4 s + g % 4) * 8
+        + e — four consecutive groups, i.e. one 32-channel MFMA tile, share a parity)."""
         co = torch.arange(cout, device=device).view(-1, 1, 1, 1)
         c = torch.arange(cin, device=device).view(1, -1, 1, 1)
         d = torch.arange(4, device=device)
         t, par = (d + 1) // 2, (d + 1) % 2            # dy = 2 ty + py - 1
         ty, py = t.view(1, 1, -1, 1), par.view(1, 1, -1, 1)
         tx, px = t.view(1, 1, 1, -1), par.view(1, 1, 1, -1)
-        ch = ((c // 8) * 4 + py * 2 + px) * 8 + c % 8
+        g = c // 8
+        ch = ((g // 4) * 16 + (py * 2 + px) * 4 + g % 4) * 8 + c % 8
         return (((co * (4 * cin) + ch) * 3 + ty) * 3 + tx).reshape(-1)
 
     def _build_packs(self, L):
@@ -174,18 +198,21 @@ class CriticEngine:
     def conv_fwd(self, L, x, use_bias=True):
         P, B, _, Hp, Wp, _ = x.shape
         y = new_at(P, B, L.cout // 8, Hp - 2, Wp - 2, x.device)
-        A.conv3x3(L.fwd, view_of(x), B, Hp - 2, Wp - 2, L.cout, out=view_of(y), use_bias=use_bias, reverse=False)
+        kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if L.strided else {}      # chunk cp = group pair: parity of quad cp >> 1
+        A.conv3x3(L.fwd, view_of(x), B, Hp - 2, Wp - 2, L.cout, out=view_of(y), use_bias=use_bias, reverse=False, **kw)
         return y
 
     def conv_dgrad(self, L, dy):
         P, B, _, Hp, Wp, _ = dy.shape
         dx = new_at(P, B, (L.cin_e + 7) // 8, Hp - 2, Wp - 2, dy.device)
-        A.conv3x3(L.tr, view_of(dy), B, Hp - 2, Wp - 2, L.cin_e, out=view_of(dx), use_bias=False, reverse=False)
+        kw = dict(tap_mask_m=MASK_FLIPPED) if L.strided else {}                     # 32-row output tile j = input quad j
+        A.conv3x3(L.tr, view_of(dy), B, Hp - 2, Wp - 2, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
         return dx
 
     def conv_wgrad(self, L, dy, x):
         P, B, _, Hp, Wp, _ = dy.shape
-        dw, db = A.conv3x3_wgrad(view_of(dy), view_of(x), None, 0, (L.cout, L.cin_e, 3, 3), B, Hp - 2, Wp - 2, 1.0, 1, dy.device)
+        dw, db = A.conv3x3_wgrad(view_of(dy), view_of(x), None, 0, (L.cout, L.cin_e, 3, 3), B, Hp - 2, Wp - 2, 1.0, 1, dy.device,
+                                 tap_masks=MASK_FWD if L.strided else None)
         if L.strided:
             dw = dw.view(-1)[L.E_index].view(L.cout, L.cin, 4, 4)
         return dw, db
@@ -400,7 +427,7 @@ class _BNActBwd(torch.autograd.Function):
         yd, dzd, ud = y.detach(), dz.detach().contiguous(), u.detach().contiguous()
         P, B, CG, Hp, Wp, _ = yd.shape
         dev = yd.device
-        g_dz = torch.zeros_like(dzd)
+        g_dz = torch.empty_like(dzd)
         g_y = new_at(P, B, CG, Hp - 2, Wp - 2, dev)
         sums3 = g_gamma = None
         if not st.const:

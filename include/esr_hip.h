@@ -116,6 +116,14 @@ typedef struct {
      * ((g / r^2)*8 + row % 8) * r^2 + s.  The activation commutes with the shuffle and is applied before it.  0: plain store. */
     int32_t pixel_shuffle;
     int32_t ps_rowgroup0;
+    /* structurally sparse weights: 9-bit tap masks (bit 3*dy + dx of the tap as the pack stores it; 0 = all nine taps).  K chunk cp (the
+     * cp-th PAIR of input channel groups) multiplies only the taps of tap_mask_k[(cp >> tap_mask_k_shift) & 3]; the j-th 32-row tile of
+     * the output (j = 2 * slice + tile) only those of tap_mask_m[j & 3]; a (tap, chunk, tile) block outside either mask is skipped, i.e.
+     * treated as zero whatever the pack holds.  Used for the critic's 4x4 stride-2 convs (codes/models/modules/architecture.py:452-480),
+     * which run as 3x3 convs over the space-to-depth input with 16 non-zero blocks of 36 (esr_hip/critic.py); plain epilogue, bf16 formats. */
+    int32_t tap_mask_k[4];
+    int32_t tap_mask_k_shift;
+    int32_t tap_mask_m[4];
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
@@ -249,6 +257,9 @@ typedef struct {
     float* db;
     float* workspace;
     int64_t workspace_floats;
+    /* 9-bit tap masks (0 = all taps): the i-th 32-channel tile of the main input only accumulates the taps of tap_masks[i & 3]; dw entries of
+     * the other taps are left untouched (the structurally zero blocks of esr_conv3x3_desc.tap_mask_k) */
+    int32_t tap_masks[4];
 } esr_wgrad_desc;
 int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d);   /* depends on B, H, W, cout, cin_main, lat only; <0: bad argument */
 int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream);

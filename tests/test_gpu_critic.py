@@ -18,6 +18,17 @@ def make_D(size=64, gain=1.0):
     return netD.cuda().train()
 
 
+def s2d(x):
+    """NCHW -> the space-to-depth channel order of esr_bn_apply (csrc/esr_critic.hip): channel ((16 (g // 4) + 4 s + g % 4) * 8 + e)."""
+    B, Cc, H, W = x.shape
+    return x.view(B, Cc // 32, 4, 8, H // 2, 2, W // 2, 2).permute(0, 1, 5, 7, 2, 3, 4, 6).reshape(B, 4 * Cc, H // 2, W // 2).contiguous()
+
+
+def d2s(xs):
+    B, C4, H2, W2 = xs.shape
+    return xs.view(B, C4 // 128, 2, 2, 4, 8, H2, W2).permute(0, 1, 4, 5, 6, 2, 7, 3).reshape(B, C4 // 4, 2 * H2, 2 * W2)
+
+
 def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
@@ -73,12 +84,12 @@ def test_backward_and_double_backward_kernels_match_float64_autograd():
         assert rel(dw, w.grad) < tol and rel(db, dy.double().sum((0, 2, 3))) < tol
     # 4x4 stride-2 block on the space-to-depth input
     x, dy = seeded_uniform((B, 64, H, W), 3).cuda() - 0.5, seeded_uniform((B, 64, H // 2, W // 2), 4).cuda() - 0.5
-    xs = x.view(B, 8, 8, H // 2, 2, W // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(B, 256, H // 2, W // 2).contiguous()
+    xs = s2d(x)
     xa, dya = K._PackIn.apply(xs, 2), K._PackIn.apply(dy, 2)
     xr, w = x.double().requires_grad_(True), L1.conv.weight.double().detach().requires_grad_(True)
     F.conv2d(xr, w, None, stride=2, padding=1).backward(dy.double())
     with torch.no_grad():
-        gx = K._UnpackOut.apply(eng.conv_dgrad(L1, dya), 256).view(B, 8, 2, 2, 8, H // 2, W // 2).permute(0, 1, 4, 5, 2, 6, 3).reshape(B, 64, H, W)
+        gx = d2s(K._UnpackOut.apply(eng.conv_dgrad(L1, dya), 256))
         assert rel(gx, xr.grad) < tol
         assert rel(eng.conv_wgrad(L1, dya, xa)[0], w.grad) < tol
     # BatchNorm (batch statistics) + LeakyReLU: gradient, and gradient of the gradient (what the penalty differentiates through)
