@@ -380,7 +380,7 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
     }
 }
 
-template <int NPL, int NST, int FMT>
+template <int NPL, int NST, int FMT, bool TMASK = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,7 +501,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                 }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    if (!((tmask >> t) & 1)) continue;           // structurally zero block of the weights (uniform branch)
+                    if (TMASK && !((tmask >> t) & 1)) continue;  // structurally zero block of the weights (uniform branch; own instantiation:
+                                                                 // the branches cost the unmasked kernels their cross-tap scheduling)
                     uint4 fb[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
@@ -570,10 +571,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #undef ESR_WG_ISSUE
 #undef ESR_WTR
 
-template <int NPL, int NST, int FMT>
+template <int NPL, int NST, int FMT, bool TMASK = false>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    wgrad_body<NPL, NST, FMT>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
+    wgrad_body<NPL, NST, FMT, TMASK>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
 }
 
 // Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
@@ -748,6 +749,13 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     void (*k)(const WgradArgs) = f16 ? (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 1> : conv3x3_wgrad_kernel<1, 1, 1>)
                                : split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0> : conv3x3_wgrad_kernel<2, 1, 0>)
                                        : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0> : conv3x3_wgrad_kernel<1, 1, 0>);
+    bool masked = false;
+    for (int i = 0; i < 4; ++i) masked = masked || a.tapmask[i] != 0x1FF;
+    if (masked) {                                                 // bf16 formats (what the critic uses)
+        if (f16) return ESR_E_UNSUPPORTED;
+        k = split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0, true> : conv3x3_wgrad_kernel<2, 1, 0, true>)
+                  : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0, true> : conv3x3_wgrad_kernel<1, 1, 0, true>);
+    }
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1, nst), (hipStream_t)stream, a);

@@ -15,6 +15,7 @@ Each op is a torch.autograd.Function whose backward is built from the other Func
 through the backward pass with the same kernels: conv <-> data-gradient are each other's adjoint, the weight gradient is bilinear.
 The two Linear layers of the classifier stay on torch (rocBLAS): 51 MFLOP of the critic's 2.2 GFLOP per image."""
 import ctypes as C
+import os
 
 import torch
 
@@ -63,6 +64,8 @@ def _tap_masks():
 
 
 MASK_FWD, MASK_FLIPPED = _tap_masks()
+if os.environ.get('ESR_CRITIC_MASKS') == '0':          # experiments: multiply the structural zeros too (same results)
+    MASK_FWD = MASK_FLIPPED = None
 
 
 def view_of(t, cg0=0, ncg=None):
@@ -198,14 +201,14 @@ class CriticEngine:
     def conv_fwd(self, L, x, use_bias=True):
         P, B, _, Hp, Wp, _ = x.shape
         y = new_at(P, B, L.cout // 8, Hp - 2, Wp - 2, x.device)
-        kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if L.strided else {}      # chunk cp = group pair: parity of quad cp >> 1
+        kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}      # chunk cp = group pair: parity of quad cp >> 1
         A.conv3x3(L.fwd, view_of(x), B, Hp - 2, Wp - 2, L.cout, out=view_of(y), use_bias=use_bias, reverse=False, **kw)
         return y
 
     def conv_dgrad(self, L, dy):
         P, B, _, Hp, Wp, _ = dy.shape
         dx = new_at(P, B, (L.cin_e + 7) // 8, Hp - 2, Wp - 2, dy.device)
-        kw = dict(tap_mask_m=MASK_FLIPPED) if L.strided else {}                     # 32-row output tile j = input quad j
+        kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}                     # 32-row output tile j = input quad j
         A.conv3x3(L.tr, view_of(dy), B, Hp - 2, Wp - 2, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
         return dx
 
