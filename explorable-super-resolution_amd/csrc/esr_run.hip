@@ -33,6 +33,19 @@ extern "C" int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t str
             case ESR_OP_WGRAD_BATCH_RUN: rc = esr_conv3x3_wgrad_batch_run(c.u.wgrad_batch_run.workspace, &c.u.wgrad_batch_run.plan, stream); break;
             case ESR_OP_PACK_BATCH_RUN: rc = esr_pack_batch_run(c.u.pack_batch_run.workspace, c.u.pack_batch_run.n, c.u.pack_batch_run.nblocks, stream); break;
             case ESR_OP_ZERO: rc = esr_zero(c.u.zero.p, c.u.zero.n16, stream); break;
+            case ESR_OP_UNPACK_NCHW: rc = esr_unpack_nchw(&c.u.unpack_nchw.src, c.u.unpack_nchw.B, c.u.unpack_nchw.nc, c.u.unpack_nchw.dst, stream); break;
+            case ESR_OP_WGRAD: rc = esr_conv3x3_wgrad(&c.u.wgrad, stream); break;
+            case ESR_OP_BN_REDUCE: rc = esr_bn_reduce(&c.u.bn.d, c.u.bn.mode, c.u.bn.sums, stream); break;
+            case ESR_OP_BN_APPLY: rc = esr_bn_apply(&c.u.bn.d, c.u.bn.mode, stream); break;
+            case ESR_OP_BN_FINALIZE: {
+                const esr_cmd_bn_finalize& a = c.u.bn_finalize;
+                rc = esr_bn_finalize(a.sums, a.groups, a.C, a.n_per_group, a.eps, a.momentum, a.gamma, a.beta, a.mean, a.rstd, a.scale, a.shift, a.running_mean,
+                                     a.running_var, stream);
+            } break;
+            case ESR_OP_BN_PARAM_GRADS: {
+                const esr_cmd_bn_param_grads& a = c.u.bn_param_grads;
+                rc = esr_bn_param_grads(a.sums2, a.sums3, a.rstd, a.groups, a.C, a.n_per_group, a.dgamma, a.dbeta, a.g_gamma, stream);
+            } break;
             default: rc = ESR_E_ARG;
         }
         if (rc != ESR_OK) {

@@ -61,7 +61,7 @@ class AdamTensor(C.Structure):
 
 # ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
 OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
-    OP_PACK_BATCH_RUN, OP_ZERO = range(1, 11)
+    OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS = range(1, 17)
 
 
 class CmdPackNchw(C.Structure):
@@ -104,10 +104,30 @@ class CmdZero(C.Structure):
     _fields_ = [('p', C.c_void_p), ('n16', C.c_int64)]
 
 
+class CmdUnpackNchw(C.Structure):
+    _fields_ = [('src', ActView), ('B', C.c_int32), ('nc', C.c_int32), ('dst', C.c_void_p)]
+
+
+class CmdBn(C.Structure):
+    _fields_ = [('d', BnDesc), ('mode', C.c_int32), ('sums', C.c_void_p)]
+
+
+class CmdBnFinalize(C.Structure):
+    _fields_ = [('sums', C.c_void_p), ('groups', C.c_int32), ('C', C.c_int32), ('n_per_group', C.c_int64), ('eps', C.c_float), ('momentum', C.c_float),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p)]
+
+
+class CmdBnParamGrads(C.Structure):
+    _fields_ = [('sums2', C.c_void_p), ('sums3', C.c_void_p), ('rstd', C.c_void_p), ('groups', C.c_int32), ('C', C.c_int32), ('n_per_group', C.c_int64),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('g_gamma', C.c_void_p)]
+
+
 class CmdUnion(C.Union):
     _fields_ = [('conv', Conv3x3Desc), ('pack_nchw', CmdPackNchw), ('unpack_grad_nchw', CmdUnpackGradNchw), ('act_combine', CmdActCombine),
                 ('pixel_unshuffle', CmdPixelUnshuffle), ('grad_absmax', CmdGradAbsmax), ('grad_scale', CmdGradScale),
-                ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero)]
+                ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero), ('unpack_nchw', CmdUnpackNchw),
+                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads)]
 
 
 class Cmd(C.Structure):
@@ -117,7 +137,8 @@ class Cmd(C.Structure):
 
 CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW: 'unpack_grad_nchw', OP_ACT_COMBINE: 'act_combine',
               OP_PIXEL_UNSHUFFLE: 'pixel_unshuffle', OP_GRAD_ABSMAX: 'grad_absmax', OP_GRAD_SCALE: 'grad_scale',
-              OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero'}
+              OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero', OP_UNPACK_NCHW: 'unpack_nchw',
+              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads'}
 
 
 _SIGS = {

@@ -119,6 +119,7 @@ class CriticEngine:
             raise EsrError('critic layout: a 3x3 first conv and the Linear classifier (num_2_strides = 5)')
         self._fp = None
         self._batch = A.PackBatch()
+        self._wgb = {}
         self.set_precision(precision)
 
     # ------------------------------------------------------------------ weights
@@ -463,4 +464,329 @@ def critic_forward(eng, x):
         gamma, beta = (L.bn.weight, L.bn.bias) if L.bn is not None else (None, None)
         t = _BNAct.apply(eng, L, y, gamma, beta, nxt_strided, training)
     feat = _UnpackOut.apply(t, eng.layers[-1].cout)
+    return net.classifier(feat.reshape(feat.size(0), -1))
+
+
+# ================================================================================================ fused passes
+# The per-layer Functions above are the readable definition (and what the tests check piece by piece against float64).  Executed that way
+# a critic step is ~700 Python-level operations (autograd nodes, FFI calls, allocations) and host-bound: 12 ms of host work for 10 ms of
+# kernels.  Below, each of the three passes — forward, backward, backward-of-backward — is ONE launch list (esr_run) over all ten blocks,
+# and the graph has two nodes: _CriticFwd (outputs: the features AND every block's pre-normalisation conv output y_l, so that cotangents
+# of the y_l can arrive) and _CriticBwd (the backward pass as a differentiable op of (d features, y_l, parameters)).  Same kernels, same
+# launch order, bit-identical results (tests/test_gpu_critic.py).
+class _Scratch:
+    """One zeroed device buffer per pass for the per-channel sums / statistics, handed out as raw pointers."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.base, self.off = self.buf.data_ptr(), 0
+
+    def take(self, nbytes):
+        p = self.base + self.off
+        self.off += (nbytes + 255) // 256 * 256
+        assert self.off <= self.buf.numel()
+        return p
+
+
+class _State:
+    pass
+
+
+def _desc(L, B, y, st, s2d, dz=None, u=None, out0=None, out1=None):
+    d = BnDesc()
+    d.y = view_of(y)
+    if dz is not None:
+        d.dz = view_of(dz)
+    if u is not None:
+        d.u = view_of(u)
+    if out0 is not None:
+        d.out0 = view_of(out0)
+    if out1 is not None:
+        d.out1 = view_of(out1)
+    d.B, d.groups, d.C = B, 1, L.cout
+    d.scale, d.shift, d.mean, d.rstd, d.gamma = st.scale, st.shift, st.mean, st.rstd, st.gamma
+    d.sums2, d.sums3 = st.sums2, st.sums3
+    d.slope, d.const_stats, d.s2d = SLOPE, 1 if st.const else 0, 1 if s2d else 0
+    return d
+
+
+def _emit_bn(rec, op, d, mode, sums=None):
+    rec.emit(op, _lib.CmdBn(d, mode, sums))
+
+
+def _fwd_pass(eng, x, training):
+    """-> (features fp32 [B, C, h, w], state).  One launch list: pack, then per block conv -> statistics -> normalise + activate."""
+    dev = x.device
+    x = x.float().contiguous()
+    B, Cin, H, W = x.shape
+    P = eng.planes
+    S = _State()
+    S.B, S.planes, S.training, S.in_shape = B, P, training, (B, Cin, H, W)
+    S.y, S.z, S.st, S.s2d = [], [], [], []
+    nstat = sum(L.cout for L in eng.layers if L.bn is not None)
+    S.scratch = _Scratch(nstat * (16 + 16) + 4096 * len(eng.layers), dev)
+    rec = A.Recorder({})
+    eval_keep = []
+    with A.recording(rec):
+        t = new_at(P, B, (Cin + 7) // 8, H, W, dev)
+        A.pack_nchw(x, view_of(t), 0, Cin)
+        S.t0 = t
+        h, w = H, W
+        tracked = []
+        for i, L in enumerate(eng.layers):
+            if L.strided:
+                h, w = h // 2, w // 2
+            y = new_at(P, B, L.cout // 8, h, w, dev)
+            kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
+            A.conv3x3(L.fwd, view_of(t), B, h, w, L.cout, out=view_of(y), reverse=False, **kw)
+            st = _Stats()
+            st.sums2 = st.sums3 = None
+            s2d = i + 1 < len(eng.layers) and eng.layers[i + 1].strided
+            if s2d and (h % 2 or w % 2):
+                raise EsrError('critic: odd feature-map size %dx%d in front of a stride-2 conv' % (h, w))
+            if L.bn is not None:
+                bn, Cc = L.bn, L.cout
+                st.gamma = bn.weight.data_ptr() if bn.weight is not None else None
+                if training:
+                    st.const = False
+                    sums = S.scratch.take(Cc * 16)
+                    st.mean, st.rstd, st.scale, st.shift = (S.scratch.take(Cc * 4) for _ in range(4))
+                    _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False), 0, sums)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(sums, 1, Cc, B * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1, st.gamma,
+                                                                     bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
+                                                                     bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None))
+                    if track and bn.num_batches_tracked is not None:
+                        tracked.append(bn.num_batches_tracked)
+                else:
+                    rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+                    g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(rstd)
+                    bt = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(rstd)
+                    sc = (g * rstd).contiguous()
+                    sh = (bt - sc * bn.running_mean.float()).contiguous()
+                    eval_keep += [sc, sh]
+                    st.scale, st.shift = sc.data_ptr(), sh.data_ptr()
+            ho, wo = (h // 2, w // 2) if s2d else (h, w)
+            z = new_at(P, B, (L.cout // 8) * (4 if s2d else 1), ho, wo, dev)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, s2d, out0=z), 0)
+            S.y.append(y); S.z.append(z); S.st.append(st); S.s2d.append(s2d)
+            t = z
+        Cl = eng.layers[-1].cout
+        feat = torch.empty(B, Cl, h, w, dtype=torch.float32, device=dev)
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, Cl, feat.data_ptr()))
+    rec.finish().run({})
+    S.keep = eval_keep
+    if tracked:
+        torch._foreach_add_(tracked, 1)
+    return feat, S
+
+
+def _wgrad_batch(eng, S, pairs, dev):
+    """Weight / bias gradients of all blocks in one launch (esr_conv3x3_wgrad_batch): pairs = [(layer, dy, x)].  Returns {layer index:
+    (dW in the parameter's shape, db)}."""
+    sizes = [L.cout * L.cin_e * 9 + L.cout for L, _, _ in pairs]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    descs, out, off = [], {}, 0
+    for (L, dy, xin), n in zip(pairs, sizes):
+        nw = L.cout * L.cin_e * 9
+        dw, db = flat[off:off + nw].view(L.cout, L.cin_e, 3, 3), flat[off + nw:off + n]
+        d, _, _ = A.wgrad_desc(view_of(dy), view_of(xin), None, 0, (L.cout, L.cin_e, 3, 3), S.B, dy.shape[3] - 2, dy.shape[4] - 2, 1.0, 1, dev, out=(dw, db))
+        descs.append(d)
+        out[L.index] = (dw, db)
+        off += n
+    A.conv3x3_wgrad_batch(descs, dev, cache=eng._wgb)
+    for L, _, _ in pairs:
+        if L.strided:
+            dw, db = out[L.index]
+            out[L.index] = (dw.reshape(-1)[L.E_index].view(L.cout, L.cin, 4, 4), db)
+    return out
+
+
+def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
+    """The backward pass as one launch list: per block (last to first) BatchNorm/LeakyReLU gradient -> [+ injected cotangent of y_l] -> data
+    gradient.  Saves dy_l / dz_l in the state (the double backward needs them).  -> (d input fp32 or None, {layer: (dW, db)}, {layer:
+    (dgamma, dbeta)})"""
+    dev = S.t0.device
+    B, P = S.B, S.planes
+    n = len(eng.layers)
+    S.dy, S.dz = [None] * n, [None] * n
+    bnl = [L for L in eng.layers if L.bn is not None and S.training]
+    scratch = _Scratch(sum(L.cout for L in bnl) * 16 + 4096 * n, dev)
+    pg = torch.empty(2 * sum(L.cout for L in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
+    pg_off, bn_grads = 0, {}
+    rec = A.Recorder({})
+    with A.recording(rec):
+        dz = torch.empty_like(S.z[-1])
+        if d_feat is None:
+            rec.emit(_lib.OP_ZERO, _lib.CmdZero(dz.data_ptr(), dz.numel() // 8))
+        else:
+            d_feat = d_feat.detach().float().contiguous()
+            A.pack_nchw(d_feat, view_of(dz), 0, d_feat.shape[1])
+        for i in reversed(range(n)):
+            L, st, y = eng.layers[i], S.st[i], S.y[i]
+            dy = torch.empty_like(y)
+            if not st.const:
+                st.sums2 = scratch.take(L.cout * 16)
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, S.s2d[i], dz=dz), 1, st.sums2)
+                if pg is not None:
+                    dg, db_ = pg[pg_off:pg_off + L.cout], pg[pg_off + L.cout:pg_off + 2 * L.cout]
+                    pg_off += 2 * L.cout
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, None, None, 1, L.cout, B * (y.shape[3] - 2) * (y.shape[4] - 2), dg.data_ptr(),
+                                                                          db_.data_ptr(), None))
+                    bn_grads[i] = (dg, db_)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, S.s2d[i], dz=dz, out0=dy), 1)
+            if g_ys is not None and g_ys[i] is not None:
+                gy = g_ys[i].detach().contiguous()
+                rec.keep.append(gy)
+                A.act_combine(view_of(dy), B, A_=view_of(dy), alpha=1.0, Bv=view_of(gy), beta=1.0, s=1)
+            S.dy[i], S.dz[i] = dy, dz
+            if i > 0 or want_dx:
+                xin = S.z[i - 1] if i > 0 else S.t0
+                dx = torch.empty_like(xin)
+                kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}
+                A.conv3x3(L.tr, view_of(dy), B, dy.shape[3] - 2, dy.shape[4] - 2, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
+                dz = dx
+        dx_in = None
+        if want_dx:
+            dx_in = torch.empty(S.in_shape, dtype=torch.float32, device=dev)
+            rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(dz), B, S.in_shape[1], dx_in.data_ptr()))
+    rec.finish().run({})
+    S.bwd_scratch = scratch
+    conv_grads = {}
+    if want_params:
+        conv_grads = _wgrad_batch(eng, S, [(L, S.dy[i], S.z[i - 1] if i > 0 else S.t0) for i, L in enumerate(eng.layers)], dev)
+    return dx_in, conv_grads, bn_grads
+
+
+def _bwd2_pass(eng, S, u, want_params):
+    """The backward of the backward pass (u: cotangent of d input), first block to last: per block conv of the incoming cotangent -> gradient
+    of the BatchNorm/LeakyReLU gradient.  -> (cotangent of d features, [cotangent of y_l], {layer: dW (second order)}, {layer: g_gamma})"""
+    dev = S.t0.device
+    B, P = S.B, S.planes
+    n = len(eng.layers)
+    bnl = [L for L in eng.layers if L.bn is not None and S.training]
+    scratch = _Scratch(sum(L.cout for L in bnl) * 24 + 4096 * n, dev)
+    gg_all = torch.empty(sum(L.cout for L in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
+    gg_off, g_gammas, g_ys, uts = 0, {}, [None] * n, []
+    rec = A.Recorder({})
+    with A.recording(rec):
+        ut = torch.empty_like(S.t0)
+        u = u.detach().float().contiguous()
+        A.pack_nchw(u, view_of(ut), 0, u.shape[1])
+        for i, L in enumerate(eng.layers):
+            st, y = S.st[i], S.y[i]
+            uts.append(ut)
+            gdy = torch.empty_like(y)
+            kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
+            A.conv3x3(L.fwd, view_of(ut), B, y.shape[3] - 2, y.shape[4] - 2, L.cout, out=view_of(gdy), use_bias=False, reverse=False, **kw)
+            if not st.const:
+                st.sums3 = scratch.take(L.cout * 24)
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, S.s2d[i], dz=S.dz[i], u=gdy), 2, st.sums3)
+                if gg_all is not None and L.bn.weight is not None:
+                    gg = gg_all[gg_off:gg_off + L.cout]
+                    gg_off += L.cout
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, st.sums3, st.rstd, 1, L.cout, B * (y.shape[3] - 2) * (y.shape[4] - 2), None, None,
+                                                                          gg.data_ptr()))
+                    g_gammas[i] = gg
+            g_dz = torch.empty_like(S.dz[i])
+            g_y = torch.empty_like(y)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, S.s2d[i], dz=S.dz[i], u=gdy, out0=g_dz, out1=g_y), 2)
+            rec.keep.append(gdy)
+            if not st.const:
+                g_ys[i] = g_y
+            ut = g_dz
+        g_dfeat = torch.empty(B, eng.layers[-1].cout, ut.shape[3] - 2, ut.shape[4] - 2, dtype=torch.float32, device=dev)
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(ut), B, eng.layers[-1].cout, g_dfeat.data_ptr()))
+    rec.finish().run({})
+    S.bwd2_scratch = scratch
+    conv2 = {}
+    if want_params:
+        conv2 = {k: v[0] for k, v in _wgrad_batch(eng, S, [(L, S.dy[i], uts[i]) for i, L in enumerate(eng.layers)], dev).items()}
+    return g_dfeat, g_ys, conv2, g_gammas
+
+
+def _param_list(eng):
+    """[(conv.weight, conv.bias, bn.weight or None, bn.bias or None)] flattened, None entries kept (positions are fixed: 4 per block)."""
+    out = []
+    for L in eng.layers:
+        out += [L.conv.weight, L.conv.bias, L.bn.weight if L.bn is not None else None, L.bn.bias if L.bn is not None else None]
+    return out
+
+
+class _CriticFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, training, x, *params):
+        ctx.set_materialize_grads(False)
+        feat, S = _fwd_pass(eng, x.detach(), training)
+        ctx.eng, ctx.S, ctx.np = eng, S, len(params)
+        outs = (feat,) + tuple(S.y)
+        ctx.save_for_backward(*[p for p in params if p is not None], *S.y)
+        ctx.pmask = [p is not None for p in params]
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_feat, *g_ys):
+        saved = list(ctx.saved_tensors)
+        nreal = sum(ctx.pmask)
+        it = iter(saved[:nreal])
+        params = [next(it) if m else None for m in ctx.pmask]
+        ys = saved[nreal:]
+        want_dx = ctx.needs_input_grad[2]
+        want_params = any(ctx.needs_input_grad[3:]) and not _state['input_grad_only']
+        outs = _CriticBwd.apply(ctx.eng, ctx.S, want_dx, want_params, d_feat, len(ys), *g_ys, *ys, *params)
+        dx, pgrads = outs[0], outs[1:]
+        return (None, None, dx) + tuple(g if (g is not None and ctx.needs_input_grad[3 + k]) else None for k, g in enumerate(pgrads))
+
+
+class _CriticBwd(torch.autograd.Function):
+    """(d input, parameter gradients) = backward pass of the critic, as a function of (d features, cotangents injected at the y_l, the y_l
+    themselves, the parameters): differentiable once more (WGAN-GP)."""
+
+    @staticmethod
+    def forward(ctx, eng, S, want_dx, want_params, d_feat, n, *rest):
+        ctx.set_materialize_grads(False)
+        g_ys, ys, params = rest[:n], rest[n:2 * n], rest[2 * n:]
+        dx, conv_grads, bn_grads = _bwd_pass(eng, S, d_feat, g_ys if any(g is not None for g in g_ys) else None, want_dx, want_params)
+        ctx.eng, ctx.S, ctx.n, ctx.nparams = eng, S, n, len(params)
+        ctx.had_dfeat = d_feat is not None
+        pg = []
+        for i, L in enumerate(eng.layers):
+            cw, cb = conv_grads.get(i, (None, None))
+            bg, bb = bn_grads.get(i, (None, None))
+            pg += [cw, cb, bg if L.bn is not None and L.bn.weight is not None else None, bb if L.bn is not None and L.bn.bias is not None else None]
+        ctx.mark_non_differentiable(*[g for g in pg if g is not None])
+        if dx is None:
+            dx = torch.zeros((), device=S.t0.device)          # placeholder output (never used: the input asked for no gradient)
+            ctx.mark_non_differentiable(dx)
+        return (dx,) + tuple(pg)
+
+    @staticmethod
+    def backward(ctx, u, *u_params):
+        n = ctx.n
+        if u is None:
+            return (None,) * (6 + 2 * n + ctx.nparams)
+        want_params = any(ctx.needs_input_grad[6 + 2 * n:]) and not _state['input_grad_only']
+        g_dfeat, g_ys, conv2, g_gammas = _bwd2_pass(ctx.eng, ctx.S, u, want_params)
+        pg = []
+        for i, L in enumerate(ctx.eng.layers):
+            pg += [conv2.get(i), None, g_gammas.get(i), None]
+        return (None, None, None, None, g_dfeat if ctx.had_dfeat else None, None) + (None,) * n + tuple(g_ys) + tuple(pg)
+
+
+FUSED = os.environ.get('ESR_CRITIC_FUSED', '1') != '0'
+_critic_forward_per_layer = critic_forward
+
+
+def critic_forward(eng, x):
+    """Logits [B, 1] of the critic for fp32 NCHW images `x`, differentiable to the order the WGAN-GP step needs.  Three launch lists per
+    forward / backward / double backward (ESR_CRITIC_FUSED=0: one autograd node and several FFI calls per layer — the same kernels)."""
+    if not FUSED:
+        return _critic_forward_per_layer(eng, x)
+    A.require_gpu(x, 'critic input')
+    net = eng.net
+    eng.refresh()
+    if x.shape[1] != eng.layers[0].cin:
+        raise EsrError('critic input: %d channels expected' % eng.layers[0].cin)
+    outs = _CriticFwd.apply(eng, net.training, x, *_param_list(eng))
+    feat = outs[0]
     return net.classifier(feat.reshape(feat.size(0), -1))

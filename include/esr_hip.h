@@ -288,47 +288,6 @@ int64_t esr_soft_hist_slabs(int64_t n);
 int esr_soft_hist_fwd(const float* v, int64_t n, int K, float lo, float hi, float T, float eps, double* partial, esr_stream_t stream);
 int esr_soft_hist_bwd(const float* v, int64_t n, int K, float lo, float hi, float T, float eps, const float* gh, float* gv, esr_stream_t stream);
 
-/* ---- launch lists: a whole pass of the generator with ONE call ----
- * The reference dispatches every layer from Python (RRDBNet.forward's module loop, codes/models/modules/architecture.py:278-302, and
- * autograd's node-by-node backward); a port that keeps one FFI call per launch pays ~19 us of host time for each of the ~1,100 launches
- * of a training step.  The launch plan of a pass is static per (network, shape, precision, buffer set): the caller records it ONCE as an
- * array of esr_cmd — each entry is the argument block of one of the entry points above — and replays it with esr_run; between replays it
- * only patches the few pointers that change from call to call (the NCHW input / output tensors).  esr_run enqueues the commands in
- * order on `stream` and stops at the first one that fails: the return value is that command's ESR_E_* code and *failed (if given) its
- * index; ESR_OK and -1 otherwise.  Nothing is copied or retained: descriptors are read during the call only. */
-enum {
-    ESR_OP_CONV3X3 = 1, ESR_OP_PACK_NCHW = 2, ESR_OP_UNPACK_GRAD_NCHW = 3, ESR_OP_ACT_COMBINE = 4, ESR_OP_PIXEL_UNSHUFFLE = 5,
-    ESR_OP_GRAD_ABSMAX = 6, ESR_OP_GRAD_SCALE = 7, ESR_OP_WGRAD_BATCH_RUN = 8, ESR_OP_PACK_BATCH_RUN = 9, ESR_OP_ZERO = 10
-};
-typedef struct { const float* src; int64_t src_batch_stride; int32_t B, C, h, w, c0, nc, pad, down; esr_act_view dst; } esr_cmd_pack_nchw;
-typedef struct { esr_act_view G; float* dst; int64_t dst_batch_stride; int32_t B, C, h, w, c0, nc, pad, down, accumulate; } esr_cmd_unpack_grad_nchw;
-/* A / Bv / mask with hi == NULL are absent (NULL in esr_act_combine) */
-typedef struct { esr_act_view A; float alpha; esr_act_view Bv; float beta; int32_t s; esr_act_view mask; float mask_slope; esr_act_view out; int32_t B; } esr_cmd_act_combine;
-typedef struct { esr_act_view src; int32_t r; esr_act_view dst; int32_t B; } esr_cmd_pixel_unshuffle;
-typedef struct { esr_act_view v; int32_t B; uint32_t* slot; } esr_cmd_grad_absmax;
-typedef struct { esr_act_view src, dst; int32_t B; const uint32_t* slot; int32_t exp; const float* scale_in; const float* scale_den; float* scale_out; } esr_cmd_grad_scale;
-typedef struct { const void* workspace; esr_wgrad_batch_plan plan; } esr_cmd_wgrad_batch_run;
-typedef struct { const void* workspace; int32_t n; int64_t nblocks; } esr_cmd_pack_batch_run;
-typedef struct { void* p; int64_t n16; } esr_cmd_zero;
-typedef struct {
-    int32_t op;              /* ESR_OP_* */
-    int32_t reserved;
-    union {
-        esr_conv3x3_desc conv;
-        esr_cmd_pack_nchw pack_nchw;
-        esr_cmd_unpack_grad_nchw unpack_grad_nchw;
-        esr_cmd_act_combine act_combine;
-        esr_cmd_pixel_unshuffle pixel_unshuffle;
-        esr_cmd_grad_absmax grad_absmax;
-        esr_cmd_grad_scale grad_scale;
-        esr_cmd_wgrad_batch_run wgrad_batch_run;
-        esr_cmd_pack_batch_run pack_batch_run;
-        esr_cmd_zero zero;
-    } u;
-} esr_cmd;
-int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);
-int64_t esr_cmd_bytes(void);       /* sizeof(esr_cmd): lets a binding check its struct layout */
-
 /* ---- Adam over many tensors in one launch ----
  * The reference steps both networks with torch.optim.Adam (codes/models/SRRaGAN_model.py:147-160: lr, betas, weight decay from the options);
  * torch's multi-tensor implementation costs ~4 ms of host time per step for the generator's 702 tensors.  Same update rule, same fp32
@@ -383,6 +342,59 @@ int esr_bn_finalize(const double* sums, int groups, int C, int64_t n_per_group, 
 /* dgamma[c] = sum_g sums2[g][c][1], dbeta[c] = sum_g sums2[g][c][0]; g_gamma (double backward; needs sums3, rstd) — any output may be NULL */
 int esr_bn_param_grads(const double* sums2, const double* sums3, const float* rstd, int groups, int C, int64_t n_per_group, float* dgamma, float* dbeta,
                        float* g_gamma, esr_stream_t stream);
+
+/* ---- launch lists: a whole pass of the generator with ONE call ----
+ * The reference dispatches every layer from Python (RRDBNet.forward's module loop, codes/models/modules/architecture.py:278-302, and
+ * autograd's node-by-node backward); a port that keeps one FFI call per launch pays ~19 us of host time for each of the ~1,100 launches
+ * of a training step.  The launch plan of a pass is static per (network, shape, precision, buffer set): the caller records it ONCE as an
+ * array of esr_cmd — each entry is the argument block of one of the entry points above — and replays it with esr_run; between replays it
+ * only patches the few pointers that change from call to call (the NCHW input / output tensors).  esr_run enqueues the commands in
+ * order on `stream` and stops at the first one that fails: the return value is that command's ESR_E_* code and *failed (if given) its
+ * index; ESR_OK and -1 otherwise.  Nothing is copied or retained: descriptors are read during the call only. */
+enum {
+    ESR_OP_CONV3X3 = 1, ESR_OP_PACK_NCHW = 2, ESR_OP_UNPACK_GRAD_NCHW = 3, ESR_OP_ACT_COMBINE = 4, ESR_OP_PIXEL_UNSHUFFLE = 5,
+    ESR_OP_GRAD_ABSMAX = 6, ESR_OP_GRAD_SCALE = 7, ESR_OP_WGRAD_BATCH_RUN = 8, ESR_OP_PACK_BATCH_RUN = 9, ESR_OP_ZERO = 10,
+    ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16
+};
+typedef struct { const float* src; int64_t src_batch_stride; int32_t B, C, h, w, c0, nc, pad, down; esr_act_view dst; } esr_cmd_pack_nchw;
+typedef struct { esr_act_view G; float* dst; int64_t dst_batch_stride; int32_t B, C, h, w, c0, nc, pad, down, accumulate; } esr_cmd_unpack_grad_nchw;
+/* A / Bv / mask with hi == NULL are absent (NULL in esr_act_combine) */
+typedef struct { esr_act_view A; float alpha; esr_act_view Bv; float beta; int32_t s; esr_act_view mask; float mask_slope; esr_act_view out; int32_t B; } esr_cmd_act_combine;
+typedef struct { esr_act_view src; int32_t r; esr_act_view dst; int32_t B; } esr_cmd_pixel_unshuffle;
+typedef struct { esr_act_view v; int32_t B; uint32_t* slot; } esr_cmd_grad_absmax;
+typedef struct { esr_act_view src, dst; int32_t B; const uint32_t* slot; int32_t exp; const float* scale_in; const float* scale_den; float* scale_out; } esr_cmd_grad_scale;
+typedef struct { const void* workspace; esr_wgrad_batch_plan plan; } esr_cmd_wgrad_batch_run;
+typedef struct { const void* workspace; int32_t n; int64_t nblocks; } esr_cmd_pack_batch_run;
+typedef struct { void* p; int64_t n16; } esr_cmd_zero;
+typedef struct { esr_act_view src; int32_t B, nc; float* dst; } esr_cmd_unpack_nchw;
+typedef struct { esr_bn_desc d; int32_t mode; double* sums; } esr_cmd_bn;                 /* esr_bn_reduce (sums) / esr_bn_apply */
+typedef struct { const double* sums; int32_t groups, C; int64_t n_per_group; float eps, momentum; const float* gamma; const float* beta;
+                 float* mean; float* rstd; float* scale; float* shift; float* running_mean; float* running_var; } esr_cmd_bn_finalize;
+typedef struct { const double* sums2; const double* sums3; const float* rstd; int32_t groups, C; int64_t n_per_group; float* dgamma; float* dbeta;
+                 float* g_gamma; } esr_cmd_bn_param_grads;
+typedef struct {
+    int32_t op;              /* ESR_OP_* */
+    int32_t reserved;
+    union {
+        esr_conv3x3_desc conv;
+        esr_cmd_pack_nchw pack_nchw;
+        esr_cmd_unpack_grad_nchw unpack_grad_nchw;
+        esr_cmd_act_combine act_combine;
+        esr_cmd_pixel_unshuffle pixel_unshuffle;
+        esr_cmd_grad_absmax grad_absmax;
+        esr_cmd_grad_scale grad_scale;
+        esr_cmd_wgrad_batch_run wgrad_batch_run;
+        esr_cmd_pack_batch_run pack_batch_run;
+        esr_cmd_zero zero;
+        esr_cmd_unpack_nchw unpack_nchw;
+        esr_wgrad_desc wgrad;
+        esr_cmd_bn bn;
+        esr_cmd_bn_finalize bn_finalize;
+        esr_cmd_bn_param_grads bn_param_grads;
+    } u;
+} esr_cmd;
+int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);
+int64_t esr_cmd_bytes(void);       /* sizeof(esr_cmd): lets a binding check its struct layout */
 
 int esr_version(void);
 

@@ -216,3 +216,45 @@ def test_bf16_critic_tracks_the_fp32_class_one():
         eng.set_precision('bf16')
         b = K.critic_forward(eng, x)
     assert rel(b, a) < 5e-2
+
+
+def test_fused_passes_equal_the_per_layer_graph_bit_for_bit(monkeypatch):
+    """Three launch lists (forward, backward, backward of the backward) against one autograd node per layer: same kernels in the same order,
+    so logits, the input gradient, the penalty and every parameter gradient of the WGAN-GP loss must be identical."""
+    from esr_hip import critic as K
+    netD = make_D(64)
+    eng = K.CriticEngine(netD, 'split')
+    real, fake = seeded_uniform((4, 3, 64, 64), 11).cuda(), seeded_uniform((4, 3, 64, 64), 12).cuda()
+    pt = seeded_uniform((4, 1, 1, 1), 13).cuda()
+    params = list(netD.parameters())
+
+    def step(fused):
+        monkeypatch.setattr(K, 'FUSED', fused)
+        for p in params:
+            p.grad = None
+        for m in netD.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        pr, pf = K.critic_forward(eng, real), K.critic_forward(eng, fake)
+        interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
+        crit = K.critic_forward(eng, interp)
+        with K.input_grad_only():
+            g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
+        gp = 10.0 * ((g.reshape(g.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
+        (pf.mean() - pr.mean() + gp).backward()
+        return [pr.detach().clone(), pf.detach().clone(), g.detach().clone(), gp.detach().clone()] + [p.grad.clone() for p in params] + \
+            [netD.features[3].running_var.clone(), netD.features[3].num_batches_tracked.clone()]
+    a, b = step(False), step(True)
+    names = ['pred_real', 'pred_fake', 'dD/dx', 'gp'] + [n for n, _ in netD.named_parameters()] + ['running_var', 'num_batches_tracked']
+    for name, u, v in zip(names, a, b):
+        assert torch.equal(u, v), (name, float((u.double() - v.double()).abs().max()))
+    # and the G step's use: input gradient with frozen parameters
+    for p in params:
+        p.requires_grad_(False)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(K, 'FUSED', fused)
+        f = fake.clone().requires_grad_(True)
+        (-K.critic_forward(eng, f).mean()).backward()
+        outs.append(f.grad.clone())
+    assert torch.equal(outs[0], outs[1])
