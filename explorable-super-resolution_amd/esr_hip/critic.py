@@ -16,6 +16,7 @@ through the backward pass with the same kernels: conv <-> data-gradient are each
 The two Linear layers of the classifier stay on torch (rocBLAS): 51 MFLOP of the critic's 2.2 GFLOP per image."""
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -120,6 +121,7 @@ class CriticEngine:
         self._fp = None
         self._batch = A.PackBatch()
         self._wgb = {}
+        self._free_sets = {}
         self.set_precision(precision)
 
     # ------------------------------------------------------------------ weights
@@ -129,6 +131,7 @@ class CriticEngine:
             return
         self.precision, self.planes, self.split = precision, (2 if precision == 'split' else 1), precision == 'split'
         self._fp = None
+        self._free_sets = {}
         for L in self.layers:
             L.fwd = L.tr = L.E = None
 
@@ -180,6 +183,15 @@ class CriticEngine:
             pk.wpack = buf_t[s * per_t:(s + 1) * per_t]
             L.tr_packs.append(pk)
         L.tr = _SlicedPack(buf_t, None, fmt)
+
+    def pointer_fingerprint(self):
+        """Everything a recorded launch list points at besides the buffer set: parameter / running-statistics storages and the weight packs."""
+        out = []
+        for L in self.layers:
+            out += [L.conv.bias.data_ptr(), L.fwd.wpack.data_ptr() if L.fwd is not None else 0, L.tr.wpack.data_ptr() if L.tr is not None else 0]
+            if L.bn is not None:
+                out += [t.data_ptr() if t is not None else 0 for t in (L.bn.weight, L.bn.bias, L.bn.running_mean, L.bn.running_var)]
+        return tuple(out)
 
     def refresh(self):
         """Weight packs follow the parameters (one batched re-pack launch when any conv weight changed)."""
@@ -471,21 +483,83 @@ def critic_forward(eng, x):
 # The per-layer Functions above are the readable definition (and what the tests check piece by piece against float64).  Executed that way
 # a critic step is ~700 Python-level operations (autograd nodes, FFI calls, allocations) and host-bound: 12 ms of host work for 10 ms of
 # kernels.  Below, each of the three passes — forward, backward, backward-of-backward — is ONE launch list (esr_run) over all ten blocks,
-# and the graph has two nodes: _CriticFwd (outputs: the features AND every block's pre-normalisation conv output y_l, so that cotangents
-# of the y_l can arrive) and _CriticBwd (the backward pass as a differentiable op of (d features, y_l, parameters)).  Same kernels, same
-# launch order, bit-identical results (tests/test_gpu_critic.py).
-class _Scratch:
-    """One zeroed device buffer per pass for the per-channel sums / statistics, handed out as raw pointers."""
+# recorded once per buffer set and replayed; the graph has two nodes: _CriticFwd (outputs: the features AND every block's
+# pre-normalisation conv output y_l, so that cotangents of the y_l can arrive) and _CriticBwd (the backward pass as a differentiable op of
+# (d features, y_l, parameters)).  Same kernels, same launch order as the per-layer graph; where two cotangents meet on one tensor
+# (second-order + first-order on y_l) they are added in fp32 here, as bf16 planes by autograd there.
+class _BufSet:
+    """Every activation / gradient buffer the three passes of ONE critic call use, for one input shape, plus the launch lists recorded over
+    them.  A call takes a free set from the engine (or makes one) and gives it back when its autograd graph is gone: steady state
+    allocates nothing and builds no descriptors."""
 
-    def __init__(self, nbytes, device):
-        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        self.base, self.off = self.buf.data_ptr(), 0
+    def __init__(self, eng, B, Cin, H, W, device):
+        P = eng.planes
+        self.key = (B, Cin, H, W, P)
+        self.B, self.in_shape, self.dev = B, (B, Cin, H, W), device
+        mk = lambda ncg, h, w: new_at(P, B, ncg, h, w, device)
+        self.t0, self.ut0, self.dx0 = mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W)
+        self.y, self.z, self.dy, self.gdy, self.g_y, self.dz, self.g_dz, self.s2d, self.hw = [], [], [], [], [], [], [], [], []
+        h, w = H, W
+        n = len(eng.layers)
+        for i, L in enumerate(eng.layers):
+            if L.strided:
+                if h % 2 or w % 2:
+                    raise EsrError('critic: odd feature-map size %dx%d in front of a stride-2 conv' % (h, w))
+                h, w = h // 2, w // 2
+            s2d = i + 1 < n and eng.layers[i + 1].strided
+            cg = L.cout // 8
+            zg, zh, zw = (cg * 4, h // 2, w // 2) if s2d else (cg, h, w)
+            self.y.append(mk(cg, h, w)); self.dy.append(mk(cg, h, w)); self.gdy.append(mk(cg, h, w)); self.g_y.append(mk(cg, h, w))
+            self.z.append(mk(zg, zh, zw)); self.dz.append(mk(zg, zh, zw)); self.g_dz.append(mk(zg, zh, zw))
+            self.s2d.append(s2d); self.hw.append((h, w))
+        self.feat_shape = (B, eng.layers[-1].cout, h, w)
+        # per-channel sums / statistics: [fwd: sums(2 doubles) mean rstd scale shift | bwd: sums2 | bwd2: sums3] per normalised block
+        self.st = []
+        off = 0
+        take = lambda nb: (off_box.__setitem__(0, off_box[0] + (nb + 255) // 256 * 256), off_box[0] - (nb + 255) // 256 * 256)[1]
+        off_box = [0]
+        lay = []
+        for L in eng.layers:
+            if L.bn is None:
+                lay.append(None)
+                continue
+            Cc = L.cout
+            lay.append(dict(sums=take(Cc * 16), mean=take(Cc * 4), rstd=take(Cc * 4), scale=take(Cc * 4), shift=take(Cc * 4)))
+        self.fwd_zero = (0, off_box[0])
+        b0 = off_box[0]
+        for L, d in zip(eng.layers, lay):
+            if d is not None:
+                d['sums2'] = take(L.cout * 16)
+        self.bwd_zero = (b0, off_box[0] - b0)
+        b1 = off_box[0]
+        for L, d in zip(eng.layers, lay):
+            if d is not None:
+                d['sums3'] = take(L.cout * 24)
+        self.bwd2_zero = (b1, off_box[0] - b1)
+        self.scratch = torch.zeros(max(off_box[0], 256), dtype=torch.uint8, device=device)
+        self.lay = lay
+        self.eval_affine = {}            # eval-mode BatchNorm: per block (scale, shift) tensors owned by the set (static addresses)
+        self.plans, self.plans_fp = {}, None
+        self.wg = {}
 
-    def take(self, nbytes):
-        p = self.base + self.off
-        self.off += (nbytes + 255) // 256 * 256
-        assert self.off <= self.buf.numel()
-        return p
+    def ptr(self, i, name):
+        return self.scratch.data_ptr() + self.lay[i][name]
+
+    def stats(self, eng, i, training):
+        L = eng.layers[i]
+        st = _Stats()
+        st.sums2 = st.sums3 = None
+        if L.bn is None:
+            return st
+        st.gamma = L.bn.weight.data_ptr() if L.bn.weight is not None else None
+        if training:
+            st.const = False
+            st.mean, st.rstd, st.scale, st.shift = (self.ptr(i, k) for k in ('mean', 'rstd', 'scale', 'shift'))
+            st.sums2, st.sums3 = self.ptr(i, 'sums2'), self.ptr(i, 'sums3')
+        else:
+            sc, sh = self.eval_affine[i]
+            st.scale, st.shift = sc.data_ptr(), sh.data_ptr()
+        return st
 
 
 class _State:
@@ -514,194 +588,242 @@ def _emit_bn(rec, op, d, mode, sums=None):
     rec.emit(op, _lib.CmdBn(d, mode, sums))
 
 
+def _zero_region(rec, bs, region):
+    off, nbytes = region
+    if nbytes:
+        rec.emit(_lib.OP_ZERO, _lib.CmdZero(bs.scratch.data_ptr() + off, nbytes // 16))
+
+
+def _acquire(eng, x):
+    B, Cin, H, W = x.shape
+    key = (B, Cin, H, W, eng.planes)
+    free = eng._free_sets.setdefault(key, [])
+    bs = free.pop() if free else _BufSet(eng, B, Cin, H, W, x.device)
+    fp = eng.pointer_fingerprint()
+    if bs.plans_fp != fp:
+        bs.plans, bs.plans_fp, bs.wg = {}, fp, {}
+    return bs
+
+
+def _release(eng, bs):
+    free = eng._free_sets.setdefault(bs.key, [])
+    if len(free) < 8:
+        free.append(bs)
+
+
+def _replay(bs, key, ext, build):
+    plan = bs.plans.get(key)
+    if plan is None:
+        rec = A.Recorder(ext)
+        with A.recording(rec):
+            build(rec)
+        plan = bs.plans[key] = rec.finish()
+    plan.run(ext)
+
+
 def _fwd_pass(eng, x, training):
     """-> (features fp32 [B, C, h, w], state).  One launch list: pack, then per block conv -> statistics -> normalise + activate."""
-    dev = x.device
     x = x.float().contiguous()
-    B, Cin, H, W = x.shape
-    P = eng.planes
+    bs = _acquire(eng, x)
+    B = bs.B
     S = _State()
-    S.B, S.planes, S.training, S.in_shape = B, P, training, (B, Cin, H, W)
-    S.y, S.z, S.st, S.s2d = [], [], [], []
-    nstat = sum(L.cout for L in eng.layers if L.bn is not None)
-    S.scratch = _Scratch(nstat * (16 + 16) + 4096 * len(eng.layers), dev)
-    rec = A.Recorder({})
-    eval_keep = []
-    with A.recording(rec):
-        t = new_at(P, B, (Cin + 7) // 8, H, W, dev)
-        A.pack_nchw(x, view_of(t), 0, Cin)
-        S.t0 = t
-        h, w = H, W
-        tracked = []
+    S.bs, S.training = bs, training
+    weakref.finalize(S, _release, eng, bs)
+    feat = torch.empty(bs.feat_shape, dtype=torch.float32, device=x.device)
+    tracked = []
+    if not training:
         for i, L in enumerate(eng.layers):
-            if L.strided:
-                h, w = h // 2, w // 2
-            y = new_at(P, B, L.cout // 8, h, w, dev)
+            if L.bn is None:
+                continue
+            bn = L.bn
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+            sc = (bn.weight.detach().float() if bn.weight is not None else torch.ones_like(rstd)) * rstd
+            sh = (bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(rstd)) - sc * bn.running_mean.float()
+            if i not in bs.eval_affine:
+                bs.eval_affine[i] = (torch.empty_like(sc), torch.empty_like(sh))
+            bs.eval_affine[i][0].copy_(sc); bs.eval_affine[i][1].copy_(sh)
+    else:
+        tracked = [L.bn.num_batches_tracked for L in eng.layers if L.bn is not None and L.bn.track_running_stats and L.bn.num_batches_tracked is not None]
+
+    def build(rec):
+        Cin = bs.in_shape[1]
+        _zero_region(rec, bs, bs.fwd_zero)
+        A.pack_nchw(x, view_of(bs.t0), 0, Cin)
+        t = bs.t0
+        for i, L in enumerate(eng.layers):
+            h, w = bs.hw[i]
+            y, z = bs.y[i], bs.z[i]
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
             A.conv3x3(L.fwd, view_of(t), B, h, w, L.cout, out=view_of(y), reverse=False, **kw)
-            st = _Stats()
-            st.sums2 = st.sums3 = None
-            s2d = i + 1 < len(eng.layers) and eng.layers[i + 1].strided
-            if s2d and (h % 2 or w % 2):
-                raise EsrError('critic: odd feature-map size %dx%d in front of a stride-2 conv' % (h, w))
-            if L.bn is not None:
-                bn, Cc = L.bn, L.cout
-                st.gamma = bn.weight.data_ptr() if bn.weight is not None else None
-                if training:
-                    st.const = False
-                    sums = S.scratch.take(Cc * 16)
-                    st.mean, st.rstd, st.scale, st.shift = (S.scratch.take(Cc * 4) for _ in range(4))
-                    _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False), 0, sums)
-                    track = bn.track_running_stats and bn.running_mean is not None
-                    rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(sums, 1, Cc, B * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1, st.gamma,
-                                                                     bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
-                                                                     bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None))
-                    if track and bn.num_batches_tracked is not None:
-                        tracked.append(bn.num_batches_tracked)
-                else:
-                    rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-                    g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(rstd)
-                    bt = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(rstd)
-                    sc = (g * rstd).contiguous()
-                    sh = (bt - sc * bn.running_mean.float()).contiguous()
-                    eval_keep += [sc, sh]
-                    st.scale, st.shift = sc.data_ptr(), sh.data_ptr()
-            ho, wo = (h // 2, w // 2) if s2d else (h, w)
-            z = new_at(P, B, (L.cout // 8) * (4 if s2d else 1), ho, wo, dev)
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, s2d, out0=z), 0)
-            S.y.append(y); S.z.append(z); S.st.append(st); S.s2d.append(s2d)
+            st = bs.stats(eng, i, training)
+            if L.bn is not None and training:
+                bn = L.bn
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False), 0, bs.ptr(i, 'sums'))
+                track = bn.track_running_stats and bn.running_mean is not None
+                rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(bs.ptr(i, 'sums'), 1, L.cout, B * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                                                 st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
+                                                                 bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None))
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], out0=z), 0)
             t = z
-        Cl = eng.layers[-1].cout
-        feat = torch.empty(B, Cl, h, w, dtype=torch.float32, device=dev)
-        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, Cl, feat.data_ptr()))
-    rec.finish().run({})
-    S.keep = eval_keep
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, bs.feat_shape[1], feat.data_ptr()), ('dst',))
+    _replay(bs, ('fwd', training), {'x': x, 'feat': feat}, build)
     if tracked:
         torch._foreach_add_(tracked, 1)
     return feat, S
 
 
-def _wgrad_batch(eng, S, pairs, dev):
-    """Weight / bias gradients of all blocks in one launch (esr_conv3x3_wgrad_batch): pairs = [(layer, dy, x)].  Returns {layer index:
-    (dW in the parameter's shape, db)}."""
-    sizes = [L.cout * L.cin_e * 9 + L.cout for L, _, _ in pairs]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-    descs, out, off = [], {}, 0
-    for (L, dy, xin), n in zip(pairs, sizes):
-        nw = L.cout * L.cin_e * 9
-        dw, db = flat[off:off + nw].view(L.cout, L.cin_e, 3, 3), flat[off + nw:off + n]
-        d, _, _ = A.wgrad_desc(view_of(dy), view_of(xin), None, 0, (L.cout, L.cin_e, 3, 3), S.B, dy.shape[3] - 2, dy.shape[4] - 2, 1.0, 1, dev, out=(dw, db))
-        descs.append(d)
-        out[L.index] = (dw, db)
-        off += n
-    A.conv3x3_wgrad_batch(descs, dev, cache=eng._wgb)
-    for L, _, _ in pairs:
-        if L.strided:
-            dw, db = out[L.index]
-            out[L.index] = (dw.reshape(-1)[L.E_index].view(L.cout, L.cin, 4, 4), db)
-    return out
+class _WgradSet:
+    """The weight-gradient launch of one pass kind over one buffer set: descriptors built once; per call a fresh zeroed flat dW buffer, the
+    table re-pointed only if its address moved (engine.WGrad.rebind's scheme)."""
+
+    def __init__(self, eng, bs, pairs):
+        self.eng, self.pairs = eng, pairs
+        self.sizes = [L.cout * L.cin_e * 9 + L.cout for L, _, _ in pairs]
+        self.n = sum(self.sizes)
+        flat = torch.zeros(self.n, dtype=torch.float32, device=bs.dev)
+        descs, off = [], 0
+        for (L, dy, xin), n in zip(pairs, self.sizes):
+            nw = L.cout * L.cin_e * 9
+            d, _, _ = A.wgrad_desc(view_of(dy), view_of(xin), None, 0, (L.cout, L.cin_e, 3, 3), bs.B, dy.shape[3] - 2, dy.shape[4] - 2, 1.0, 1, bs.dev,
+                                   out=(flat[off:off + nw], flat[off + nw:off + n]))
+            descs.append(d)
+            off += n
+        self.arr = (_lib.WgradDesc * len(descs))(*descs)
+        self.flat_ptr = flat.data_ptr()
+        need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self.arr, len(descs))
+        check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+        self.ws = torch.empty(int(need), dtype=torch.uint8, device=bs.dev)
+        self.plan = None
+        self._first = flat
+
+    def run(self):
+        """-> {layer index: (dW in the parameter's shape, db)}"""
+        flat, self._first = (self._first, None) if self._first is not None else (torch.zeros(self.n, dtype=torch.float32, device=self.ws.device), None)
+        delta = flat.data_ptr() - self.flat_ptr
+        if delta or self.plan is None:
+            for d in self.arr:
+                d.dw += delta
+                d.db += delta
+            self.flat_ptr += delta
+            self.plan = _lib.WgradBatchPlan()
+            check(_lib.lib.esr_conv3x3_wgrad_batch_upload(self.arr, len(self.arr), self.ws.data_ptr(), self.ws.numel(), C.byref(self.plan), A.stream_ptr()),
+                  'esr_conv3x3_wgrad_batch_upload')
+        check(_lib.lib.esr_conv3x3_wgrad_batch_run(self.ws.data_ptr(), C.byref(self.plan), A.stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
+        out, off = {}, 0
+        for (L, _, _), n in zip(self.pairs, self.sizes):
+            nw = L.cout * L.cin_e * 9
+            dw, db = flat[off:off + nw], flat[off + nw:off + n]
+            dw = dw[L.E_index].view(L.cout, L.cin, 4, 4) if L.strided else dw.view(L.cout, L.cin_e, 3, 3)
+            out[L.index] = (dw, db)
+            off += n
+        return out
 
 
 def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
     """The backward pass as one launch list: per block (last to first) BatchNorm/LeakyReLU gradient -> [+ injected cotangent of y_l] -> data
-    gradient.  Saves dy_l / dz_l in the state (the double backward needs them).  -> (d input fp32 or None, {layer: (dW, db)}, {layer:
+    gradient.  dy_l / dz_l stay in the buffer set (the double backward reads them).  -> (d input fp32 or None, {layer: (dW, db)}, {layer:
     (dgamma, dbeta)})"""
-    dev = S.t0.device
-    B, P = S.B, S.planes
-    n = len(eng.layers)
-    S.dy, S.dz = [None] * n, [None] * n
-    bnl = [L for L in eng.layers if L.bn is not None and S.training]
-    scratch = _Scratch(sum(L.cout for L in bnl) * 16 + 4096 * n, dev)
-    pg = torch.empty(2 * sum(L.cout for L in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
-    pg_off, bn_grads = 0, {}
-    rec = A.Recorder({})
-    with A.recording(rec):
-        dz = torch.empty_like(S.z[-1])
+    bs, training = S.bs, S.training
+    B, dev, n = bs.B, bs.dev, len(eng.layers)
+    bnl = [i for i, L in enumerate(eng.layers) if L.bn is not None and training]
+    pg = torch.empty(2 * sum(eng.layers[i].cout for i in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
+    inj = tuple(g is not None for g in g_ys) if g_ys is not None else (False,) * n
+    if g_ys is not None:
+        for i, g in enumerate(g_ys):         # the cotangents of the y_l come out of this set's own double-backward pass
+            if g is not None and g.data_ptr() != bs.g_y[i].data_ptr():
+                bs.g_y[i].copy_(g)
+    ext = {}
+    if d_feat is not None:
+        d_feat = d_feat.detach().float().contiguous()
+        ext['d_feat'] = d_feat
+    dx_in = torch.empty(bs.in_shape, dtype=torch.float32, device=dev) if want_dx else None
+    if dx_in is not None:
+        ext['dx_in'] = dx_in
+    if pg is not None:
+        ext['pg'] = pg
+    bn_grads, pg_off = {}, 0
+    for i in reversed(bnl):
+        if pg is not None:
+            c = eng.layers[i].cout
+            bn_grads[i] = (pg[pg_off:pg_off + c], pg[pg_off + c:pg_off + 2 * c])
+            pg_off += 2 * c
+
+    def build(rec):
+        _zero_region(rec, bs, bs.bwd_zero)
+        dz = bs.dz[n - 1]
         if d_feat is None:
             rec.emit(_lib.OP_ZERO, _lib.CmdZero(dz.data_ptr(), dz.numel() // 8))
         else:
-            d_feat = d_feat.detach().float().contiguous()
             A.pack_nchw(d_feat, view_of(dz), 0, d_feat.shape[1])
         for i in reversed(range(n)):
-            L, st, y = eng.layers[i], S.st[i], S.y[i]
-            dy = torch.empty_like(y)
+            L, y, dy, dz = eng.layers[i], bs.y[i], bs.dy[i], bs.dz[i]
+            h, w = bs.hw[i]
+            st = bs.stats(eng, i, training)
             if not st.const:
-                st.sums2 = scratch.take(L.cout * 16)
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, S.s2d[i], dz=dz), 1, st.sums2)
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=dz), 1, st.sums2)
                 if pg is not None:
-                    dg, db_ = pg[pg_off:pg_off + L.cout], pg[pg_off + L.cout:pg_off + 2 * L.cout]
-                    pg_off += 2 * L.cout
-                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, None, None, 1, L.cout, B * (y.shape[3] - 2) * (y.shape[4] - 2), dg.data_ptr(),
-                                                                          db_.data_ptr(), None))
-                    bn_grads[i] = (dg, db_)
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, S.s2d[i], dz=dz, out0=dy), 1)
-            if g_ys is not None and g_ys[i] is not None:
-                gy = g_ys[i].detach().contiguous()
-                rec.keep.append(gy)
-                A.act_combine(view_of(dy), B, A_=view_of(dy), alpha=1.0, Bv=view_of(gy), beta=1.0, s=1)
-            S.dy[i], S.dz[i] = dy, dz
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, None, None, 1, L.cout, B * h * w, bn_grads[i][0].data_ptr(),
+                                                                          bn_grads[i][1].data_ptr(), None), ('dgamma', 'dbeta'))
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=dz, out0=dy), 1)
+            if inj[i]:
+                A.act_combine(view_of(dy), B, A_=view_of(dy), alpha=1.0, Bv=view_of(bs.g_y[i]), beta=1.0, s=1)
             if i > 0 or want_dx:
-                xin = S.z[i - 1] if i > 0 else S.t0
-                dx = torch.empty_like(xin)
+                dx = bs.dz[i - 1] if i > 0 else bs.dx0
                 kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}
-                A.conv3x3(L.tr, view_of(dy), B, dy.shape[3] - 2, dy.shape[4] - 2, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
-                dz = dx
-        dx_in = None
+                A.conv3x3(L.tr, view_of(dy), B, h, w, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
         if want_dx:
-            dx_in = torch.empty(S.in_shape, dtype=torch.float32, device=dev)
-            rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(dz), B, S.in_shape[1], dx_in.data_ptr()))
-    rec.finish().run({})
-    S.bwd_scratch = scratch
+            rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(bs.dx0), B, bs.in_shape[1], dx_in.data_ptr()), ('dst',))
+    _replay(bs, ('bwd', training, d_feat is not None, inj, want_dx, pg is not None), ext, build)
     conv_grads = {}
     if want_params:
-        conv_grads = _wgrad_batch(eng, S, [(L, S.dy[i], S.z[i - 1] if i > 0 else S.t0) for i, L in enumerate(eng.layers)], dev)
+        if 'bwd' not in bs.wg:
+            bs.wg['bwd'] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.z[i - 1] if i > 0 else bs.t0) for i, L in enumerate(eng.layers)])
+        conv_grads = bs.wg['bwd'].run()
     return dx_in, conv_grads, bn_grads
 
 
 def _bwd2_pass(eng, S, u, want_params):
     """The backward of the backward pass (u: cotangent of d input), first block to last: per block conv of the incoming cotangent -> gradient
     of the BatchNorm/LeakyReLU gradient.  -> (cotangent of d features, [cotangent of y_l], {layer: dW (second order)}, {layer: g_gamma})"""
-    dev = S.t0.device
-    B, P = S.B, S.planes
-    n = len(eng.layers)
-    bnl = [L for L in eng.layers if L.bn is not None and S.training]
-    scratch = _Scratch(sum(L.cout for L in bnl) * 24 + 4096 * n, dev)
-    gg_all = torch.empty(sum(L.cout for L in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
-    gg_off, g_gammas, g_ys, uts = 0, {}, [None] * n, []
-    rec = A.Recorder({})
-    with A.recording(rec):
-        ut = torch.empty_like(S.t0)
-        u = u.detach().float().contiguous()
-        A.pack_nchw(u, view_of(ut), 0, u.shape[1])
+    bs, training = S.bs, S.training
+    B, dev, n = bs.B, bs.dev, len(eng.layers)
+    bnl = [i for i, L in enumerate(eng.layers) if L.bn is not None and training and L.bn.weight is not None]
+    gg_all = torch.empty(sum(eng.layers[i].cout for i in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
+    u = u.detach().float().contiguous()
+    g_dfeat = torch.empty(bs.feat_shape, dtype=torch.float32, device=dev)
+    ext = {'u': u, 'g_dfeat': g_dfeat}
+    g_gammas, off = {}, 0
+    if gg_all is not None:
+        ext['gg'] = gg_all
+        for i in bnl:
+            g_gammas[i] = gg_all[off:off + eng.layers[i].cout]
+            off += eng.layers[i].cout
+
+    def build(rec):
+        _zero_region(rec, bs, bs.bwd2_zero)
+        A.pack_nchw(u, view_of(bs.ut0), 0, u.shape[1])
+        ut = bs.ut0
         for i, L in enumerate(eng.layers):
-            st, y = S.st[i], S.y[i]
-            uts.append(ut)
-            gdy = torch.empty_like(y)
+            y, gdy = bs.y[i], bs.gdy[i]
+            h, w = bs.hw[i]
+            st = bs.stats(eng, i, training)
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
-            A.conv3x3(L.fwd, view_of(ut), B, y.shape[3] - 2, y.shape[4] - 2, L.cout, out=view_of(gdy), use_bias=False, reverse=False, **kw)
+            A.conv3x3(L.fwd, view_of(ut), B, h, w, L.cout, out=view_of(gdy), use_bias=False, reverse=False, **kw)
             if not st.const:
-                st.sums3 = scratch.take(L.cout * 24)
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, S.s2d[i], dz=S.dz[i], u=gdy), 2, st.sums3)
-                if gg_all is not None and L.bn.weight is not None:
-                    gg = gg_all[gg_off:gg_off + L.cout]
-                    gg_off += L.cout
-                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, st.sums3, st.rstd, 1, L.cout, B * (y.shape[3] - 2) * (y.shape[4] - 2), None, None,
-                                                                          gg.data_ptr()))
-                    g_gammas[i] = gg
-            g_dz = torch.empty_like(S.dz[i])
-            g_y = torch.empty_like(y)
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, S.s2d[i], dz=S.dz[i], u=gdy, out0=g_dz, out1=g_y), 2)
-            rec.keep.append(gdy)
-            if not st.const:
-                g_ys[i] = g_y
-            ut = g_dz
-        g_dfeat = torch.empty(B, eng.layers[-1].cout, ut.shape[3] - 2, ut.shape[4] - 2, dtype=torch.float32, device=dev)
-        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(ut), B, eng.layers[-1].cout, g_dfeat.data_ptr()))
-    rec.finish().run({})
-    S.bwd2_scratch = scratch
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy), 2, st.sums3)
+                if i in g_gammas:
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, st.sums3, st.rstd, 1, L.cout, B * h * w, None, None, g_gammas[i].data_ptr()),
+                             ('g_gamma',))
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy, out0=bs.g_dz[i], out1=bs.g_y[i]), 2)
+            ut = bs.g_dz[i]
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(ut), B, bs.feat_shape[1], g_dfeat.data_ptr()), ('dst',))
+    _replay(bs, ('bwd2', training, gg_all is not None), ext, build)
+    g_ys = [bs.g_y[i].detach() if (eng.layers[i].bn is not None and training) else None for i in range(n)]
     conv2 = {}
     if want_params:
-        conv2 = {k: v[0] for k, v in _wgrad_batch(eng, S, [(L, S.dy[i], uts[i]) for i, L in enumerate(eng.layers)], dev).items()}
+        if 'bwd2' not in bs.wg:
+            bs.wg['bwd2'] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.ut0 if i == 0 else bs.g_dz[i - 1]) for i, L in enumerate(eng.layers)])
+        conv2 = {k: v[0] for k, v in bs.wg['bwd2'].run().items()}
     return g_dfeat, g_ys, conv2, g_gammas
 
 
@@ -719,10 +841,10 @@ class _CriticFwd(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         feat, S = _fwd_pass(eng, x.detach(), training)
         ctx.eng, ctx.S, ctx.np = eng, S, len(params)
-        outs = (feat,) + tuple(S.y)
-        ctx.save_for_backward(*[p for p in params if p is not None], *S.y)
+        ys = tuple(y.detach() for y in S.bs.y)        # fresh tensor objects over the set's storage: autograd attaches its history to these
+        ctx.save_for_backward(*[p for p in params if p is not None], *ys)
         ctx.pmask = [p is not None for p in params]
-        return outs
+        return (feat,) + ys
 
     @staticmethod
     def backward(ctx, d_feat, *g_ys):
@@ -735,7 +857,7 @@ class _CriticFwd(torch.autograd.Function):
         want_params = any(ctx.needs_input_grad[3:]) and not _state['input_grad_only']
         outs = _CriticBwd.apply(ctx.eng, ctx.S, want_dx, want_params, d_feat, len(ys), *g_ys, *ys, *params)
         dx, pgrads = outs[0], outs[1:]
-        return (None, None, dx) + tuple(g if (g is not None and ctx.needs_input_grad[3 + k]) else None for k, g in enumerate(pgrads))
+        return (None, None, dx if want_dx else None) + tuple(g if (g is not None and ctx.needs_input_grad[3 + k]) else None for k, g in enumerate(pgrads))
 
 
 class _CriticBwd(torch.autograd.Function):
@@ -745,7 +867,7 @@ class _CriticBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, S, want_dx, want_params, d_feat, n, *rest):
         ctx.set_materialize_grads(False)
-        g_ys, ys, params = rest[:n], rest[n:2 * n], rest[2 * n:]
+        g_ys, params = rest[:n], rest[2 * n:]
         dx, conv_grads, bn_grads = _bwd_pass(eng, S, d_feat, g_ys if any(g is not None for g in g_ys) else None, want_dx, want_params)
         ctx.eng, ctx.S, ctx.n, ctx.nparams = eng, S, n, len(params)
         ctx.had_dfeat = d_feat is not None
@@ -756,7 +878,7 @@ class _CriticBwd(torch.autograd.Function):
             pg += [cw, cb, bg if L.bn is not None and L.bn.weight is not None else None, bb if L.bn is not None and L.bn.bias is not None else None]
         ctx.mark_non_differentiable(*[g for g in pg if g is not None])
         if dx is None:
-            dx = torch.zeros((), device=S.t0.device)          # placeholder output (never used: the input asked for no gradient)
+            dx = torch.zeros((), device=S.bs.dev)             # placeholder output (never used: the input asked for no gradient)
             ctx.mark_non_differentiable(dx)
         return (dx,) + tuple(pg)
 
