@@ -837,6 +837,24 @@ extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgra
     return ESR_OK;
 }
 
+namespace {
+__global__ void wgrad_rebase_kernel(WgradArgs* table, int n, long long delta_bytes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    table[i].dw = (float*)((char*)table[i].dw + delta_bytes);
+    if (table[i].db) table[i].db = (float*)((char*)table[i].db + delta_bytes);
+}
+}  // namespace
+
+extern "C" int esr_conv3x3_wgrad_batch_rebase(void* workspace, const esr_wgrad_batch_plan* plan, int64_t delta_bytes, esr_stream_t stream) {
+    if (!workspace || !plan || plan->n <= 0) return ESR_E_ARG;
+    if (delta_bytes == 0) return ESR_OK;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(wgrad_rebase_kernel, dim3((plan->n + 63) / 64), dim3(64), 0, (hipStream_t)stream, (WgradArgs*)workspace, plan->n, (long long)delta_bytes);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
 extern "C" int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
     esr_wgrad_batch_plan plan;
     const int rc = esr_conv3x3_wgrad_batch_upload(descs, n, workspace, workspace_bytes, &plan, stream);

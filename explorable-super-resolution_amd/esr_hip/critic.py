@@ -700,14 +700,13 @@ class _WgradSet:
         """-> {layer index: (dW in the parameter's shape, db)}"""
         flat, self._first = (self._first, None) if self._first is not None else (torch.zeros(self.n, dtype=torch.float32, device=self.ws.device), None)
         delta = flat.data_ptr() - self.flat_ptr
-        if delta or self.plan is None:
-            for d in self.arr:
-                d.dw += delta
-                d.db += delta
-            self.flat_ptr += delta
+        if self.plan is None:
             self.plan = _lib.WgradBatchPlan()
             check(_lib.lib.esr_conv3x3_wgrad_batch_upload(self.arr, len(self.arr), self.ws.data_ptr(), self.ws.numel(), C.byref(self.plan), A.stream_ptr()),
                   'esr_conv3x3_wgrad_batch_upload')
+        elif delta:            # a new flat buffer: move the table's dW / db pointers on the device (no host copy)
+            check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self.ws.data_ptr(), C.byref(self.plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
+            self.flat_ptr += delta
         check(_lib.lib.esr_conv3x3_wgrad_batch_run(self.ws.data_ptr(), C.byref(self.plan), A.stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
         out, off = {}, 0
         for (L, _, _), n in zip(self.pairs, self.sizes):

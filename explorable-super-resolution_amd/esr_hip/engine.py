@@ -767,14 +767,9 @@ class WGrad:
             return None
         flat = torch.zeros(self._n, dtype=torch.float32, device=self._dev)
         delta = flat.data_ptr() - self._flat_ptr
-        if delta:
-            for d in self._arr:
-                d.dw += delta
-                d.db += delta
+        if delta:             # the table's dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
+            _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self._ws.data_ptr(), C.byref(self._plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
             self._flat_ptr += delta
-            before = bytes(self._plan)
-            self._upload()
-            assert bytes(self._plan) == before      # same shapes -> same launch geometry: the recorded command stays valid
         parts = flat.split(self._sizes)
         grads = {}
         for i, (w, b) in enumerate(self._params):

@@ -278,6 +278,9 @@ typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16; } esr
 int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                    esr_stream_t stream);
 int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
+/* Every dw / db of an uploaded table moved by the same byte offset (all layers' gradients are views of one flat buffer and the caller got a new
+ * flat buffer for this pass): patch the table on the device — one tiny launch, no host traffic, stream-ordered behind the previous run. */
+int esr_conv3x3_wgrad_batch_rebase(void* workspace, const esr_wgrad_batch_plan* plan, int64_t delta_bytes, esr_stream_t stream);
 
 /* ---- Z-objective kernels (reference: codes/Z_optimization.py:170-209, SoftHistogramLoss.ComputeSoftHistogram, gray-scale / patch-size-1
  * form).  Soft histogram of n values with K bins whose centres run from lo to hi:  h[k] = (1/n) sum_i exp(-(d(v_i, c_k) + eps)^2 / T), the

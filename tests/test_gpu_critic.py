@@ -254,7 +254,9 @@ def test_fused_passes_equal_the_per_layer_graph_bit_for_bit(monkeypatch):
             # parameter gradients: where the penalty's second-order cotangent and the first-order one meet on a conv output, the fused
             # pass adds them in fp32 (esr_act_combine) while autograd adds the per-layer graph's bf16 planes — plus another summation
             # order in the batched weight-gradient launch
-            assert float((u.double() - v.double()).norm()) < 3e-2 * max(float(u.norm()), 1e-3 * scale), name
+            if max(float(u.norm()), float(v.norm())) < 1e-3 * scale:
+                continue                      # analytically zero (conv bias in front of BatchNorm): noise on both sides
+            assert float((u.double() - v.double()).norm()) < 3e-2 * float(u.norm()), name
     # and the G step's use: input gradient with frozen parameters
     for p in params:
         p.requires_grad_(False)
