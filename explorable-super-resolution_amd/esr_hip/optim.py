@@ -67,4 +67,6 @@ class Adam(torch.optim.Optimizer):
             _lib.check(_lib.lib.esr_adam_run(tab[1].data_ptr(), tab[2], tab[3], float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
                                              1 - b1 ** t, math.sqrt(1 - b2 ** t), stream_ptr()), 'esr_adam_run')
             first.fill_(t)
+            # the kernel wrote the parameters behind torch's back: tell the version counters (weight packs, autograd's saved-tensor checks)
+            torch.autograd.graph.increment_version(ps)
         return loss

@@ -131,6 +131,7 @@ def test_multi_tensor_adam_matches_torch_adam(weight_decay):
         for p, q in zip(pa, pb):
             assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()), it
     assert oa.param_groups[0]['lr'] == ob.param_groups[0]['lr'] == 5e-3
+    assert all(p._version == q._version for p, q in zip(pa, pb))      # the step is visible to everything that watches version counters (weight packs)
     for p, q in zip(pa, pb):
         assert float(oa.state[p]['step']) == float(ob.state[q]['step']) == 6
         torch.testing.assert_close(oa.state[p]['exp_avg_sq'], ob.state[q]['exp_avg_sq'], rtol=1e-5, atol=1e-12)
