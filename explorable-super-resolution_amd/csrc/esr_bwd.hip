@@ -334,7 +334,7 @@ struct WgradArgs {
     float* dw;
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
-    int tapmask[4];            // taps accumulated for main input tile i: tapmask[i & 3] (esr_wgrad_desc.tap_masks; 0x1FF = all)
+    int tapmode;               // 1: esr_wgrad_desc.tap_masks name the space-to-depth pattern (S2D_TAPS below); 0: all taps
 };
 #ifdef ESR_TRACE
 // debug build only (make trace): per-workgroup phase stamps of the weight-gradient kernels, 64 slots per workgroup — [0] HW_ID, [1] stamps used,
@@ -380,13 +380,14 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
     }
 }
 
-template <int NPL, int NST, int FMT, bool TMASK = false>
+// TM (compile time): the taps whose weight gradient is wanted (structurally zero blocks of the weights are skipped: the unrolled tap loop
+// drops their reads and MFMAs; their accumulators stay zero)
+template <int NPL, int NST, int FMT, int TM = 0x1FF>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cit = group / a.mt, cot = group % a.mt;            // input-channel tile, output-channel tile
     const bool lat_tile = cit >= a.ncit_main;
-    const int tmask = lat_tile ? 0x1FF : a.tapmask[cit & 3];     // uniform
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     constexpr int STAGE = NPL * (WG_X_BYTES + WG_Y_BYTES);       // [X hi | X lo | dY hi | dY lo], 4 group planes each
     constexpr int NX = NPL * XSLOTS, NY = NPL * YSLOTS;          // DMA instructions per wave per tile: 12 + 8 (6 + 4 without lo)
@@ -501,8 +502,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                 }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    if (TMASK && !((tmask >> t) & 1)) continue;  // structurally zero block of the weights (uniform branch; own instantiation:
-                                                                 // the branches cost the unmasked kernels their cross-tap scheduling)
+                    if (!((TM >> t) & 1)) continue;             // folds at compile time (t is an unrolled constant)
                     uint4 fb[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
@@ -571,22 +571,42 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #undef ESR_WG_ISSUE
 #undef ESR_WTR
 
-template <int NPL, int NST, int FMT, bool TMASK = false>
+// s2d (WgradArgs.tapmode == 1): the layer is a stride-2 conv run as a 3x3 conv over the space-to-depth input (esr_hip/critic.py): main input
+// tile i (one 32-channel quad of one parity) has non-zero weights only at the taps S2D_TAPS[i & 3] — five copies of the body, picked by a
+// uniform switch, each with its tap set as a compile-time constant
+constexpr int S2D_TAPS[4] = {432, 216, 54, 27};
+template <int NPL, int NST, int FMT, bool S2D>
+__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
+    if constexpr (S2D) {
+        const int cit = group / a.mt;
+        if (a.tapmode == 1 && cit < a.ncit_main) {
+            switch (cit & 3) {
+                case 0: wgrad_body<NPL, NST, FMT, S2D_TAPS[0]>(a, group, slice, smem); return;
+                case 1: wgrad_body<NPL, NST, FMT, S2D_TAPS[1]>(a, group, slice, smem); return;
+                case 2: wgrad_body<NPL, NST, FMT, S2D_TAPS[2]>(a, group, slice, smem); return;
+                default: wgrad_body<NPL, NST, FMT, S2D_TAPS[3]>(a, group, slice, smem); return;
+            }
+        }
+    }
+    wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
+}
+
+template <int NPL, int NST, int FMT, bool S2D = false>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    wgrad_body<NPL, NST, FMT, TMASK>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
+    wgrad_dispatch<NPL, NST, FMT, S2D>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
 }
 
 // Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
 // slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
-template <int NPL, int NST, int FMT>
+template <int NPL, int NST, int FMT, bool S2D = false>
 __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
-    wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
+    wgrad_dispatch<NPL, NST, FMT, S2D>(a, group, slice, smem);
 }
 
 // dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
@@ -677,7 +697,8 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     a.dw = d->dw;
     a.db = d->db;
     a.ws = ws;
-    for (int i = 0; i < 4; ++i) a.tapmask[i] = d->tap_masks[i] ? (d->tap_masks[i] & 0x1FF) : 0x1FF;
+    // (a hint: any other mask pattern accumulates all nine taps — zeros where the weights are structurally zero)
+    a.tapmode = (d->tap_masks[0] == 432 && d->tap_masks[1] == 216 && d->tap_masks[2] == 54 && d->tap_masks[3] == 27 && d->cin_main % 128 == 0) ? 1 : 0;
     return a;
 }
 
@@ -749,13 +770,9 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     void (*k)(const WgradArgs) = f16 ? (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 1> : conv3x3_wgrad_kernel<1, 1, 1>)
                                : split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0> : conv3x3_wgrad_kernel<2, 1, 0>)
                                        : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0> : conv3x3_wgrad_kernel<1, 1, 0>);
-    bool masked = false;
-    for (int i = 0; i < 4; ++i) masked = masked || a.tapmask[i] != 0x1FF;
-    if (masked) {                                                 // bf16 formats (what the critic uses)
-        if (f16) return ESR_E_UNSUPPORTED;
+    if (a.tapmode == 1 && !f16)
         k = split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0, true> : conv3x3_wgrad_kernel<2, 1, 0, true>)
                   : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0, true> : conv3x3_wgrad_kernel<1, 1, 0, true>);
-    }
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(p.ngroups * p.nslices), dim3(256), wgrad_lds(split ? 2 : 1, nst), (hipStream_t)stream, a);
@@ -813,6 +830,9 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     plan->max_red = max_red;
     plan->split = split ? 1 : 0;
     plan->f16 = descs[0].dy.fmt == ESR_FMT_F16 ? 1 : 0;
+    plan->s2d = 0;
+    for (const WgradArgs& t : table) plan->s2d |= t.tapmode == 1 ? 1 : 0;
+    plan->reserved = 0;
     return ESR_OK;
 }
 
@@ -824,6 +844,9 @@ extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgra
     void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
                                              : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
                                                      : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
+    if (plan->s2d && !f16)        // some layers are space-to-depth embedded stride-2 convs: the variant that skips their zero blocks
+        k = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0, true> : conv3x3_wgrad_batch_kernel<2, 1, 0, true>)
+                  : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0, true> : conv3x3_wgrad_batch_kernel<1, 1, 0, true>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,

@@ -115,10 +115,6 @@ struct ConvArgs {
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
     int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
     int nslices;                    // cout / 64 when cout > 64, else 1
-    // tap masks (TMASK kernels; esr_conv3x3_desc.tap_mask_k / tap_mask_m): structurally zero (tap, K chunk) / (tap, 32-row output tile) blocks
-    // of the weights are not multiplied — the 4x4 stride-2 convs of the critic run as 3x3 convs over the space-to-depth input, 16 of whose
-    // 36 (tap, parity) blocks are non-zero
-    int tmk[4], tmk_shift, tmm[4];
     long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
@@ -345,9 +341,13 @@ __device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const Con
 // The MFMAs of one chunk (2 channel groups x 9 taps) out of one LDS stage, with the fragment reads of tap t+1 interleaved between the
 // MFMAs of tap t (sched_barrier-pinned).  XLO: the chunk's activations have a lo plane.  Terms per product, in issue order:
 // Wlo*Xhi (if the weights have a lo plane), Whi*Xlo (if XLO), Whi*Xhi.
-template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP, bool TMASK = false>
+// TM0 / TM1 (compile time): 9-bit masks of the taps whose weights are not structurally zero for M tile 0 / 1 of this chunk; the unrolled
+// loops below drop the dead MFMAs and the fragment reads nobody needs (no run-time branches: those cost more than the MFMAs they save)
+template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP, int TM0 = 0x1FF, int TM1 = 0x1FF>
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes,
-                                           u32x4 (&wa)[9 * MT], const uint4* wnext, const int (&tm)[MT]) {
+                                           u32x4 (&wa)[9 * MT], const uint4* wnext) {
+    constexpr int TMU = TM0 | (MT == 2 ? TM1 : 0);      // taps any M tile needs: the activation fragments to read
+#define ESR_TAP_LIVE(t, m) ((((m) == 0 ? TM0 : TM1) >> (t)) & 1)
     // wa / wnext (weights-in-registers kernels): wa holds this chunk's A fragments [tap][mtile]; once a tap's MFMAs are issued its slots are
     // refilled with the NEXT chunk's fragments from wnext (nullptr: last chunk) — in flight for the rest of this chunk's MFMA phase
     constexpr bool WREG = wreg_of(NPW);
@@ -362,6 +362,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
     // the first MFMAs of the next tap need comes first
     auto load_frag = [&](int t, int k, int buf) {
         const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+        if (!((TMU >> t) & 1)) return;               // nobody multiplies this tap
         if (WREG) {                                  // only activation fragments come from LDS: [B hi x R, then B lo x R (if any)]
             if (k < R) fb[buf][k][0] = *(const uint4*)(sb + k * NW * 512 + tapoff);
             else fb[buf][k - R][NPB - 1] = *(const uint4*)(sb + (k - R) * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
@@ -369,7 +370,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
         }
         if (k < MT) {
             const int pl = NPW == 2 ? 1 : 0;
-            fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
+            if (ESR_TAP_LIVE(t, k)) fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
         } else if (k < MT + R) {
 #ifdef ESR_ABL_BREUSE                      // ablation (timing only): one activation read per tap ROW, the other two taps copy registers
             if (t % 3 != 0) { fb[buf][k - MT][0] = fb[buf ^ 1][k - MT][0]; return; }
@@ -377,7 +378,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
             fb[buf][k - MT][0] = *(const uint4*)(sb + (k - MT) * NW * 512 + tapoff);
         } else if (NPW == 2 && k < 2 * MT + R) {
             const int idx = k - MT - R;
-            fa[buf][idx][0] = *(const uint4*)(sa + ((t * MT + idx) * NPW) * 1024);
+            if (ESR_TAP_LIVE(t, idx)) fa[buf][idx][0] = *(const uint4*)(sa + ((t * MT + idx) * NPW) * 1024);
         } else {
             const int idx = k - (NPW == 2 ? 2 * MT + R : MT + R);
             fb[buf][idx][NPB - 1] = *(const uint4*)(sb + idx * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
@@ -398,8 +399,8 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
                 const int idx = ti + skip;                                    // index into the present-term list
                 const int term = (idx < has0) ? 0 : ((idx < has0 + has1) ? 1 : 2);
                 const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
-                if (TMASK && !((tm[m] >> t) & 1)) {
-                    // (uniform) this tap's weights for M tile m are structurally zero
+                if (!ESR_TAP_LIVE(t, m)) {
+                    // this tap's weights for M tile m are structurally zero (compile-time: t and m are unrolled constants)
                 } else if (WREG) acc[m][r] = mfma<FMT>(__builtin_bit_cast(uint4, wa[t * MT + m]), fb[cb][r][pb], acc[m][r]);
                 else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
             }
@@ -414,6 +415,12 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
     }
 }
 
+#undef ESR_TAP_LIVE
+
+// tap masks of the critic's stride-2 convs run as 3x3 convs over the space-to-depth input (esr_hip/critic.py): by parity s = 2 py + px of a
+// 32-channel tile, the non-zero taps of the embedded weight (bit 3 ty + tx) — and of its flipped / transposed form (data gradient)
+constexpr int S2D_FWD[4] = {432, 216, 54, 27}, S2D_FLIP[4] = {27, 54, 216, 432};
+
 // One output tile per workgroup.
 //   NST == 1: single LDS stage, 2 workgroups resident per CU: latency hiding comes from the co-resident workgroup instead of an
 //             in-workgroup pipeline (the persistent multi-stage variant measured slower).  Large launches.
@@ -424,7 +431,9 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 //             wait for the next one, waves 0-3 ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
 //             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
 //             placed), so only a second wave on the same SIMD can multiply meanwhile.
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, bool TMASK = false>
+// TMODE: 0 all taps; 1 the K chunks' tap sets follow S2D_FWD by the parity (cp >> 1) & 3 of their channel quad (forward of an embedded stride-2
+// conv); 2 the M tiles' tap sets follow S2D_FLIP by the parity of output tile 2 * slice + m (its data gradient)
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
     // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
     // same staged input.  All workgroups of all slices are in flight together: a 512-channel layer on an 8x8 map is one launch of
@@ -484,10 +493,8 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
-    int tm_all[MT], tm_m[MT];                      // tap masks: all taps / this slice's M tiles (uniform)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) { tm_all[m] = 0x1FF; tm_m[m] = TMASK ? a.tmm[(2 * (int)blockIdx.y + m) & 3] : 0x1FF; }
-    static_assert(!(TMASK && NST == 3), "no producer / consumer form of the tap-masked kernels");
+    static_assert(!(TMODE != 0 && NST == 3), "no producer / consumer form of the tap-masked kernels");
+    static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
 #ifdef ESR_ABL_TERMS
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
                 wait_vm_upto(nstg == 3 ? ahead : 0);
             } else {
                 ESR_TR(); ESR_TR(); ESR_TR();
-                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr, tm_all);
+                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr);
                 if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
             }
             ESR_TR();
@@ -577,11 +584,20 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
 #pragma unroll
             for (int f = 0; f < 9 * MT; ++f) pin_frag(wa[f]);
         }
-        int tm[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) tm[m] = TMASK ? (a.tmk[(cp >> a.tmk_shift) & 3] & tm_m[m]) : 0x1FF;
-        chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, TMASK>(acc, sa, sb, P, plane_bytes, wa,
-                                                                (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr, tm);
+        const uint4* const wnx = (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr;
+        if constexpr (TMODE == 1) {
+            switch ((cp >> 1) & 3) {                 // uniform: four copies of the chunk body, each with its own compile-time tap set
+                case 0: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[0], S2D_FWD[0]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
+                case 1: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[1], S2D_FWD[1]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
+                case 2: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[2], S2D_FWD[2]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
+                default: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[3], S2D_FWD[3]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
+            }
+        } else if constexpr (TMODE == 2) {
+            if (blockIdx.y & 1) chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[2], S2D_FLIP[3]>(acc, sa, sb, P, plane_bytes, wa, wnx);
+            else chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[0], S2D_FLIP[1]>(acc, sa, sb, P, plane_bytes, wa, wnx);
+        } else {
+            chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, wnx);
+        }
         if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
         ESR_TR();
         __syncthreads();
@@ -869,9 +885,9 @@ TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, bool TMASK = false>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMASK>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMODE>;
     ESR_ALLOW_160K_LDS(k);
     const int nslices = a.wslice ? a.nslices : 1;
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
@@ -885,7 +901,7 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     return ESR_OK;
 }
 
-template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO, bool TMASK = false>
+template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
@@ -893,12 +909,12 @@ int launch(const ConvArgs& a, hipStream_t s) {
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool small = ntiles <= 320;
 #if ESR_PC
-    if constexpr (!wreg_of(NPW) && !TMASK) {
+    if constexpr (!wreg_of(NPW) && TMODE == 0) {
         if (force == 3) return launch_nst<NPL, MT, EPI, 3, FMT, NPW, PARTLO>(a, s);
     }
 #endif
     const bool two = force ? force == 2 : small;
-    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMASK>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMASK>(a, s);
+    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
@@ -1113,19 +1129,15 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     }
     if (split && d->out.hi && !d->out.lo) partlo = true;
     if (partlo && !f16) return ESR_E_UNSUPPORTED;                   // single-plane intermediates exist for the fp16 formats only
-    bool masked = false;
-    for (int i = 0; i < 4; ++i) {
-        a.tmk[i] = d->tap_mask_k[i] ? (d->tap_mask_k[i] & 0x1FF) : 0x1FF;
-        a.tmm[i] = d->tap_mask_m[i] ? (d->tap_mask_m[i] & 0x1FF) : 0x1FF;
-        masked = masked || a.tmk[i] != 0x1FF || a.tmm[i] != 0x1FF;
-    }
-    a.tmk_shift = d->tap_mask_k_shift;
-    if (masked) {
-        // the tap-masked kernels exist for the plain epilogue of the bf16 formats (what the critic launches)
-        if (epi != 0 || f16 || partlo || a.tmk_shift < 0 || a.tmk_shift > 8) return ESR_E_UNSUPPORTED;
-        if (split) return mt == 1 ? launch<2, 1, 0, 0, 2, false, true>(a, s) : launch<2, 2, 0, 0, 2, false, true>(a, s);
-        return mt == 1 ? launch<1, 1, 0, 0, 1, false, true>(a, s) : launch<1, 2, 0, 0, 1, false, true>(a, s);
-    }
+    // tap masks are a HINT (blocks outside them must be zero in the pack): the two patterns with compiled kernels are honoured, anything
+    // else multiplies all nine taps — the same result
+    auto all9 = [](const int32_t (&m)[4]) { return (m[0] == 0 || m[0] == 0x1FF) && (m[1] == 0 || m[1] == 0x1FF) && (m[2] == 0 || m[2] == 0x1FF) && (m[3] == 0 || m[3] == 0x1FF); };
+    auto same = [](const int32_t (&m)[4], const int (&p)[4]) { return m[0] == p[0] && m[1] == p[1] && m[2] == p[2] && m[3] == p[3]; };
+    const bool plain = epi == 0 && !f16 && !partlo && mt == 2 && a.in0.ncg == 0;
+    if (plain && same(d->tap_mask_k, S2D_FWD) && d->tap_mask_k_shift == 1 && all9(d->tap_mask_m) && (a.in1.ncg % 4) == 0)
+        return split ? launch<2, 2, 0, 0, 2, false, 1>(a, s) : launch<1, 2, 0, 0, 1, false, 1>(a, s);
+    if (plain && same(d->tap_mask_m, S2D_FLIP) && all9(d->tap_mask_k))
+        return split ? launch<2, 2, 0, 0, 2, false, 2>(a, s) : launch<1, 2, 0, 0, 1, false, 2>(a, s);
     if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
     if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
     if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);

@@ -38,7 +38,7 @@ class WgradDesc(C.Structure):
 
 class WgradBatchPlan(C.Structure):
     """esr_wgrad_batch_plan (include/esr_hip.h)."""
-    _fields_ = [('nwg', C.c_int64), ('table_bytes', C.c_int64), ('n', C.c_int32), ('max_red', C.c_int32), ('split', C.c_int32), ('f16', C.c_int32)]
+    _fields_ = [('nwg', C.c_int64), ('table_bytes', C.c_int64), ('n', C.c_int32), ('max_red', C.c_int32), ('split', C.c_int32), ('f16', C.c_int32), ('s2d', C.c_int32), ('reserved', C.c_int32)]
 
 
 class PackDesc(C.Structure):

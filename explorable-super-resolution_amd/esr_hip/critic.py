@@ -685,7 +685,7 @@ class _WgradSet:
         for (L, dy, xin), n in zip(pairs, self.sizes):
             nw = L.cout * L.cin_e * 9
             d, _, _ = A.wgrad_desc(view_of(dy), view_of(xin), None, 0, (L.cout, L.cin_e, 3, 3), bs.B, dy.shape[3] - 2, dy.shape[4] - 2, 1.0, 1, bs.dev,
-                                   out=(flat[off:off + nw], flat[off + nw:off + n]))
+                                   out=(flat[off:off + nw], flat[off + nw:off + n]), tap_masks=MASK_FWD if (L.strided and MASK_FWD) else None)
             descs.append(d)
             off += n
         self.arr = (_lib.WgradDesc * len(descs))(*descs)

@@ -116,11 +116,13 @@ typedef struct {
      * ((g / r^2)*8 + row % 8) * r^2 + s.  The activation commutes with the shuffle and is applied before it.  0: plain store. */
     int32_t pixel_shuffle;
     int32_t ps_rowgroup0;
-    /* structurally sparse weights: 9-bit tap masks (bit 3*dy + dx of the tap as the pack stores it; 0 = all nine taps).  K chunk cp (the
-     * cp-th PAIR of input channel groups) multiplies only the taps of tap_mask_k[(cp >> tap_mask_k_shift) & 3]; the j-th 32-row tile of
-     * the output (j = 2 * slice + tile) only those of tap_mask_m[j & 3]; a (tap, chunk, tile) block outside either mask is skipped, i.e.
-     * treated as zero whatever the pack holds.  Used for the critic's 4x4 stride-2 convs (codes/models/modules/architecture.py:452-480),
-     * which run as 3x3 convs over the space-to-depth input with 16 non-zero blocks of 36 (esr_hip/critic.py); plain epilogue, bf16 formats. */
+    /* structurally sparse weights, a HINT: 9-bit tap masks (bit 3*dy + dx of the tap as the pack stores it; 0 = all nine taps).  The caller
+     * promises that K chunk cp (the cp-th PAIR of input channel groups) has non-zero weights only at the taps of
+     * tap_mask_k[(cp >> tap_mask_k_shift) & 3], and the j-th 32-row tile of the output (j = 2 * slice + tile) only at those of
+     * tap_mask_m[j & 3]; the library skips blocks outside the masks where it has a kernel for the pattern and multiplies the zeros
+     * otherwise — same result.  Patterns with kernels: the critic's 4x4 stride-2 convs (codes/models/modules/architecture.py:452-480) run as
+     * 3x3 convs over the space-to-depth input, 16 non-zero blocks of 36 (esr_hip/critic.py): forward (K masks {432, 216, 54, 27}, shift 1) and
+     * data gradient (M masks {27, 54, 216, 432}); plain epilogue, bf16 formats, cout a multiple of 64. */
     int32_t tap_mask_k[4];
     int32_t tap_mask_k_shift;
     int32_t tap_mask_m[4];
@@ -257,8 +259,8 @@ typedef struct {
     float* db;
     float* workspace;
     int64_t workspace_floats;
-    /* 9-bit tap masks (0 = all taps): the i-th 32-channel tile of the main input only accumulates the taps of tap_masks[i & 3]; dw entries of
-     * the other taps are left untouched (the structurally zero blocks of esr_conv3x3_desc.tap_mask_k) */
+    /* a HINT, as esr_conv3x3_desc.tap_mask_k: the weights whose gradient this is are structurally zero outside the taps of tap_masks[i & 3] for
+     * the i-th 32-channel tile of the main input; dw entries outside the masks receive zeros or are left untouched (0 = all taps) */
     int32_t tap_masks[4];
 } esr_wgrad_desc;
 int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d);   /* depends on B, H, W, cout, cin_main, lat only; <0: bad argument */
@@ -274,7 +276,7 @@ int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace,
  * allocator handing back the same dW storage): _upload writes the descriptor table into `workspace` (a host-blocking copy from pageable
  * memory: NOT capturable in a HIP graph) and fills `plan`; _run enqueues the launch from the table already on the device (capturable; no
  * host traffic).  esr_conv3x3_wgrad_batch == _upload followed by _run. */
-typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16; } esr_wgrad_batch_plan;
+typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16, s2d, reserved; } esr_wgrad_batch_plan;
 int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                    esr_stream_t stream);
 int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);

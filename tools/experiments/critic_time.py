@@ -64,3 +64,20 @@ for name, run in (('hip %s' % prec, lambda x: K.critic_forward(eng, x)), ('torch
     for what, fn in passes(run):
         wall, host = timed(fn)
         print('%-28s %-22s %7.2f ms   (host enqueue %6.2f ms)' % (name, what, wall, host))
+
+if os.environ.get('CRITIC_PROFILE'):
+    import cProfile, io, pstats
+    run = lambda x: K.critic_forward(eng, x)
+    fn = dict(passes(run))['WGAN-GP critic step']
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        fn()
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
+    print('\n'.join(l[:170] for l in s.getvalue().splitlines()[4:44]))
