@@ -394,9 +394,9 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
 
 
 def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
-    """configs[2] at its per-GPU shape: SRRaGANModel.optimize_parameters() (G forward/backward through the HIP path, discriminator
-    + WGAN-GP on stock MIOpen kernels, two Adam steps) on 32 crops of 52x52 (HR 208x208, latent 3) per GPU; G and D gradients are
-    all-reduced over RCCL when N > 1."""
+    """configs[2] at its per-GPU shape: SRRaGANModel.optimize_parameters() (G forward/backward, Discriminator_VGG_128 forward / backward / the
+    WGAN-GP penalty's double backward and both Adam steps on the library's kernels) on 32 crops of 52x52 (HR 208x208, latent 3) per GPU; G and D
+    gradients are all-reduced over RCCL when N > 1."""
     import contextlib
     import io
     import torch
@@ -442,7 +442,8 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     bytes_g = 3 * B * 52 * 52 * (49268 + 15728) * (4 if precision in ('split', 'mixed') else 2)
     return {'metric': 'LR crops/sec (RRDB-23 x4 lat 3 G + Discriminator_VGG_128 WGAN-GP step, 32 x 52x52 per GPU)', 'value': world * B * args.steps / dt, 'unit': 'LR crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator %s on MIOpen' % ('bf16 autocast' if d_bf16 else 'fp32'), 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision) + ' (generator); discriminator ' + (('%s on the HIP kernels (esr_hip/critic.py)' % ('bf16' if d_bf16 else 'bf16x3'))
+                                                                              if model.D_engine is not None else ('%s on MIOpen' % ('bf16 autocast' if d_bf16 else 'fp32'))), 'data': 'synthetic',
             'config': {'workload': 'configs[2] per-GPU shape: SRRaGANModel.optimize_parameters(), G+D step, %d crops of 52x52 (HR 208x208, latent 3) per GPU' % B,
                        'global_batch': B * world, 'parallelism': 'dp%d (G and D gradients all-reduced over RCCL)' % world},
             'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],

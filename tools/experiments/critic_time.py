@@ -60,7 +60,13 @@ def stock(x):
         return netD(x).float()
 
 
-for name, run in (('hip %s' % prec, lambda x: K.critic_forward(eng, x)), ('torch/MIOpen %s' % ('bf16 autocast' if prec == 'bf16' else 'fp32'), stock)):
+variants = [('hip %s' % prec, lambda x: K.critic_forward(eng, x)), ('torch/MIOpen %s' % ('bf16 autocast' if prec == 'bf16' else 'fp32'), stock)]
+if os.environ.get('CRITIC_ONLY') == 'hip':
+    variants = variants[:1]
+if os.environ.get('CRITIC_ONLY') == 'step':          # profiling runs: the critic step alone, 10 + 3 iterations
+    variants = []
+    timed(dict(passes(lambda x: K.critic_forward(eng, x)))['WGAN-GP critic step'])
+for name, run in variants:
     for what, fn in passes(run):
         wall, host = timed(fn)
         print('%-28s %-22s %7.2f ms   (host enqueue %6.2f ms)' % (name, what, wall, host))
