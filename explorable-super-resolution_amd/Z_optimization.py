@@ -23,7 +23,16 @@ def ArcTanH(input_tensor):
     return 0.5 * torch.log((1 + input_tensor + eps) / (1 - input_tensor + eps))
 
 
-def TV_Loss(image):
+def TV_Loss(image, mask=None, clamp01=False):
+    """reference :324-326.  GPU tensors: one reduction kernel (esr_hip.zobj.tv_loss; `mask` / `clamp01` fold the image mask and the clamp of
+    Output_Batch(within_0_1=True) into its read); CPU tensors: the defining torch expression."""
+    if image.is_cuda:
+        from esr_hip import zobj
+        return zobj.tv_loss(image, mask, clamp01)
+    if clamp01:
+        image = torch.clamp(image, 0, 1)
+    if mask is not None:
+        image = image * mask
     return (image[:, :, :, :-1] - image[:, :, :, 1:]).abs().mean(dim=(1, 2, 3)) + (image[:, :, :-1, :] - image[:, :, 1:, :]).abs().mean(dim=(1, 2, 3))
 
 
@@ -171,6 +180,9 @@ class Z_optimizer():
 
     def Masked_STD(self, first_image_only=False):
         # whole-image objectives: the STD of EVERY sample, [1, B], whatever the flag says (as the reference, see __init__)
+        if self.model.fake_H.is_cuda:        # clamp, mask and the two moments in one pass over the batch (esr_img_stats)
+            from esr_hip import zobj
+            return zobj.image_std(self.model.fake_H, self.image_mask, clamp01=True).view(1, -1)
         out = self.model.Output_Batch(within_0_1=True)
         return torch.std(out if self.image_mask is None else out * self.image_mask, dim=(1, 2, 3)).view(1, -1)
 
@@ -231,7 +243,8 @@ class Z_optimizer():
                 Z_loss = (self.output_image - self.desired_im).abs().mean(dim=(1, 2, 3))
             elif 'TV' in self.objective:
                 Z_loss = (self.STD_PRESERVING_WEIGHT * (self.Masked_STD() - self.initial_STD) ** 2).mean(0) + \
-                    TV_Loss(self.output_image if self.image_mask is None else self.output_image * self.image_mask)
+                    (TV_Loss(self.model.fake_H, self.image_mask, clamp01=True) if not self.model_training else
+                     TV_Loss(self.output_image if self.image_mask is None else self.output_image * self.image_mask))
             else:
                 Z_loss = self.Masked_STD()
                 if any(p in self.objective for p in ['increase', 'decrease']):

@@ -183,6 +183,8 @@ _SIGS = {
     'esr_soft_hist_slabs': (C.c_int64, [C.c_int64]),
     'esr_soft_hist_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'esr_soft_hist_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'esr_img_stats': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'esr_img_stats_grad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'esr_cem_downscale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'esr_cem_lrfilter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

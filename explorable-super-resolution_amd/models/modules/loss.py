@@ -106,6 +106,9 @@ class FilterLoss(nn.Module):
 
     @staticmethod
     def structure_tensor(x):
+        if x.is_cuda:                       # one reduction kernel per call, closed-form gradient (esr_img_stats kind 2)
+            from esr_hip import zobj
+            return zobj.structure_tensor(x)
         ix = (x[..., :, 1:] - x[..., :, :-1])[..., :-1, :]
         iy = (x[..., 1:, :] - x[..., :-1, :])[..., :, :-1]
         return torch.stack([(ix * ix).mean(dim=(1, 2, 3)), (iy * iy).mean(dim=(1, 2, 3)), (ix * iy).mean(dim=(1, 2, 3))], 0)      # [3, B]

@@ -308,6 +308,18 @@ int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* workspace, 
 int esr_adam_run(const void* workspace, int n, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float bias_correction1, float bias_correction2_sqrt, esr_stream_t stream);
 
+/* Per-image statistics of the SR output and their gradients — the reductions of the Z-search loop and of the L_struct training loss, one pass
+ * over the image each (csrc/esr_zobj.hip):
+ *   kind 0  masked STD       codes/Z_optimization.py:383-388  torch.std(image * mask, dim=(1,2,3))              sums[b] = (sum v, sum v^2, -)
+ *   kind 1  TV_Loss          codes/Z_optimization.py:324-326                                                       sums[b] = (sum |dx|, sum |dy|, -)
+ *   kind 2  structure tensor codes/models/modules/loss.py:49-62,141-151 (2x2 difference filters, (H-1) x (W-1) frame)  sums[b] = (sum ix^2, sum iy^2, sum ix iy)
+ * x: fp32 [B][C][H][W]; v = clamp(x, 0, 1) when clamp01 (the reference's Output_Batch(within_0_1=True)), times mask [H][W] when given (the GUI's
+ * image mask).  sums: [B][3] doubles, zeroed by the caller (the kernels add).  _grad: dx = sum_k coef[b][k] * d sums[b][k] / dx in closed form
+ * (the caller folds the scalar ops after the reduction — sqrt, division by N — into coef); accumulate != 0 adds into dx. */
+int esr_img_stats(const float* x, int B, int C, int H, int W, const float* mask, int clamp01, int kind, double* sums, esr_stream_t stream);
+int esr_img_stats_grad(const float* x, int B, int C, int H, int W, const float* mask, int clamp01, int kind, const float* coef, float* dx, int accumulate,
+                       esr_stream_t stream);
+
 /* ---- the critic's glue: BatchNorm2d (training mode) + LeakyReLU, its gradient and the gradient of its gradient ----
  * Reference: Discriminator_VGG_128 (codes/models/modules/architecture.py:446-508): conv_block = nn.Conv2d -> nn.BatchNorm2d(affine, batch
  * statistics while training; block.py:25-35,129-146) -> LeakyReLU(0.2); the WGAN-GP penalty (codes/models/modules/loss.py:260-279)

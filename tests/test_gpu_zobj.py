@@ -66,3 +66,61 @@ def test_hist_objective_of_z_optimizer_reduces_the_divergence():
                      initial_Z=z0.clone(), initial_LR=0.1, batch_size=2)
     z = zo.optimize()
     assert all(np.isfinite(zo.loss_values)) and zo.loss_values[-1] < zo.loss_values[0] and float((z - z0).abs().max()) > 1e-3
+
+
+def _ref_stats(x, mask, clamp01, kind):
+    v = x.double()
+    if clamp01:
+        v = torch.clamp(v, 0, 1)
+    if mask is not None:
+        v = v * mask.double()
+    if kind == 0:
+        return torch.std(v, dim=(1, 2, 3))
+    if kind == 1:
+        return (v[:, :, :, :-1] - v[:, :, :, 1:]).abs().mean(dim=(1, 2, 3)) + (v[:, :, :-1, :] - v[:, :, 1:, :]).abs().mean(dim=(1, 2, 3))
+    ix = (v[..., :, 1:] - v[..., :, :-1])[..., :-1, :]
+    iy = (v[..., 1:, :] - v[..., :-1, :])[..., :, :-1]
+    return torch.stack([(ix * ix).mean(dim=(1, 2, 3)), (iy * iy).mean(dim=(1, 2, 3)), (ix * iy).mean(dim=(1, 2, 3))], 0)
+
+
+@pytest.mark.parametrize('kind', [0, 1, 2])
+@pytest.mark.parametrize('masked,clamp01', [(False, False), (True, True)])
+def test_image_statistic_kernels_match_the_torch_expressions(kind, masked, clamp01):
+    """Masked STD (Z_optimization.py:383-388), TV_Loss (:324-326) and the structure tensor of FilterLoss (loss.py:49-62,141-151): value and
+    gradient of the single-pass kernels against the reference's torch expressions evaluated in float64."""
+    from esr_hip import zobj
+    from oracle.weights import seeded_uniform
+    x = (seeded_uniform((3, 3, 37, 45), 1200 + kind) * 1.6 - 0.3).cuda()                 # some values outside [0, 1]: the clamp's gradient mask matters
+    mask = (seeded_uniform((37, 45), 1210) > 0.35).float().cuda() if masked else None
+    if kind == 2 and masked:
+        pytest.skip('the structure tensor is taken of the whole image')
+    fn = {0: zobj.image_std, 1: zobj.tv_loss}.get(kind)
+    xa = x.clone().requires_grad_(True)
+    got = fn(xa, mask, clamp01) if fn else zobj.structure_tensor(xa)
+    xr = x.clone().requires_grad_(True)
+    ref = _ref_stats(xr, mask, clamp01, kind)
+    torch.testing.assert_close(got.double(), ref, rtol=2e-6, atol=1e-9)
+    w = seeded_uniform(tuple(ref.shape), 1220).cuda().double() + 0.5
+    (got.double() * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(xa.grad.double(), xr.grad.double(), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('code', ['SVDinNormedOut_structure_tensor', 'structure_tensor'])
+def test_filter_loss_on_the_gpu_matches_the_reference(code):
+    """FilterLoss (reference loss.py:27-209) on GPU tensors — structure tensor and its gradient by the HIP kernels — against fixture F10
+    (values of three consecutive calls of the reference's class, and d loss / d SR)."""
+    import numpy as np
+    import os
+    from models.modules.loss import FilterLoss
+    from oracle.weights import seeded_uniform
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_loss.npz'))
+    fl = FilterLoss(latent_channels=code)
+    for call in range(3):
+        sr = seeded_uniform((4, 3, 24, 20), 1000 + call).cuda().requires_grad_(True)
+        hr = seeded_uniform((4, 3, 24, 20), 1010 + call).cuda()
+        z = (seeded_uniform((4, 3, 1, 1), 1020 + call, -1.0, 1.0) * torch.ones(4, 3, 24, 20)).cuda()
+        loss = fl({'SR': sr, 'HR': hr, 'Z': z})
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g['%s/call%d' % (code, call)], rtol=2e-5, atol=1e-7)
+    loss.sum().backward()
+    np.testing.assert_allclose(sr.grad.cpu().numpy(), g[code + '/dSR'], rtol=1e-4, atol=1e-8)
