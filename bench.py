@@ -171,6 +171,18 @@ def newest_pmc(precision):
     return json.load(open(pmc[-1]))['hbm_bytes_per_launch'], os.path.basename(pmc[-1])
 
 
+def newest_pmc_mfma(precision):
+    """MFMA-pipe occupancy and effective shader clock of the conv launches from the newest committed counter summary of this command
+    (tools/pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE in separate rocprofv3 --pmc passes) — static, like roofline.traffic."""
+    import glob
+    import re
+    fs = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')) if json.load(open(f)).get('precision') == precision),
+                key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])
+    if not fs:
+        return None, None
+    return json.load(open(fs[-1])).get('all_conv_launches'), os.path.basename(fs[-1])
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -355,6 +367,12 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
     }
     if traffic:
         out['roofline']['frac_physical_static'] = traffic / t_launch / HBM_PEAK      # bytes the mode really moves (static PMC figure) / measured time
+    pm, pm_src = newest_pmc_mfma(precision) if BATCH == 32 else (None, None)
+    if pm:
+        # counters of an earlier rocprofv3 run of this command (a profiled run clocks ~2 % lower): fraction of cycles the MFMA pipes were busy
+        # and GRBM_GUI_ACTIVE / wall time; 32 busy cycles per v_mfma_f32_32x32x16
+        out['roofline'].update({'mfma_busy_frac': pm.get('mfma_busy_frac'), 'effective_clock_ghz': pm.get('effective_clock_ghz'),
+                                'mfma_issue_pflops_bf16_pmc': pm.get('mfma_issue_pflops_bf16'), 'mfma_counters_static': True, 'mfma_counters_source': pm_src})
     gen_err = None
     if not args.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
         cb, xs, ys, gen_ref = cpu_baseline(G, cem)      # gen_ref: the oracle's generator output on the padded frame
