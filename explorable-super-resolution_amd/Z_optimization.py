@@ -233,6 +233,10 @@ class Z_optimizer():
             if USE_MIN_LOSS_Z:
                 per_iter_pre_tanh_Z.append(1 * self.Z_model.PreTanhZ())
             self.model.feed_data(data, need_GT=False)
+            # drop the previous iteration's output first: its graph holds the generator's saved-activation buffers, and a forward that finds
+            # them busy allocates a second full set (2 x 90 GB at the configs[3] shape)
+            self.output_image = Z_loss = loss = None
+            self.model.fake_H = self.model.output_image = None
             self.model.test(prevent_grads_calc=False)
             self.output_image = self.model.Output_Batch(within_0_1=True)
             if self.model_training:

@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
                             if (EPI & EPI_OUT2) {
                                 const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
                                 ((uint4*)a.out2.hi)[o2] = hv;
-                                if (NPL == 2 && (!PARTLO || a.out2.lo)) ((uint4*)a.out2.lo)[o2] = lv;
+                                if (NPL == 2 && a.out2.lo) ((uint4*)a.out2.lo)[o2] = lv;       // (a hi-only second destination: the mask stash)
                             }
                         }
                     }
@@ -1050,7 +1050,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (!ps && d->out.hi && d->out.ncg * 8 < d->cout) return ESR_E_ARG;
     // a missing lo OUTPUT plane with hi+lo inputs is the single-plane-intermediate case (fp16 formats only, checked below)
     if (d->out.hi && d->out.lo && !split) return ESR_E_ARG;
-    if (d->out2.hi && (!d->out.hi || (d->out2.lo != nullptr) != (d->out.lo != nullptr))) return ESR_E_ARG;
+    if (d->out2.hi && (!d->out.hi || (d->out2.lo && !d->out.lo))) return ESR_E_ARG;      // out2 may drop the lo plane, not add one
     if (d->act_slope <= 0.f || d->act_slope > 1.f) return ESR_E_ARG;
 
     ConvArgs a{};

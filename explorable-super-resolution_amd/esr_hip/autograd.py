@@ -11,7 +11,7 @@ from . import cem_ops
 class _RRDBFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, pad, x, *params):
-        g, bufs = engine.run_forward(x, pad, keep=True)
+        g, bufs = engine.run_forward(x, pad, keep=engine.keep_mode())
         ctx.engine, ctx.pad, ctx.bufs, ctx.x_shape = engine, pad, bufs, tuple(x.shape)
         ctx.params = params
         return g

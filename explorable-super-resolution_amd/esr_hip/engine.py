@@ -51,6 +51,11 @@ class RRDBEngine:
         # launch lists (esr_run): a pass over a cached buffer set is recorded once and replayed with one C call per segment afterwards;
         # ESR_PLANS=0 issues every launch from Python instead (the recording path itself, used by the tests as the reference)
         self.use_plans = os.environ.get('ESR_PLANS', '1') != '0'
+        # what a differentiable forward keeps for its backward when NO parameter wants a gradient (the Z search: frozen generator): 'masks' —
+        # three rotating dense-block buffers as in inference plus, per RDB, a ONE-plane copy of its four intermediate activations, of which the
+        # data gradient reads nothing but the signs (LeakyReLU'); 'full' — every RDB's whole 24-group hi+lo buffer, as training needs (the
+        # weight gradient contracts the activations themselves).  Same gradients bit for bit; 1/3 of the memory per RDB.
+        self.stash = os.environ.get('ESR_STASH', 'masks')
         self._ptr_fp, self._ptr_epoch = None, 0   # parameter storages the recorded descriptors point into; epoch moves when any changes
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
@@ -271,7 +276,10 @@ class RRDBEngine:
         d['xin'] = A.ActBuf(B, 1, h, w, dev, sp)
         d['fea'] = A.ActBuf(B, 8, h, w, dev, sp)
         # inference: three rotating RDB buffers; differentiable forward: one per RDB (saved activations)
-        d['rdb'] = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3 * net.nb if keep else 3)]
+        d['rdb'] = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3 * net.nb if keep is True else 3)]
+        if keep == 'masks':
+            one_plane = 'f16' if sp in ('mixed', 'f16', 'f16x2', 'f16x3') else False
+            d['stash'] = [A.ActBuf(B, 16, h, w, dev, one_plane) for _ in range(3 * net.nb)]
         d['last'] = A.ActBuf(B, 8, h, w, dev, sp)
         d['trunk'] = A.ActBuf(B, 8, h, w, dev, sp)
         ups = []
@@ -300,6 +308,12 @@ class RRDBEngine:
         if x.shape[1] != lat1 * sf * sf + 3:
             raise EsrError('expected %d input channels (latent %d x sf^2 + 3), got %d' % (lat1 * sf * sf + 3, lat1, x.shape[1]))
         return sf, has_lat, lat1
+
+    def keep_mode(self):
+        """What a differentiable forward saves: everything (True) when a parameter wants a gradient, else per self.stash."""
+        if self.stash == 'masks' and not any(p.requires_grad for p in self.parameters()):
+            return 'masks'
+        return True
 
     def _plan_key(self, kind, *what):
         # a forward list points into the forward packs only: creating the data-gradient packs later (first backward) leaves it valid
@@ -362,7 +376,7 @@ class RRDBEngine:
         def buf_of(j):       # buffer that holds RDB j's dense block (j = 3*r + k); j == nrdb: the trunk's last feature map
             if j == nrdb:
                 return bufs['last']
-            return rdb[j] if keep else rdb[j % 3]
+            return rdb[j] if keep is True else rdb[j % 3]
 
         # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
         conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, 8) if net.nb else None)
@@ -380,8 +394,9 @@ class RRDBEngine:
             for k in range(3):
                 buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
                 for i in range(4):
+                    o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
                     conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), **(lo_in if (i > 0 or xlo_mode != 'all') else {}))
+                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), **lo_c4)
@@ -417,6 +432,8 @@ class RRDBEngine:
         if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
                                       "use 'split' (fp32-class) or 'bf16' for training / Z optimisation")
+        if need_dw and 'stash' in bufs:
+            raise EsrError('this forward kept LeakyReLU masks only (no parameter asked for a gradient when it ran): weight gradients need the activations')
         dg = dg.detach()
         dg = (dg if dg.dtype == torch.float32 else dg.float()).contiguous()
         self.packed_t()                       # weight packs refreshed outside any recording
@@ -600,16 +617,19 @@ class RRDBEngine:
         for r in reversed(range(net.nb)):
             G_rrdb = G_cur                    # its groups 0:8 = d(output of RRDB r), needed again for the RRDB's skip connection
             for k in reversed(range(3)):
-                X = bufs['rdb'][3 * r + k]
+                stash = bufs['stash'][3 * r + k] if 'stash' in bufs else None       # masks-only forward: no full buffer per RDB
+                X = bufs['rdb'][3 * r + k] if stash is None else None
                 G = G_cur
                 name = 'rrdb%d.rdb%d' % (r, k)
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
-                wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
+                if need_dw:
+                    wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
                 for c in (3, 2, 1, 0):
                     g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
                     conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
-                         mask_src=X.view(8 + 4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
-                    wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
+                         mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
+                    if need_dw:
+                        wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
                     conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)

@@ -91,7 +91,7 @@ typedef struct {
     esr_act_view res1; float beta1;   /* optional (hi == NULL: absent); same H, W as the output */
     esr_act_view res2; float beta2;
     esr_act_view out;        /* act-layout destination (ncg*8 >= cout), or hi == NULL */
-    esr_act_view out2;       /* optional second destination (same values) */
+    esr_act_view out2;       /* optional second destination (same values; may be hi-only when `out` is hi+lo: a one-plane copy) */
     float* out_nchw;         /* optional fp32 [B][cout][H][W] destination */
     /* data-gradient helper: multiply the result for output groups [mask_cg0, mask_cg1) by
      * act'(mask_src) = (mask_src > 0 ? 1 : mask_slope) AFTER the residual add (LeakyReLU backward of

@@ -39,7 +39,7 @@ def test_replayed_forward_is_bit_identical_to_direct_launches(precision):
         got = [net(x, pad=2) for x in xs]           # call 0 records, calls 1-2 replay into new output tensors from new inputs
     for r, g in zip(ref, got):
         assert torch.equal(r, g)
-    plans = [p for b in eng._bufs.values() for p in b['_plans'].values()]
+    plans = [p for b in eng._bufs.values() for p in b['_plans'].values()]        # (no_grad forwards: one inference buffer set)
     assert len(plans) == 1 and plans[0].n_cmds >= 3 + 15 * 2 + 5      # one list for the whole pass, not one per call
     assert len({g.data_ptr() for g in got}) == 3
 
@@ -138,3 +138,32 @@ def test_multi_tensor_adam_matches_torch_adam(weight_decay):
     oc = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), weight_decay=weight_decay)
     oc.load_state_dict(oa.state_dict())                     # same state layout: checkpoints are interchangeable
     assert float(oc.state[pb[0]]['step']) == 6
+
+
+@pytest.mark.parametrize('precision', ['split', 'mixed'])
+def test_mask_stash_gives_the_same_input_gradient_with_a_third_of_the_memory(precision):
+    """A differentiable forward through a FROZEN generator (the Z search) keeps three rotating dense-block buffers and a one-plane copy of
+    each RDB's intermediate activations instead of every 24-group hi+lo buffer: the data gradient only reads their signs (LeakyReLU').  Same
+    dx bit for bit; weight gradients are refused loudly."""
+    net = make_net(nb=3, precision=precision)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    eng = net.engine
+    x0 = inputs(2, 3, 4, 16, 20, 130)
+    cot = None
+    out = {}
+    for mode in ('full', 'masks'):
+        eng.stash = mode
+        x = x0.clone().requires_grad_(True)
+        y = net(x, pad=2)
+        cot = seeded_uniform(tuple(y.shape), 131).cuda() if cot is None else cot
+        (y * cot).sum().backward()
+        bufs = [b for k, b in eng._bufs.items() if k[-1] == (True if mode == 'full' else 'masks')][0]
+        nbytes = sum(t.nbytes() for t in bufs['rdb']) + sum(t.nbytes() for t in bufs.get('stash', []))
+        out[mode] = (y.detach().clone(), x.grad.clone(), nbytes)
+        del y
+    assert torch.equal(out['full'][0], out['masks'][0]) and torch.equal(out['full'][1], out['masks'][1])
+    assert out['masks'][2] < 0.67 * out['full'][2]            # nb = 3: (3 x 24 x 2 + 9 x 16) / (9 x 24 x 2) planes; -> 1/3 for deep nets
+    # a parameter that wants a gradient switches the forward back to keeping everything
+    next(net.parameters()).requires_grad_(True)
+    assert eng.keep_mode() is True
