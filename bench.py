@@ -2,7 +2,7 @@
 """Headline benchmark: HR pixels / second of the RRDB-23 x4 generator + CEM (eval mode) forward on synthetic
 32 x 3 x 128 x 128 fp32 batches per GPU (BASELINE.json configs[1]), weak scaling over N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
 
 `--gpus N` with N > 1 launches its own ranks (python -m torch.distributed.run, one process per GPU, RCCL) unless it already runs
 under a launcher (WORLD_SIZE set).  A step = one pass of the hot path over one batch already resident in HBM.  Rank 0 prints ONE
@@ -189,8 +189,10 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3'],
-                    help="c2 (default, the headline): configs[1] forward; c3: configs[2] G+D training step at its per-GPU shape, gradients all-reduced over RCCL")
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
+                    help="c2 (default, the headline): configs[1] forward; c3: configs[2] G+D training step at its per-GPU shape, gradients all-reduced over RCCL; "
+                         "c4: configs[3] Z-search iterations (64 Z samples of 512x512, sharded over the ranks); c5: configs[4] x8 inference with the "
+                         "blurry_cubic_2.0 CEM kernel (16 images of 256x256, sharded over the ranks)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precision', action='store_true', help="skip the extra timing of the 'mixed' fp16 mode")
     ap.add_argument('--precision', default=None, choices=['mixed', 'split', 'f16x2', 'bf16', 'f16'],
@@ -279,6 +281,10 @@ def main(argv=None):
 
     if args.workload == 'c3':
         out = run_c3(args, dev, rank, world, dist, sync, max_over_ranks)
+    elif args.workload == 'c4':
+        out = run_c4(args, dev, rank, world, dist, sync, max_over_ranks)
+    elif args.workload == 'c5':
+        out = run_c5(args, dev, rank, world, dist, sync, max_over_ranks)
     else:
         out = run_c2(args, dev, rank, world, dist, sync, max_over_ranks)
     infos = rank_info()
@@ -473,5 +479,129 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
                                  'and all-reduce are in the denominator; per-owner GPU time of a step: profiles/*_c3_*_step_kernels.csv'}}
 
 
+def run_c4(args, dev, rank, world, dist, sync, max_over_ranks):
+    """configs[3]: latent search — Z_optimizer.optimize() iterations on 64 Z samples of 512x512 for one 128x128 LR image (RRDB-23 x4 lat 3 +
+    CEM eval: G on 148x148), objective STD_increase, Adam on Z.  One step = one iteration = forward with graph, CEM, objective, data gradient
+    through the frozen generator, Adam.  The Z samples are independent: sharded over the ranks, no data-path collective (one scalar
+    all-reduce per iteration for the loss history)."""
+    import contextlib
+    import io
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_paths
+    import models
+    from esr_hip import dist as D
+    from Z_optimization import Z_optimizer
+    precision = args.precision or 'split'
+    B = 64 if args.batch == BATCH else args.batch
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.create_model(bench_paths.make_opt(False))
+    net = model.netG.generated_image_model
+    net.set_precision(precision)
+    lr = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(3000)).to(dev)
+    lo, hi = D.shard_range(B)
+    model.feed_data({'LR': lr.expand(hi - lo, -1, -1, -1), 'Z': torch.zeros(hi - lo, 3, 512, 512, device=dev)}, need_GT=False)
+    model.test()
+    with contextlib.redirect_stdout(io.StringIO()):
+        zo = Z_optimizer(objective='STD_increase', Z_size=[512, 512], model=model, Z_range=1, max_iters=max(args.warmup, 1), data={'LR': lr, 'STD_increment': 0.01},
+                         initial_LR=0.1, batch_size=B)
+        zo.optimize()                           # warm-up iterations (records the launch lists)
+        zo.max_iters = args.steps
+        torch.cuda.reset_peak_memory_stats()
+        sync()
+        t0 = time.perf_counter()
+        zo.optimize()
+        sync()
+    dt, per_rank = max_over_ranks(time.perf_counter() - t0)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    if rank != 0:
+        return None
+    t_it = dt / args.steps
+    lr_px = B * 148 * 148                                    # LR pixels through G per iteration (SURVEY 8(d): 1,401,856 at B = 64)
+    flop = 2 * 2 * 18316944 * lr_px                          # forward + data gradient, RRDB-23 x4 lat 3
+    algo_bytes = 2 * 259984 * lr_px                          # layer-granular fp32-equivalent bytes of the two passes
+    terms = MFMA_TERMS.get(precision, 1)
+    return {'metric': 'HR pixels/sec of Z-search iterations (RRDB-23 x4 lat 3 + CEM, 64 Z samples of 512x512, forward + data gradient + Adam on Z)',
+            'value': B * 512 * 512 * args.steps / dt, 'unit': 'HR pixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t_it * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': DTYPE.get(precision, precision), 'data': 'synthetic',
+            'config': {'workload': 'configs[3]: Z_optimizer.optimize(), STD_increase, %d Z samples of 512x512 on one 128x128 LR image (G on 148x148), Adam lr 0.1; '
+                                   'the reference config runs 200 such iterations' % B,
+                       'global_batch': B, 'parallelism': 'dp%d (Z samples sharded, no data-path collective)' % world},
+            'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],
+            'seconds_for_200_iterations': 200 * t_it, 'loss_first_last': [float(zo.loss_values[0]), float(zo.loss_values[-1])], 'iterations_kept': len(zo.loss_values),
+            'peak_memory_GB': peak, 'activation_stash': net.engine.stash,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_tile_kernel (forward and data gradient of the frozen generator)', 'achieved': terms * flop / t_it / 1e12 / world,
+                         'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': terms * flop / t_it / 2.5e15 / world, 'traffic': None,
+                         'fp32_equiv_tflops': flop / t_it / 1e12 / world, 'algorithmic_bytes_per_iteration': algo_bytes,
+                         'hbm_frac': algo_bytes / t_it / HBM_PEAK / world,
+                         'note': 'MFMA issue rate over the WHOLE iteration (CEM, objective, Adam and the host in the denominator); per GPU'}}
+
+
+def run_c5(args, dev, rank, world, dist, sync, max_over_ranks):
+    """configs[4]: RRDB-23 x8 inference with a non-bicubic CEM kernel ('blurry_cubic_2.0': 45^2 / 35^2 taps, margin 12), 16 images of 256x256 ->
+    2048x2048, fp16 operands as the config names (--precision split for the fp32-class mode); images sharded over the ranks."""
+    import contextlib
+    import io
+    import torch
+    import CEM.CEMnet as CEMnet
+    import models.modules.architecture as arch
+    import models.networks as networks
+    from esr_hip import dist as D
+    precision = args.precision or 'f16'
+    B = 16 if args.batch == BATCH else args.batch
+    torch.manual_seed(0)
+    cem = CEMnet.CEMnet(CEMnet.Get_CEM_Conf(8), upscale_kernel='blurry_cubic_2.0')
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=NB, gc=32, upscale=8, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                       latent_input=None, num_latent_channels=0)
+    G = cem.WrapArchitecture_PyTorch(net)
+    with contextlib.redirect_stdout(io.StringIO()):
+        networks.init_weights(G, init_type='kaiming', scale=0.1)
+    G = G.to(dev).eval()
+    net.set_precision(precision)
+    lo, hi = D.shard_range(B)
+    x = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4000))[lo:hi].to(dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = G(x)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            net.engine._ev = (ev0[i], ev1[i])
+            y = G(x)
+        net.engine._ev = None
+        sync()
+        dt, per_rank = max_over_ranks(time.perf_counter() - t0)
+        d = G.DownscaleOP(y)
+    if rank != 0:
+        return None
+    m = int(cem.invalidity_margins_LR)
+    cons = float(((d - x)[..., m:-m, m:-m] ** 2).mean().sqrt())
+    t = dt / args.steps
+    conv_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))[len(ev0) // 2]
+    side = 256 + 2 * m
+    lr_px = (hi - lo) * side * side                                    # per rank
+    bytes_per_px = 313356 // (1 if precision in ('split', 'mixed') else 2)       # SURVEY 8(d): RRDB-23 x8, fp32 / fp16 elements
+    algo = lr_px * bytes_per_px
+    flop = 2 * 22138560 * lr_px
+    terms = MFMA_TERMS.get(precision, 1)
+    n_launch = 3 + NB * 15 + 3 + 1
+    return {'metric': 'HR pixels/sec (RRDB-23 x8, 256->2048, 16 images, fwd + CEM with the blurry_cubic_2.0 kernel)', 'value': B * 2048 * 2048 * args.steps / dt,
+            'unit': 'HR pixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': DTYPE.get(precision, precision), 'data': 'synthetic',
+            'config': {'workload': "configs[4]: RRDB-23 x8 SR forward, %d images of 256x256 -> 2048x2048, CEM with upscale_kernel='blurry_cubic_2.0' (eval: G on %dx%d)" % (B, side, side),
+                       'arithmetic': ARITHMETIC.get(precision, precision), 'global_batch': B, 'parallelism': 'dp%d (independent image shards, no data-path collective)' % world},
+            'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank], 'cem_consistency_rmse_interior': cons,
+            'cem_kernel_sizes': [int(cem.ds_kernel.shape[0]), int(cem.inv_hTh.shape[0])], 'peak_memory_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
+            'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (%d launches per forward)' % n_launch, 'achieved': algo / (conv_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9,
+                         'unit': 'GB/s', 'frac': algo / (conv_ms * 1e-3) / HBM_PEAK, 'traffic': None, 'algorithmic_bytes_per_forward_per_gpu': algo,
+                         'generator_ms_per_step': conv_ms, 'avg_launch_ms': conv_ms / n_launch,
+                         'mfma_issue_frac': terms * flop / (conv_ms * 1e-3) / 2.5e15,
+                         'note': 'layer-granular bytes at the element size the precision stores (SURVEY 8(d): 313,356 B per LR pixel in fp32, half in fp16); rank 0'}}
+
+
 if __name__ == '__main__':
     main()
+
