@@ -372,9 +372,6 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
             const int pl = NPW == 2 ? 1 : 0;
             if (ESR_TAP_LIVE(t, k)) fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
         } else if (k < MT + R) {
-#ifdef ESR_ABL_BREUSE                      // ablation (timing only): one activation read per tap ROW, the other two taps copy registers
-            if (t % 3 != 0) { fb[buf][k - MT][0] = fb[buf ^ 1][k - MT][0]; return; }
-#endif
             fb[buf][k - MT][0] = *(const uint4*)(sb + (k - MT) * NW * 512 + tapoff);
         } else if (NPW == 2 && k < 2 * MT + R) {
             const int idx = k - MT - R;
@@ -497,11 +494,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
-#ifdef ESR_ABL_TERMS
-    constexpr int NTERM_CAP = ESR_ABL_TERMS;   // ablation build: wrong results, timing only
-#else
     constexpr int NTERM_CAP = 3;
-#endif
     u32x4 wa[9 * MT];                                // (WREG) the current chunk's A fragments
     const uint4* const wbase = a.wpack + lane;       // fragment f of chunk cp: wbase + (cp * 9 * MT + f) * 64
     if (WREG) {
@@ -556,12 +549,6 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         if (NST == 1) {
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
             DmaShare sh = share;
-#ifdef ESR_ABL_NOWDMA
-            if (cp > 0) sh.wc = 0;
-#endif
-#ifdef ESR_ABL_NOADMA
-            if (cp > 0) sh.nsl = 0;
-#endif
             dma_chunk<NPL, MT, NPW>(fs, bs, sh, lds0, plane_bytes, xlo);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,16 +735,8 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
                                 const int sp = rg % r2;
                                 o = b * a.out.bs + (rg / r2) * a.out.cs + (long long)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1);
                             }
-#ifdef ESR_ABL_NOSTORE                     // ablation (timing only, wrong results): the epilogue computes but stores one pixel per wave
-                            if ((lane & 63) != 0) continue;
-#endif
-#ifdef ESR_ABL_NTSTORE                     // experiment: non-temporal stores (the next layer reads through L2 / MALL anyway)
-                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hv), &((u32x4*)a.out.hi)[o]);
-                            if (NPL == 2 && (!PARTLO || a.out.lo)) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, lv), &((u32x4*)a.out.lo)[o]);
-#else
                             ((uint4*)a.out.hi)[o] = hv;
                             if (NPL == 2 && (!PARTLO || a.out.lo)) ((uint4*)a.out.lo)[o] = lv;
-#endif
                             if (EPI & EPI_OUT2) {
                                 const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
                                 ((uint4*)a.out2.hi)[o2] = hv;
