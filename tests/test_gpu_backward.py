@@ -26,6 +26,13 @@ def assert_grad_close(got, ref, what=''):
     med = np.median(np.abs(got - ref)) / rms
     assert med < 2e-4, (what, 'median', med)
     assert rel_l2(got, ref) < 5e-2, (what, 'rel_l2', rel_l2(got, ref))
+    # ... and nothing systematic may hide behind the flips: the component of `got` along `ref` (a scale error of the whole gradient, or of
+    # a large part of it, shows here — a 1 % error on half of the elements moves it by 5e-3; flips are local and sign-indefinite) and the
+    # 90th percentile of the element errors (an error confined to a minority of the elements — borders, one channel group — shows here)
+    proj = float((got * ref).sum() / (ref * ref).sum())
+    assert abs(proj - 1) < 1e-3, (what, 'projection', proj)
+    p90 = np.percentile(np.abs(got - ref), 90) / rms
+    assert p90 < 3e-3, (what, 'p90', p90)
 
 
 def _cem(sf, kernel=None, bound=None):
