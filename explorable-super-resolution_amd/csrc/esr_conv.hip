@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     constexpr bool PC = NST == 3;                                  // producer / consumer waves
-    constexpr int NSTAGES = NST == 1 ? 1 : 2;
+    constexpr int NSTAGES = NST == 1 ? 1 : (NST == 4 ? 4 : 2);
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = PC && wave_all >= NW;
     const int wave = PC ? (wave_all % NW) : wave_all;
@@ -505,6 +505,15 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
         dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks);
     }
+    if (NST == 4) {                           // ring of four stages: chunks 0, 1, 2 in flight before the first multiply
+        static_assert(NST != 4 || !PARTLO, "the four-stage ring counts its copies per chunk: one count for all chunks");
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < a.ncp) {
+                const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, fs.b, lane);
+                dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + c * stage_bytes, plane_bytes, true);
+            }
+    }
     // (producer waves) issue all copies of chunk cp into its ring stage; returns how many this wave issued
     auto produce = [&](const int cp) {
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
     auto step = [&](auto XLO_T, const int cp) {
         constexpr bool xlo = decltype(XLO_T)::value;
-        const int st = PC ? cp % nstg : (NST >= 2 ? (cp & 1) : 0);
+        const int st = PC ? cp % nstg : (NST == 4 ? (cp & 3) : (NST >= 2 ? (cp & 1) : 0));
         const unsigned char* const sb = sb0 + st * stage_bytes;
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
@@ -552,6 +561,17 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
             dma_chunk<NPL, MT, NPW>(fs, bs, sh, lds0, plane_bytes, xlo);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (NST == 4) {
+            // NST == 4 (launches of few, small tiles with a long K axis — the critic's 512-channel layers on 8x8 / 4x4 maps): each chunk is a
+            // handful of MFMAs behind a copy round trip, so the round trips of THREE chunks are kept in flight.  The stage refilled now
+            // (chunk cp + 3) was last read in iteration cp - 1, closed by its trailing barrier.
+            if (cp + 3 < a.ncp) {
+                const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 3, fs.b, lane);
+                dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + ((cp + 3) & 3) * stage_bytes, plane_bytes, true);
+            }
+            const int ahead = a.ncp - 1 - cp < 3 ? a.ncp - 1 - cp : 3;         // chunks behind cp that stay in flight
+            ESR_TR();
+            wait_vm_upto(ahead * dma_count<NPL>(share, true));
         } else if (cp + 1 < a.ncp) {
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
             // everything EXCEPT the copies just issued
@@ -872,7 +892,7 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
     ConvArgs b = a;
     b.pc_stages = (NST == 3 && 3 * stage + (size_t)MT * 32 * 4 <= 160 * 1024) ? 3 : 2;
-    const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : 2)) * stage + (size_t)MT * 32 * 4;
+    const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : (NST == 4 ? 4 : 2))) * stage + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
@@ -892,6 +912,11 @@ int launch(const ConvArgs& a, hipStream_t s) {
         if (force == 3) return launch_nst<NPL, MT, EPI, 3, FMT, NPW, PARTLO>(a, s);
     }
 #endif
+    // few small tiles, long K: the four-stage ring where it fits (plain bf16 kernels — what the critic's deep layers launch)
+    if constexpr (EPI == 0 && !PARTLO && FMT == 0 && !wreg_of(NPW) && MT == 2) {
+        const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
+        if (!force && small && a.ncp >= 16 && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
+    }
     const bool two = force ? force == 2 : small;
     return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
 }

@@ -70,6 +70,12 @@ if os.environ.get('ESR_CRITIC_MASKS') == '0':          # experiments: multiply t
 
 
 def view_of(t, cg0=0, ncg=None):
+    if getattr(t, '_esr_stacked', False):              # [planes][CG][B][H+2][W+2][8]: see stacked_at()
+        P, CG, B, Hp, Wp, _ = t.shape
+        n = CG - cg0 if ncg is None else ncg
+        cs = B * Hp * Wp
+        hi = t.data_ptr() + cg0 * cs * 16
+        return ActView(hi, hi + t.stride(0) * 2 if P == 2 else None, n, Hp - 2, Wp - 2, Hp * Wp, cs, 0)
     P, B, CG, Hp, Wp, _ = t.shape
     n = CG - cg0 if ncg is None else ncg
     cs = Hp * Wp
@@ -77,6 +83,40 @@ def view_of(t, cg0=0, ncg=None):
     hi = t.data_ptr() + off
     lo = hi + t.stride(0) * 2 if P == 2 else None
     return ActView(hi, lo, n, Hp - 2, Wp - 2, CG * cs, cs, 0)
+
+
+def stacked_at(planes, B, ncg, H, W, device):
+    """Group-major activation tensor [planes][CG][B][H+2][W+2][8] for SMALL feature maps: the B images of one channel group are stacked
+    vertically, each with its own zero border rows, so that the whole batch is ONE image of B*(H+2) - 2 rows to a conv launch (tall_view):
+    a tile then spans several images, and the layer's weights are fetched once per ~384 pixels instead of once per 16- or 64-pixel image.
+    The rows between two images are their bottom / top borders: zero in every conv INPUT (the producers write them), garbage in conv
+    OUTPUTS (which are only ever read at interior pixels)."""
+    t = torch.empty(planes, ncg, B, H + 2, W + 2, 8, dtype=torch.bfloat16, device=device)
+    t._esr_stacked = True
+    return t
+
+
+def tall_view(t):
+    """The stacked tensor as one image per channel group (B' = 1): (view, rows)."""
+    P, CG, B, Hp, Wp, _ = t.shape
+    cs = B * Hp * Wp
+    hi = t.data_ptr()
+    rows = B * Hp - 2
+    return ActView(hi, hi + t.stride(0) * 2 if P == 2 else None, CG, rows, Wp - 2, cs * CG, cs, 0), rows
+
+
+def conv_io(t_in, t_out, B, h, w):
+    """(input view, output view, B', H', W') of a conv launch over `t_in` -> `t_out`: per image, or the whole stacked batch as one image."""
+    if getattr(t_in, '_esr_stacked', False):
+        assert getattr(t_out, '_esr_stacked', False)
+        vi, rows = tall_view(t_in)
+        vo, rows_o = tall_view(t_out)
+        assert rows == rows_o
+        return vi, vo, 1, rows, w
+    return view_of(t_in), view_of(t_out), B, h, w
+
+
+STACK_MAX = int(os.environ.get('ESR_CRITIC_STACK', '8'))       # feature maps up to this height are stacked (0: never)
 
 
 class _Layer:
@@ -496,7 +536,7 @@ class _BufSet:
         P = eng.planes
         self.key = (B, Cin, H, W, P)
         self.B, self.in_shape, self.dev = B, (B, Cin, H, W), device
-        mk = lambda ncg, h, w: new_at(P, B, ncg, h, w, device)
+        mk = lambda ncg, h, w: stacked_at(P, B, ncg, h, w, device) if h <= STACK_MAX else new_at(P, B, ncg, h, w, device)
         self.t0, self.ut0, self.dx0 = mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W)
         self.y, self.z, self.dy, self.gdy, self.g_y, self.dz, self.g_dz, self.s2d, self.hw = [], [], [], [], [], [], [], [], []
         h, w = H, W
@@ -654,7 +694,8 @@ def _fwd_pass(eng, x, training):
             h, w = bs.hw[i]
             y, z = bs.y[i], bs.z[i]
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
-            A.conv3x3(L.fwd, view_of(t), B, h, w, L.cout, out=view_of(y), reverse=False, **kw)
+            vi, vo, Bc, hc, wc = conv_io(t, y, B, h, w)
+            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, **kw)
             st = bs.stats(eng, i, training)
             if L.bn is not None and training:
                 bn = L.bn
@@ -684,7 +725,8 @@ class _WgradSet:
         descs, off = [], 0
         for (L, dy, xin), n in zip(pairs, self.sizes):
             nw = L.cout * L.cin_e * 9
-            d, _, _ = A.wgrad_desc(view_of(dy), view_of(xin), None, 0, (L.cout, L.cin_e, 3, 3), bs.B, dy.shape[3] - 2, dy.shape[4] - 2, 1.0, 1, bs.dev,
+            vx, vdy, Bc, hc, wc = conv_io(xin, dy, bs.B, dy.shape[3] - 2, dy.shape[4] - 2)       # (stacked maps: one tall image; their borders are zero)
+            d, _, _ = A.wgrad_desc(vdy, vx, None, 0, (L.cout, L.cin_e, 3, 3), Bc, hc, wc, 1.0, 1, bs.dev,
                                    out=(flat[off:off + nw], flat[off + nw:off + n]), tap_masks=MASK_FWD if (L.strided and MASK_FWD) else None)
             descs.append(d)
             off += n
@@ -769,7 +811,8 @@ def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
             if i > 0 or want_dx:
                 dx = bs.dz[i - 1] if i > 0 else bs.dx0
                 kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}
-                A.conv3x3(L.tr, view_of(dy), B, h, w, L.cin_e, out=view_of(dx), use_bias=False, reverse=False, **kw)
+                vi, vo, Bc, hc, wc = conv_io(dy, dx, B, h, w)
+                A.conv3x3(L.tr, vi, Bc, hc, wc, L.cin_e, out=vo, use_bias=False, reverse=False, **kw)
         if want_dx:
             rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(bs.dx0), B, bs.in_shape[1], dx_in.data_ptr()), ('dst',))
     _replay(bs, ('bwd', training, d_feat is not None, inj, want_dx, pg is not None), ext, build)
@@ -807,7 +850,8 @@ def _bwd2_pass(eng, S, u, want_params):
             h, w = bs.hw[i]
             st = bs.stats(eng, i, training)
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
-            A.conv3x3(L.fwd, view_of(ut), B, h, w, L.cout, out=view_of(gdy), use_bias=False, reverse=False, **kw)
+            vi, vo, Bc, hc, wc = conv_io(ut, gdy, B, h, w)
+            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, use_bias=False, reverse=False, **kw)
             if not st.const:
                 _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy), 2, st.sums3)
                 if i in g_gammas:
