@@ -622,14 +622,17 @@ class RRDBEngine:
                 G = G_cur
                 name = 'rrdb%d.rdb%d' % (r, k)
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
-                if need_dw:
+                per_layer = need_dw and not wg.use_rdb
+                if per_layer:
                     wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
                 for c in (3, 2, 1, 0):
                     g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
                     conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
                          mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
-                    if need_dw:
+                    if per_layer:
                         wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
+                if need_dw and not per_layer:         # G' is complete: the block's five weight gradients as one work item list
+                    wg.rdb(name, G.view(0, 24), X.view(0, 24), zview('zlr') if lat else None, h, w, s_out, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
                     conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
@@ -705,6 +708,9 @@ class WGrad:
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
         self.descs, self.keep, self.permuted = [], [], []
+        # dense blocks go to the block-level launch (esr_wgrad_rdb_*: one input tile against all the output tiles that pair with it);
+        # ESR_WGRAD_RDB=0: every layer through the per-pair batched launch
+        self.rdb_descs, self.use_rdb = [], os.environ.get('ESR_WGRAD_RDB', '1') != '0'
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0
@@ -714,6 +720,33 @@ class WGrad:
             self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(self.mods.values())).weight.device)
             self._sizes = [k for c in self.mods.values() for k in (c.weight.numel(), c.weight.shape[0])]
             self._params = [(c.weight, c.bias) for c in self.mods.values()]
+
+    def rdb(self, name, G, X, x_lat, H, W, s_out, keep=()):
+        """All five convs of dense block `name` ('rrdbR.rdbK'): X its 24-group activation buffer view, G its 24-group gradient buffer view
+        [dy conv4 | dy conv3 | dy conv2 | dy conv1 | dy conv0] (complete when this is called), s_out the scale of its output in the RRDB sum."""
+        if not self.enabled:
+            return
+        if self.hi_only:
+            G, X, x_lat = A.hi_plane(G), A.hi_plane(X), A.hi_plane(x_lat)
+        d = _lib.WgradRdbDesc()
+        d.x, d.g = X, G
+        lat = self.lats[name + '.conv0'] if x_lat is not None else 0
+        d.z = x_lat if x_lat is not None else A.NO_VIEW
+        d.lat, d.B, d.H, d.W = lat, self.B, H, W
+        for i in range(5):
+            lname = '%s.conv%d' % (name, i)
+            c = self.mods[lname]
+            o, nw, co = self.offsets[lname], c.weight.numel(), c.weight.shape[0]
+            assert c.weight.shape[1] == lat + 64 + 32 * i and co == (64 if i == 4 else 32)
+            dw, db = self.flat[o:o + nw].view(c.weight.shape), self.flat[o + nw:o + nw + co]
+            d.dw[i], d.db[i], d.alpha[i] = dw.data_ptr(), db.data_ptr(), (0.2 * s_out if i == 4 else 1.0)
+            if self.gscale is not None:
+                self.scaled.append((o, nw + co, self.gscale))
+            self.grads[c.weight] = dw
+            if c.bias is not None:
+                self.grads[c.bias] = db
+        self.rdb_descs.append(d)
+        self.keep.extend(keep)
 
     def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=(), rows=None):
         """rows: dy's channels are a permutation of the layer's output channels (pixel-shuffle convs): dy channel i is output channel rows[i]."""
@@ -741,25 +774,47 @@ class WGrad:
         else:
             self.keep.append(db)
 
+    def _rdb_upload(self, dev):
+        """Upload the dense blocks' descriptor table: (workspace tensor, plan)."""
+        arr = (_lib.WgradRdbDesc * len(self.rdb_descs))(*self.rdb_descs)
+        need = _lib.lib.esr_wgrad_rdb_workspace_bytes(len(arr))
+        _lib.check(min(need, 0), 'esr_wgrad_rdb_workspace_bytes')
+        ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        plan = _lib.WgradRdbPlan()
+        _lib.check(_lib.lib.esr_wgrad_rdb_upload(arr, len(arr), ws.data_ptr(), ws.numel(), C.byref(plan), A.stream_ptr()), 'esr_wgrad_rdb_upload')
+        return ws, plan
+
     def result(self):
-        if self.enabled and self.descs:
+        if self.enabled and (self.descs or self.rdb_descs):
             rec = A._rec()
+            dev = self.flat.device
             if rec is not None:
-                # recorded pass: the descriptor table goes to the device now, its launch into the list; rebind() serves the replays
-                self._arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
+                # recorded pass: the descriptor tables go to the device now, their launches into the list; rebind() serves the replays
                 self._flat_ptr = self.flat.data_ptr()
-                need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self._arr, len(self.descs))
-                _lib.check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
-                self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.flat.device)
-                self._upload()
-                rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(self._ws.data_ptr(), self._plan))
+                self._ws = self._plan = self._rdb_ws = self._rdb_plan = None
+                if self.descs:
+                    self._arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
+                    need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self._arr, len(self.descs))
+                    _lib.check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+                    self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                    self._upload()
+                    rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(self._ws.data_ptr(), self._plan))
+                    rec.keep.append(self._ws)
+                if self.rdb_descs:
+                    self._rdb_ws, self._rdb_plan = self._rdb_upload(dev)
+                    rec.emit(_lib.OP_WGRAD_RDB_RUN, _lib.CmdWgradRdbRun(self._rdb_ws.data_ptr(), self._rdb_plan))
+                    rec.keep.append(self._rdb_ws)
                 rec.keep.extend(self.keep)
-                rec.keep.append(self._ws)
                 assert not self.permuted and not self.scaled
-                self._n, self._dev = self.flat.numel(), self.flat.device
-                grads, self.descs, self.keep, self.flat, self.grads = self.grads, [], [], None, None      # hold no reference to a step's gradients
+                self._n, self._dev = self.flat.numel(), dev
+                grads, self.descs, self.rdb_descs, self.keep, self.flat, self.grads = self.grads, [], [], [], None, None      # hold no reference to a step's gradients
                 return grads
-            A.conv3x3_wgrad_batch(self.descs, next(iter(self.grads)).device, cache=self.engine._wgb)
+            if self.descs:
+                A.conv3x3_wgrad_batch(self.descs, dev, cache=self.engine._wgb)
+            if self.rdb_descs:
+                ws, plan = self._rdb_upload(dev)
+                _lib.check(_lib.lib.esr_wgrad_rdb_run(ws.data_ptr(), C.byref(plan), A.stream_ptr()), 'esr_wgrad_rdb_run')
+                self.keep.append(ws)
             for (tdw, tdb), (dw, db), rows in self.permuted:
                 dw.index_copy_(0, rows, tdw)
                 db.index_copy_(0, rows, tdb)
@@ -772,7 +827,7 @@ class WGrad:
                     runs.append([o, n, g])
             for o, n, g in runs:
                 self.flat[o:o + n].div_(g)
-            self.descs, self.keep = [], []
+            self.descs, self.rdb_descs, self.keep = [], [], []
         return self.grads
 
     def _upload(self):
@@ -787,8 +842,11 @@ class WGrad:
             return None
         flat = torch.zeros(self._n, dtype=torch.float32, device=self._dev)
         delta = flat.data_ptr() - self._flat_ptr
-        if delta:             # the table's dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
-            _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self._ws.data_ptr(), C.byref(self._plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
+        if delta:             # the tables' dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
+            if self._ws is not None:
+                _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self._ws.data_ptr(), C.byref(self._plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
+            if self._rdb_ws is not None:
+                _lib.check(_lib.lib.esr_wgrad_rdb_rebase(self._rdb_ws.data_ptr(), C.byref(self._rdb_plan), delta, A.stream_ptr()), 'esr_wgrad_rdb_rebase')
             self._flat_ptr += delta
         parts = flat.split(self._sizes)
         grads = {}
