@@ -708,9 +708,10 @@ class WGrad:
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
         self.descs, self.keep, self.permuted = [], [], []
-        # dense blocks go to the block-level launch (esr_wgrad_rdb_*: one input tile against all the output tiles that pair with it);
-        # ESR_WGRAD_RDB=0: every layer through the per-pair batched launch
-        self.rdb_descs, self.use_rdb = [], os.environ.get('ESR_WGRAD_RDB', '1') != '0'
+        # ESR_WGRAD_RDB=1: dense blocks through the block-level launch (esr_wgrad_rdb_*: one input tile against all the output tiles that
+        # pair with it).  Correct (same tests) and a third of the on-chip operand traffic, but measured 9-18 % SLOWER than the per-pair
+        # batched launch at the configs[2] shape (7.3 + 0.6 vs 6.7 ms in bf16) — off by default.
+        self.rdb_descs, self.use_rdb = [], os.environ.get('ESR_WGRAD_RDB', '0') == '1'
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0

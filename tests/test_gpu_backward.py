@@ -439,3 +439,21 @@ def test_gradients_meet_the_bar_under_the_gpu_activation_pattern(nb, sf, lat):
         worst = max(worst, e)
         assert e < 1e-3, (k, e)
     print('flips %d of %d activations; dx rel_l2 %.2e; worst parameter-gradient rel_l2 %.2e' % (flips, sum(s.numel() for s in stored), rel_l2(dx.cpu().numpy(), xg.grad.numpy()), worst))
+
+
+@pytest.mark.parametrize('precision', ['split', 'bf16'])
+def test_block_level_weight_gradient_matches_the_per_pair_launch(precision, monkeypatch):
+    """esr_wgrad_rdb_* (a dense block's five weight gradients from one work decomposition: one input tile against all the output tiles that pair
+    with it) against esr_conv3x3_wgrad_batch (one workgroup per pair) on the same backward pass: same dW / db up to summation order."""
+    outs = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('ESR_WGRAD_RDB', flag)
+        net = _rrdb(2, 4, 3).to(DEV)
+        net.set_precision(precision)
+        x = seeded_uniform((3, 3 + 3 * 16, 20, 37), 1301, -1.0, 1.0).to(DEV)
+        y = net(x)
+        (y * seeded_uniform(tuple(y.shape), 1302, -1.0, 1.0).to(DEV)).sum().backward()
+        outs[flag] = {n: p.grad.clone() for n, p in net.named_parameters()}
+    for n in outs['0']:
+        a, b = outs['1'][n].double(), outs['0'][n].double()
+        assert float((a - b).norm()) <= 2e-5 * max(float(b.norm()), 1e-6 * float(max(v.norm() for v in outs['0'].values()))), n
