@@ -149,6 +149,11 @@ __device__ __forceinline__ void glds16(const uint4* src, unsigned lds_dst) {
     // (readfirstlane: the destination is wave-uniform by construction, but the compiler cannot always prove it and M0 takes a scalar)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
+// the same copy with the source given as a uniform base (SGPR pair) + a per-lane 32-bit byte offset: no 64-bit per-lane address arithmetic per
+// copy (the offsets of a tile's slots are computed once per tile, the bases once per chunk)
+__device__ __forceinline__ void glds16s(const uint4* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
 // (their packed weights are zero, the data only has to be finite)
@@ -206,7 +211,7 @@ __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int 
     Bases<NPL> r;
 #pragma unroll
     for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
-    r.w = a.wpack + (size_t)cp * (9 * MT * NPW) * 64 + lane;
+    r.w = a.wpack + (size_t)cp * (9 * MT * NPW) * 64;          // uniform: the lane's 16 bytes are the copy's per-lane offset
     return r;
 }
 
@@ -246,14 +251,16 @@ __device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>&
     for (int s = 0; s < MAXS; ++s) {
         if (s >= d.nsl) break;                          // wave-uniform
         const int so = f.soff[s];
+        const unsigned vo = (unsigned)so * 16;
         const unsigned dst = stage + (unsigned)f.slot[s] * 1024;
 #pragma unroll
         for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
             if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
-            if (so >= 0) glds16(bs.p[cgpl] + so, dst + cgpl * plane_bytes);
+            if (so >= 0) glds16s(bs.p[cgpl], vo, dst + cgpl * plane_bytes);
         }
     }
-    for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16(bs.w + j * 64, stage + 2 * NPL * plane_bytes + j * 1024);
+    const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
+    for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
