@@ -2,8 +2,8 @@
 """Steady-state per-step kernel summary of a training-step profile (rocprofv3 --kernel-trace of `bench.py --workload c3`).
 
 rocprofv3's own --stats table covers the whole process, including MIOpen's one-off kernel search / naive fallbacks during the first steps.
-This script cuts the trace at the generator's batched weight-gradient launches (exactly one per step) and aggregates the LAST `--steps`
-complete steps: per kernel name, launches per step, average duration, milliseconds per step.
+This script cuts the trace at a kernel launched exactly once per step (`--marker`, default the CEM's down-scaling pass of the generator
+forward; the batched weight-gradient kernel no longer qualifies since the critic uses it too) and aggregates the LAST `--steps` complete steps: per kernel name, launches per step, average duration, milliseconds per step.
 
     python tools/summarise_step_trace.py --trace <dir with *_kernel_trace.csv> --tag r02_c3_bf16 [--steps 4]
 """
@@ -28,12 +28,13 @@ def main():
     ap.add_argument('--trace', required=True)
     ap.add_argument('--tag', required=True)
     ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--marker', default='cem_downscale_sep_kernel')
     a = ap.parse_args()
     f = glob.glob(os.path.join(a.trace, '**', '*_kernel_trace.csv'), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-    marks = [i for i, r in enumerate(rows) if 'conv3x3_wgrad_batch_kernel' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(rows) if a.marker in r['Kernel_Name']]
     assert len(marks) > a.steps, 'not enough steps in the trace'
-    lo, hi = marks[-a.steps - 1] + 1, marks[-1] + 1
+    lo, hi = marks[-a.steps - 1], marks[-1]
     window = rows[lo:hi]
     span = (int(window[-1]['End_Timestamp']) - int(window[0]['Start_Timestamp'])) / 1e6 / a.steps
     per = collections.OrderedDict()
@@ -53,7 +54,7 @@ def main():
         groups = collections.OrderedDict((g, 0) for g in ('esr_hip conv / wgrad / pack / CEM', 'MIOpen + CK convolutions', 'MIOpen batch norm',
                                                             'layout transposes', 'torch element-wise / reductions / copies', 'other'))
         for k, (n, t) in per.items():
-            if re.match(r'(conv3x3_|pack_|cem_|act_|unpack_|grad_|pixel_|soft_hist|zero_)', k): g = 'esr_hip conv / wgrad / pack / CEM'
+            if re.match(r'(conv3x3_|pack_|cem_|act_|unpack_|grad_|pixel_|soft_hist|zero_|bn_|adam_|wgrad_|img_|tv_|struct)', k): g = 'esr_hip conv / wgrad / pack / CEM'
             elif 'igemm' in k or 'grouped_conv' in k or 'Conv' in k or 'gemm' in k.lower() or 'Cijk' in k: g = 'MIOpen + CK convolutions'
             elif 'BatchNorm' in k: g = 'MIOpen batch norm'
             elif 'transpose' in k: g = 'layout transposes'
