@@ -176,7 +176,9 @@ def newest_pmc_mfma(precision):
     (tools/pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE in separate rocprofv3 --pmc passes) — static, like roofline.traffic."""
     import glob
     import re
-    fs = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')) if json.load(open(f)).get('precision') == precision),
+    # only summaries of the shipping kernel: r<round>_v<n>_<precision>_pmc_mfma.json (experiment variants carry a suffix after the precision)
+    fs = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json'))
+                 if re.fullmatch(r'r\d+_v\d+_%s_pmc_mfma\.json' % precision, os.path.basename(f))),
                 key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])
     if not fs:
         return None, None

@@ -116,6 +116,11 @@ struct ConvArgs {
     int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
     int nslices;                    // cout / 64 when cout > 64, else 1
     long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
+    // split K (esr_conv3x3_desc.k_split_ws): blockIdx.z = which run of `ncp` chunks (kz_groups channel groups) of the input this workgroup
+    // contracts; its fp32 partial sums go to slab z of the workspace ([B][nchw_ctot][H][W] each, EPI_NCHW store), bias in slab 0 only
+    int ksplit, kz_groups;
+    long long kz_slab;              // floats between two slabs
+    int nchw_ctot;                  // channels of the fp32 NCHW destination (== cout unless the launch covers output slices)
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -241,11 +246,17 @@ __device__ __forceinline__ DmaShare dma_share(int npix_l, int wave) {
     return d;
 }
 // number of copies dma_chunk() issues (for the counted waits of the two-stage kernels)
-template <int NPL>
-__device__ __forceinline__ int dma_count(const DmaShare& d, bool xlo) { return (xlo ? 2 * NPL : 2) * d.nsl + d.wc; }
+// TMODE != 0 (tap-masked kernels): only the 4 * MT * NPW fragments of the chunk's live taps are copied, wave k those of the k-th live tap
+// (per M tile: its own k-th live tap) — MT * NPW copies per wave whatever the chunk's tap set is
+template <int NPL, int MT = 1, int NPW = 1, int TMODE = 0>
+__device__ __forceinline__ int dma_count(const DmaShare& d, bool xlo) { return (xlo ? 2 * NPL : 2) * d.nsl + (TMODE != 0 ? MT * NPW : d.wc); }
 
-template <int NPL, int MT, int NPW>
-__device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo) {
+// tsel (TMODE 1: the chunk's tap-set index (cp >> 1) & 3; TMODE 2: parity of the output slice): the live taps of an embedded stride-2 conv are
+// the 2x2 block of taps at (r0, c0): S2D_FWD[q] -> (1 - (q >> 1), 1 - (q & 1)), S2D_FLIP[q] -> (q >> 1, q & 1) with q = 2 * parity + m.  The dead
+// taps' fragments (5 of 9: zeros in the pack) are neither copied nor read — on the 512-channel layers the weight copies ARE the launch.
+template <int NPL, int MT, int NPW, int TMODE = 0>
+__device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo,
+                                          int tsel = 0, int wave = 0) {
     constexpr int MAXS = maxs_of(MT);
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
@@ -260,7 +271,21 @@ __device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>&
         }
     }
     const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
-    for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+    if constexpr (TMODE == 0) {
+        for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+    } else {
+        static_assert(TMODE == 0 || NW == 4, "one live tap per wave");
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r0 = TMODE == 1 ? 1 - (tsel >> 1) : tsel, c0 = TMODE == 1 ? 1 - (tsel & 1) : m;
+            const int tap = (r0 + (wave >> 1)) * 3 + c0 + (wave & 1);
+#pragma unroll
+            for (int pl = 0; pl < NPW; ++pl) {
+                const int j = (tap * MT + m) * NPW + pl;
+                glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+            }
+        }
+    }
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
@@ -449,6 +474,17 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         if (a.bias) a.bias += sl * 64;
         auto shift = [&](DView& v) { if (v.hi) { v.hi += sl * 8 * v.cs; if (v.lo) v.lo += sl * 8 * v.cs; } };
         shift(a.out); shift(a.out2); shift(a.res1); shift(a.res2); shift(a.mask);
+        if constexpr ((EPI & EPI_NCHW) != 0) {
+            a.out_nchw += sl * 64 * (long long)a.H * a.W;           // (slices with an fp32 destination: the split-K partial sums, B == 1 per image row below)
+            if (a.ksplit > 1) {
+                const long long kz = blockIdx.z;
+                a.in1.hi += kz * a.kz_groups * a.in1.cs;
+                if (a.in1.lo) a.in1.lo += kz * a.kz_groups * a.in1.cs;
+                a.wpack += kz * a.ncp * (9 * MT * NPW * 64);
+                a.out_nchw += kz * a.kz_slab;
+                if (kz) a.bias = nullptr;
+            }
+        }
     }
     // PARTLO: only the first a.lo_chunks chunks of the input carry a lo plane (a dense block's trunk input), the rest are single-plane
     // intermediates; and the output's lo plane is optional.  Non-PARTLO kernels treat every chunk alike.
@@ -502,6 +538,9 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
     constexpr int NTERM_CAP = 3;
+    static_assert(TMODE == 0 || !WREG, "the tap-masked kernels stage their weights through LDS");
+    // which 2x2 block of taps chunk c's weights live in (dma_chunk)
+    auto tsel_of = [&](const int c) { return TMODE == 1 ? ((c >> 1) & 3) : (TMODE == 2 ? (int)(blockIdx.y & 1) : 0); };
     u32x4 wa[9 * MT];                                // (WREG) the current chunk's A fragments
     const uint4* const wbase = a.wpack + lane;       // fragment f of chunk cp: wbase + (cp * 9 * MT + f) * 64
     if (WREG) {
@@ -510,7 +549,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     }
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
-        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks);
+        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks, tsel_of(0), wave);
     }
     if (NST == 4) {                           // ring of four stages: chunks 0, 1, 2 in flight before the first multiply
         static_assert(NST != 4 || !PARTLO, "the four-stage ring counts its copies per chunk: one count for all chunks");
@@ -518,15 +557,15 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         for (int c = 0; c < 3; ++c)
             if (c < a.ncp) {
                 const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, fs.b, lane);
-                dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + c * stage_bytes, plane_bytes, true);
+                dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + c * stage_bytes, plane_bytes, true, tsel_of(c), wave);
             }
     }
     // (producer waves) issue all copies of chunk cp into its ring stage; returns how many this wave issued
     auto produce = [&](const int cp) {
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
         const bool xl = !PARTLO || cp < a.lo_chunks;
-        dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (cp % nstg) * stage_bytes, plane_bytes, xl);
-        return dma_count<NPL>(share, xl);
+        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + (cp % nstg) * stage_bytes, plane_bytes, xl, tsel_of(cp), wave);
+        return dma_count<NPL, MT, NPW, TMODE>(share, xl);
     };
     if (PC) {
         if (producer) {
@@ -565,7 +604,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         if (NST == 1) {
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
             DmaShare sh = share;
-            dma_chunk<NPL, MT, NPW>(fs, bs, sh, lds0, plane_bytes, xlo);
+            dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, sh, lds0, plane_bytes, xlo, tsel_of(cp), wave);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (NST == 4) {
@@ -574,19 +613,19 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
             // (chunk cp + 3) was last read in iteration cp - 1, closed by its trailing barrier.
             if (cp + 3 < a.ncp) {
                 const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 3, fs.b, lane);
-                dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + ((cp + 3) & 3) * stage_bytes, plane_bytes, true);
+                dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + ((cp + 3) & 3) * stage_bytes, plane_bytes, true, tsel_of(cp + 3), wave);
             }
             const int ahead = a.ncp - 1 - cp < 3 ? a.ncp - 1 - cp : 3;         // chunks behind cp that stay in flight
             ESR_TR();
-            wait_vm_upto(ahead * dma_count<NPL>(share, true));
+            wait_vm_upto(ahead * dma_count<NPL, MT, NPW, TMODE>(share, true));
         } else if (cp + 1 < a.ncp) {
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
             // everything EXCEPT the copies just issued
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 1, fs.b, lane);
             const bool xlo_next = !PARTLO || cp + 1 < a.lo_chunks;
-            dma_chunk<NPL, MT, NPW>(fs, bs, share, lds0 + (st ^ 1) * stage_bytes, plane_bytes, xlo_next);
+            dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + (st ^ 1) * stage_bytes, plane_bytes, xlo_next, tsel_of(cp + 1), wave);
             ESR_TR();
-            wait_vm_upto(dma_count<NPL>(share, xlo_next));
+            wait_vm_upto(dma_count<NPL, MT, NPW, TMODE>(share, xlo_next));
         } else {
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -723,7 +762,7 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
 #pragma unroll
                                 for (int i = 0; i < 4; ++i)
                                     if (ch0 + i < a.cout)
-                                        a.out_nchw[((long long)(b * a.cout + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
+                                        a.out_nchw[((long long)(b * a.nchw_ctot + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
                             }
                             continue;                                    // the fp32 NCHW destination replaces the act-layout one
                         }
@@ -902,7 +941,7 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : (NST == 4 ? 4 : 2))) * stage + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -911,7 +950,7 @@ template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO, int TMODE = 0
 int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
-    const int ntiles = a.tiles_x * a.tiles_y * a.B * (a.wslice ? a.nslices : 1);
+    const int ntiles = a.tiles_x * a.tiles_y * a.B * (a.wslice ? a.nslices : 1) * (a.ksplit > 1 ? a.ksplit : 1);
     static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
     const bool small = ntiles <= 320;
 #if ESR_PC
@@ -920,9 +959,9 @@ int launch(const ConvArgs& a, hipStream_t s) {
     }
 #endif
     // few small tiles, long K: the four-stage ring where it fits (plain bf16 kernels — what the critic's deep layers launch)
-    if constexpr (EPI == 0 && !PARTLO && FMT == 0 && !wreg_of(NPW) && MT == 2) {
+    if constexpr ((EPI == 0 || EPI == EPI_NCHW) && !PARTLO && FMT == 0 && !wreg_of(NPW) && MT == 2) {
         const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
-        if (!force && small && a.ncp >= 16 && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
+        if (!force && small && a.ncp >= (EPI == EPI_NCHW ? 8 : 16) && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
     }
     const bool two = force ? force == 2 : small;
     return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
@@ -956,6 +995,31 @@ int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
         case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW, PARTLO>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
+}
+
+// split K, second launch: out = sum of the S fp32 partial slabs (fixed order: the result does not depend on scheduling), stored as bf16 hi [+ lo]
+// at the interior pixels like the conv epilogue does.  One thread per (b, group, y, x): 8 channels x S coalesced reads, one 16-byte store per plane.
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, int S, long long slab, DView out, int C, int H, int W, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    long long t = idx / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int ncg = C >> 3;
+    const int cg = (int)(t % ncg);
+    const int b = (int)(t / ncg);
+    uint32_t vh[8], vl[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float* p = ws + ((long long)(b * C + cg * 8 + e) * H + y) * W + x;
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += p[k * slab];
+        split_bf16(v, vh[e], vl[e]);
+    }
+    const long long o = b * out.bs + cg * out.cs + (long long)(y + 1) * (W + 2) + (x + 1);
+    ((uint4*)out.hi)[o] = make_uint4(vh[0] | (vh[1] << 16), vh[2] | (vh[3] << 16), vh[4] | (vh[5] << 16), vh[6] | (vh[7] << 16));
+    if (out.lo) ((uint4*)out.lo)[o] = make_uint4(vl[0] | (vl[1] << 16), vl[2] | (vl[3] << 16), vl[4] | (vl[5] << 16), vl[6] | (vl[7] << 16));
 }
 
 }  // namespace
@@ -1093,6 +1157,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.out2 = to_dview(d->out2);
     a.mask = to_dview(d->mask_src);
     a.out_nchw = d->out_nchw;
+    a.nchw_ctot = d->cout;
     a.mask_cg0 = d->mask_cg0;
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
@@ -1145,9 +1210,44 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     auto all9 = [](const int32_t (&m)[4]) { return (m[0] == 0 || m[0] == 0x1FF) && (m[1] == 0 || m[1] == 0x1FF) && (m[2] == 0 || m[2] == 0x1FF) && (m[3] == 0 || m[3] == 0x1FF); };
     auto same = [](const int32_t (&m)[4], const int (&p)[4]) { return m[0] == p[0] && m[1] == p[1] && m[2] == p[2] && m[3] == p[3]; };
     const bool plain = epi == 0 && !f16 && !partlo && mt == 2 && a.in0.ncg == 0;
-    if (plain && same(d->tap_mask_k, S2D_FWD) && d->tap_mask_k_shift == 1 && all9(d->tap_mask_m) && (a.in1.ncg % 4) == 0)
+    const bool tm1 = plain && same(d->tap_mask_k, S2D_FWD) && d->tap_mask_k_shift == 1 && all9(d->tap_mask_m) && (a.in1.ncg % 4) == 0;
+    const bool tm2 = plain && !tm1 && same(d->tap_mask_m, S2D_FLIP) && all9(d->tap_mask_k);
+    // split K (k_split_ws): launches of few workgroups with a long K axis — the critic's 256- / 512-channel layers on 16x16 ... 4x4 maps are 24-100
+    // workgroups walking 32-128 chunks each on a 256-CU part.  S = 8, 4 or 2 sets of workgroups (grid z) contract 1/S of the input channels each
+    // into their own fp32 slab; a second launch adds the slabs in order.  Chosen here, from the tiling: the caller only lends the workspace.
+    if (plain && d->k_split_ws && d->act_slope == 1.f && ups == 1 && d->cout % 64 == 0) {
+        const long long slab = (long long)d->B * d->cout * d->H * d->W;
+        const long long wgs = (long long)a.tiles_x * a.tiles_y * a.B * nslices;
+        int S = 1;
+        for (int c = 8; c >= 2; c /= 2) {
+            if (a.ncp % c || a.ncp / c < 8 || (tm1 && (a.ncp / c) % 8)) continue;
+            if (wgs * c > 320 || slab * c > d->k_split_ws_floats) continue;
+            S = c;
+            break;
+        }
+        if (S > 1) {
+            a.ksplit = S;
+            a.ncp /= S;                      // (a.wslice above is the stride of the FULL pack)
+            a.kz_groups = 2 * a.ncp;
+            a.in1.ncg = a.kz_groups;
+            a.kz_slab = slab;
+            a.out_nchw = d->k_split_ws;
+            int rc;
+            if (tm1) rc = split ? launch<2, 2, EPI_NCHW, 0, 2, false, 1>(a, s) : launch<1, 2, EPI_NCHW, 0, 1, false, 1>(a, s);
+            else if (tm2) rc = split ? launch<2, 2, EPI_NCHW, 0, 2, false, 2>(a, s) : launch<1, 2, EPI_NCHW, 0, 1, false, 2>(a, s);
+            else rc = split ? launch<2, 2, EPI_NCHW, 0, 2, false>(a, s) : launch<1, 2, EPI_NCHW, 0, 1, false>(a, s);
+            if (rc != ESR_OK) return rc;
+            const long long total = (long long)d->B * (d->cout / 8) * d->H * d->W;
+            ESR_CLEAR_ERR();
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->k_split_ws, S, slab, a.out,
+                               d->cout, d->H, d->W, total);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
+    if (tm1)
         return split ? launch<2, 2, 0, 0, 2, false, 1>(a, s) : launch<1, 2, 0, 0, 1, false, 1>(a, s);
-    if (plain && same(d->tap_mask_m, S2D_FLIP) && all9(d->tap_mask_k))
+    if (tm2)
         return split ? launch<2, 2, 0, 0, 2, false, 2>(a, s) : launch<1, 2, 0, 0, 1, false, 2>(a, s);
     if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
     if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);

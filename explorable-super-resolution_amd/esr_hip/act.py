@@ -466,7 +466,7 @@ def reset_launch_parity():
 
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
             out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0,
-            pixel_shuffle=0, ps_rowgroup0=0, tap_mask_k=None, tap_mask_k_shift=0, tap_mask_m=None):
+            pixel_shuffle=0, ps_rowgroup0=0, tap_mask_k=None, tap_mask_k_shift=0, tap_mask_m=None, k_split_ws=None):
     d = _lib.Conv3x3Desc()
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
@@ -500,6 +500,8 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
         d.tap_mask_k_shift = tap_mask_k_shift
     if tap_mask_m is not None:
         d.tap_mask_m[:] = tap_mask_m
+    if k_split_ws is not None:            # fp32 workspace the library may use to split the K axis of a small, deep launch (esr_hip.h)
+        d.k_split_ws, d.k_split_ws_floats = k_split_ws.data_ptr(), k_split_ws.numel()
     rec = _rec()
     if rec is not None:
         rec.emit(_lib.OP_CONV3X3, d, ('out_nchw',))

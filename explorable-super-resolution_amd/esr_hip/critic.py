@@ -117,6 +117,10 @@ def conv_io(t_in, t_out, B, h, w):
 
 
 STACK_MAX = int(os.environ.get('ESR_CRITIC_STACK', '8'))       # feature maps up to this height are stacked (0: never)
+# fused passes lend every conv launch an fp32 workspace: the library splits the K axis of the deep layers' launches (24-100 workgroups walking
+# 32-128 chunks each) over 2-8 workgroup sets (esr_conv3x3_desc.k_split_ws); 0: never
+SPLITK = os.environ.get('ESR_CRITIC_SPLITK', '1') != '0'
+SPLITK_MAX_FLOATS = 16 << 20
 
 
 class _Layer:
@@ -553,6 +557,14 @@ class _BufSet:
             self.z.append(mk(zg, zh, zw)); self.dz.append(mk(zg, zh, zw)); self.g_dz.append(mk(zg, zh, zw))
             self.s2d.append(s2d); self.hw.append((h, w))
         self.feat_shape = (B, eng.layers[-1].cout, h, w)
+        # split-K workspace: room for 8 slabs of the largest deep-layer output (or input gradient), capped
+        self.ksw = None
+        if SPLITK:
+            # (a slab is B*C*H*W floats; numel / planes also counts the border pixels: an upper bound)
+            nch = lambda t: 8 * (t.shape[1] if getattr(t, '_esr_stacked', False) else t.shape[2])
+            need = max([8 * (t.numel() // P) for t in self.y + self.dz if nch(t) >= 256] + [0])
+            if need:
+                self.ksw = torch.empty(min(need, SPLITK_MAX_FLOATS), dtype=torch.float32, device=device)
         # per-channel sums / statistics: [fwd: sums(2 doubles) mean rstd scale shift | bwd: sums2 | bwd2: sums3] per normalised block
         self.st = []
         off = 0
@@ -695,7 +707,7 @@ def _fwd_pass(eng, x, training):
             y, z = bs.y[i], bs.z[i]
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
             vi, vo, Bc, hc, wc = conv_io(t, y, B, h, w)
-            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, **kw)
+            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, k_split_ws=bs.ksw, **kw)
             st = bs.stats(eng, i, training)
             if L.bn is not None and training:
                 bn = L.bn
@@ -812,7 +824,7 @@ def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
                 dx = bs.dz[i - 1] if i > 0 else bs.dx0
                 kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}
                 vi, vo, Bc, hc, wc = conv_io(dy, dx, B, h, w)
-                A.conv3x3(L.tr, vi, Bc, hc, wc, L.cin_e, out=vo, use_bias=False, reverse=False, **kw)
+                A.conv3x3(L.tr, vi, Bc, hc, wc, L.cin_e, out=vo, use_bias=False, reverse=False, k_split_ws=bs.ksw, **kw)
         if want_dx:
             rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(bs.dx0), B, bs.in_shape[1], dx_in.data_ptr()), ('dst',))
     _replay(bs, ('bwd', training, d_feat is not None, inj, want_dx, pg is not None), ext, build)
@@ -851,7 +863,7 @@ def _bwd2_pass(eng, S, u, want_params):
             st = bs.stats(eng, i, training)
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
             vi, vo, Bc, hc, wc = conv_io(ut, gdy, B, h, w)
-            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, use_bias=False, reverse=False, **kw)
+            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, use_bias=False, reverse=False, k_split_ws=bs.ksw, **kw)
             if not st.const:
                 _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy), 2, st.sums3)
                 if i in g_gammas:

@@ -126,6 +126,14 @@ typedef struct {
     int32_t tap_mask_k[4];
     int32_t tap_mask_k_shift;
     int32_t tap_mask_m[4];
+    /* optional split-K workspace (caller-owned device memory, `k_split_ws_floats` floats; NULL: never split).  A launch of few output tiles
+     * with a long K axis (the critic's 256- / 512-channel layers on 16x16 ... 4x4 maps: 24-100 workgroups x 32-128 K chunks on 256 CUs) may be
+     * run as S = 2, 4 or 8 sets of workgroups that each contract 1/S of the input channels into an fp32 slab of B*cout*H*W floats, followed by a
+     * second launch that adds the slabs in a fixed order and stores `out`.  The library decides from its tiling (S * workgroups <= 320, >= 8 chunks
+     * per set, S slabs fit); only plain launches qualify (act_slope 1, no residual / mask / out2 / out_nchw / pixel_shuffle / upsample / in0,
+     * bf16 formats, cout a multiple of 64).  The result differs from the unsplit launch by fp32 summation order only. */
+    float* k_split_ws;
+    int64_t k_split_ws_floats;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
