@@ -25,18 +25,26 @@ from . import act as A
 from ._lib import ActView, BnDesc, EsrError, check
 
 SLOPE = 0.2
-_state = {'input_grad_only': 0}
+_state = {'input_grad_only': 0, 'group': None}
 
 
 class input_grad_only:
     """with input_grad_only(): ... — backward passes inside compute data gradients only (the penalty's d critic / d input: autograd cannot
-    tell the conv nodes that the weight gradients it would also hand back are not wanted by torch.autograd.grad(inputs=[interp]))."""
+    tell the conv nodes that the weight gradients it would also hand back are not wanted by torch.autograd.grad(inputs=[interp])).
+    group = g: the cotangent that enters a critic_forward_group() graph inside is non-zero for the g-th input only (the penalty
+    differentiates the interpolated batch's logits alone) — the backward pass, and later the backward of that backward pass, then run on
+    that input's images only.  A promise the caller makes: rows of the other inputs are not looked at."""
+
+    def __init__(self, group=None):
+        self.group = group
 
     def __enter__(self):
         _state['input_grad_only'] += 1
+        self.prev, _state['group'] = _state['group'], self.group
 
     def __exit__(self, *exc):
         _state['input_grad_only'] -= 1
+        _state['group'] = self.prev
 
 
 
@@ -69,17 +77,18 @@ if os.environ.get('ESR_CRITIC_MASKS') == '0':          # experiments: multiply t
     MASK_FWD = MASK_FLIPPED = None
 
 
-def view_of(t, cg0=0, ncg=None):
+def view_of(t, cg0=0, ncg=None, b0=0):
+    """View of channel groups [cg0, cg0 + ncg) starting at image b0 (the view has no batch size: the launch says how many images)."""
     if getattr(t, '_esr_stacked', False):              # [planes][CG][B][H+2][W+2][8]: see stacked_at()
         P, CG, B, Hp, Wp, _ = t.shape
         n = CG - cg0 if ncg is None else ncg
         cs = B * Hp * Wp
-        hi = t.data_ptr() + cg0 * cs * 16
+        hi = t.data_ptr() + (cg0 * cs + b0 * Hp * Wp) * 16
         return ActView(hi, hi + t.stride(0) * 2 if P == 2 else None, n, Hp - 2, Wp - 2, Hp * Wp, cs, 0)
     P, B, CG, Hp, Wp, _ = t.shape
     n = CG - cg0 if ncg is None else ncg
     cs = Hp * Wp
-    off = cg0 * cs * 16
+    off = (cg0 * cs + b0 * CG * cs) * 16
     hi = t.data_ptr() + off
     lo = hi + t.stride(0) * 2 if P == 2 else None
     return ActView(hi, lo, n, Hp - 2, Wp - 2, CG * cs, cs, 0)
@@ -96,24 +105,25 @@ def stacked_at(planes, B, ncg, H, W, device):
     return t
 
 
-def tall_view(t):
-    """The stacked tensor as one image per channel group (B' = 1): (view, rows)."""
+def tall_view(t, b0=0, nb=None):
+    """Images [b0, b0 + nb) of the stacked tensor as one image per channel group (B' = 1): (view, rows)."""
     P, CG, B, Hp, Wp, _ = t.shape
     cs = B * Hp * Wp
-    hi = t.data_ptr()
-    rows = B * Hp - 2
+    hi = t.data_ptr() + b0 * Hp * Wp * 16
+    rows = (B - b0 if nb is None else nb) * Hp - 2
     return ActView(hi, hi + t.stride(0) * 2 if P == 2 else None, CG, rows, Wp - 2, cs * CG, cs, 0), rows
 
 
-def conv_io(t_in, t_out, B, h, w):
-    """(input view, output view, B', H', W') of a conv launch over `t_in` -> `t_out`: per image, or the whole stacked batch as one image."""
+def conv_io(t_in, t_out, B, h, w, b0=0):
+    """(input view, output view, B', H', W') of a conv launch over images [b0, b0 + B) of `t_in` -> `t_out`: per image, or the stacked
+    images as one tall image."""
     if getattr(t_in, '_esr_stacked', False):
         assert getattr(t_out, '_esr_stacked', False)
-        vi, rows = tall_view(t_in)
-        vo, rows_o = tall_view(t_out)
+        vi, rows = tall_view(t_in, b0, B)
+        vo, rows_o = tall_view(t_out, b0, B)
         assert rows == rows_o
         return vi, vo, 1, rows, w
-    return view_of(t_in), view_of(t_out), B, h, w
+    return view_of(t_in, b0=b0), view_of(t_out, b0=b0), B, h, w
 
 
 STACK_MAX = int(os.environ.get('ESR_CRITIC_STACK', '8'))       # feature maps up to this height are stacked (0: never)
@@ -536,10 +546,11 @@ class _BufSet:
     them.  A call takes a free set from the engine (or makes one) and gives it back when its autograd graph is gone: steady state
     allocates nothing and builds no descriptors."""
 
-    def __init__(self, eng, B, Cin, H, W, device):
+    def __init__(self, eng, B, Cin, H, W, device, groups=1):
         P = eng.planes
-        self.key = (B, Cin, H, W, P)
+        self.key = (B, Cin, H, W, P, groups)
         self.B, self.in_shape, self.dev = B, (B, Cin, H, W), device
+        self.groups, self.Bg = groups, B // groups              # `groups` runs of Bg images, each with its own batch statistics
         mk = lambda ncg, h, w: stacked_at(P, B, ncg, h, w, device) if h <= STACK_MAX else new_at(P, B, ncg, h, w, device)
         self.t0, self.ut0, self.dx0 = mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W), mk((Cin + 7) // 8, H, W)
         self.y, self.z, self.dy, self.gdy, self.g_y, self.dz, self.g_dz, self.s2d, self.hw = [], [], [], [], [], [], [], [], []
@@ -575,18 +586,18 @@ class _BufSet:
             if L.bn is None:
                 lay.append(None)
                 continue
-            Cc = L.cout
+            Cc = L.cout * groups                                # every array is [groups][C]
             lay.append(dict(sums=take(Cc * 16), mean=take(Cc * 4), rstd=take(Cc * 4), scale=take(Cc * 4), shift=take(Cc * 4)))
         self.fwd_zero = (0, off_box[0])
         b0 = off_box[0]
         for L, d in zip(eng.layers, lay):
             if d is not None:
-                d['sums2'] = take(L.cout * 16)
+                d['sums2'] = take(L.cout * groups * 16)
         self.bwd_zero = (b0, off_box[0] - b0)
         b1 = off_box[0]
         for L, d in zip(eng.layers, lay):
             if d is not None:
-                d['sums3'] = take(L.cout * 24)
+                d['sums3'] = take(L.cout * groups * 24)
         self.bwd2_zero = (b1, off_box[0] - b1)
         self.scratch = torch.zeros(max(off_box[0], 256), dtype=torch.uint8, device=device)
         self.lay = lay
@@ -594,10 +605,15 @@ class _BufSet:
         self.plans, self.plans_fp = {}, None
         self.wg = {}
 
-    def ptr(self, i, name):
-        return self.scratch.data_ptr() + self.lay[i][name]
+    _PER_CH = dict(sums=16, mean=4, rstd=4, scale=4, shift=4, sums2=16, sums3=24)
 
-    def stats(self, eng, i, training):
+    def ptr(self, i, name, g=0, eng=None):
+        """Address of block i's array `name` ([groups][C] ...), at group g."""
+        off = g * eng.layers[i].cout * self._PER_CH[name] if g else 0
+        return self.scratch.data_ptr() + self.lay[i][name] + off
+
+    def stats(self, eng, i, training, g=0):
+        """Statistics pointers of block i, starting at group g (a launch over ONE group passes g and groups = 1)."""
         L = eng.layers[i]
         st = _Stats()
         st.sums2 = st.sums3 = None
@@ -606,8 +622,8 @@ class _BufSet:
         st.gamma = L.bn.weight.data_ptr() if L.bn.weight is not None else None
         if training:
             st.const = False
-            st.mean, st.rstd, st.scale, st.shift = (self.ptr(i, k) for k in ('mean', 'rstd', 'scale', 'shift'))
-            st.sums2, st.sums3 = self.ptr(i, 'sums2'), self.ptr(i, 'sums3')
+            st.mean, st.rstd, st.scale, st.shift = (self.ptr(i, k, g, eng) for k in ('mean', 'rstd', 'scale', 'shift'))
+            st.sums2, st.sums3 = self.ptr(i, 'sums2', g, eng), self.ptr(i, 'sums3', g, eng)
         else:
             sc, sh = self.eval_affine[i]
             st.scale, st.shift = sc.data_ptr(), sh.data_ptr()
@@ -618,18 +634,19 @@ class _State:
     pass
 
 
-def _desc(L, B, y, st, s2d, dz=None, u=None, out0=None, out1=None):
+def _desc(L, B, y, st, s2d, dz=None, u=None, out0=None, out1=None, groups=1, b0=0):
+    """BatchNorm launch over images [b0, b0 + B) as `groups` runs with their own statistics (st: pointers at the first of those groups)."""
     d = BnDesc()
-    d.y = view_of(y)
+    d.y = view_of(y, b0=b0)
     if dz is not None:
-        d.dz = view_of(dz)
+        d.dz = view_of(dz, b0=b0)
     if u is not None:
-        d.u = view_of(u)
+        d.u = view_of(u, b0=b0)
     if out0 is not None:
-        d.out0 = view_of(out0)
+        d.out0 = view_of(out0, b0=b0)
     if out1 is not None:
-        d.out1 = view_of(out1)
-    d.B, d.groups, d.C = B, 1, L.cout
+        d.out1 = view_of(out1, b0=b0)
+    d.B, d.groups, d.C = B, groups, L.cout
     d.scale, d.shift, d.mean, d.rstd, d.gamma = st.scale, st.shift, st.mean, st.rstd, st.gamma
     d.sums2, d.sums3 = st.sums2, st.sums3
     d.slope, d.const_stats, d.s2d = SLOPE, 1 if st.const else 0, 1 if s2d else 0
@@ -646,11 +663,13 @@ def _zero_region(rec, bs, region):
         rec.emit(_lib.OP_ZERO, _lib.CmdZero(bs.scratch.data_ptr() + off, nbytes // 16))
 
 
-def _acquire(eng, x):
+def _acquire(eng, x, groups=1):
     B, Cin, H, W = x.shape
-    key = (B, Cin, H, W, eng.planes)
+    if B % groups:
+        raise EsrError('critic: %d images do not split into %d equal groups' % (B, groups))
+    key = (B, Cin, H, W, eng.planes, groups)
     free = eng._free_sets.setdefault(key, [])
-    bs = free.pop() if free else _BufSet(eng, B, Cin, H, W, x.device)
+    bs = free.pop() if free else _BufSet(eng, B, Cin, H, W, x.device, groups)
     fp = eng.pointer_fingerprint()
     if bs.plans_fp != fp:
         bs.plans, bs.plans_fp, bs.wg = {}, fp, {}
@@ -673,11 +692,13 @@ def _replay(bs, key, ext, build):
     plan.run(ext)
 
 
-def _fwd_pass(eng, x, training):
-    """-> (features fp32 [B, C, h, w], state).  One launch list: pack, then per block conv -> statistics -> normalise + activate."""
+def _fwd_pass(eng, x, training, groups=1):
+    """-> (features fp32 [B, C, h, w], state).  One launch list: pack, then per block conv -> statistics -> normalise + activate.  groups > 1:
+    x is `groups` batches back to back, each normalised with its own batch statistics (the critic's separate calls as one pass; the running
+    statistics are updated group after group, as the separate calls would)."""
     x = x.float().contiguous()
-    bs = _acquire(eng, x)
-    B = bs.B
+    bs = _acquire(eng, x, groups)
+    B, G = bs.B, bs.groups
     S = _State()
     S.bs, S.training = bs, training
     weakref.finalize(S, _release, eng, bs)
@@ -711,17 +732,17 @@ def _fwd_pass(eng, x, training):
             st = bs.stats(eng, i, training)
             if L.bn is not None and training:
                 bn = L.bn
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False), 0, bs.ptr(i, 'sums'))
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False, groups=G), 0, bs.ptr(i, 'sums'))
                 track = bn.track_running_stats and bn.running_mean is not None
-                rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(bs.ptr(i, 'sums'), 1, L.cout, B * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(bs.ptr(i, 'sums'), G, L.cout, bs.Bg * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
                                                                  st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
                                                                  bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None))
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], out0=z), 0)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], out0=z, groups=G), 0)
             t = z
         rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, bs.feat_shape[1], feat.data_ptr()), ('dst',))
     _replay(bs, ('fwd', training), {'x': x, 'feat': feat}, build)
     if tracked:
-        torch._foreach_add_(tracked, 1)
+        torch._foreach_add_(tracked, G)
     return feat, S
 
 
@@ -729,15 +750,16 @@ class _WgradSet:
     """The weight-gradient launch of one pass kind over one buffer set: descriptors built once; per call a fresh zeroed flat dW buffer, the
     table re-pointed only if its address moved (engine.WGrad.rebind's scheme)."""
 
-    def __init__(self, eng, bs, pairs):
+    def __init__(self, eng, bs, pairs, b0=0, nb=None):
         self.eng, self.pairs = eng, pairs
+        nb = bs.B - b0 if nb is None else nb                       # the images the sum runs over: [b0, b0 + nb)
         self.sizes = [L.cout * L.cin_e * 9 + L.cout for L, _, _ in pairs]
         self.n = sum(self.sizes)
         flat = torch.zeros(self.n, dtype=torch.float32, device=bs.dev)
         descs, off = [], 0
         for (L, dy, xin), n in zip(pairs, self.sizes):
             nw = L.cout * L.cin_e * 9
-            vx, vdy, Bc, hc, wc = conv_io(xin, dy, bs.B, dy.shape[3] - 2, dy.shape[4] - 2)       # (stacked maps: one tall image; their borders are zero)
+            vx, vdy, Bc, hc, wc = conv_io(xin, dy, nb, dy.shape[3] - 2, dy.shape[4] - 2, b0)     # (stacked maps: one tall image; their borders are zero)
             d, _, _ = A.wgrad_desc(vdy, vx, None, 0, (L.cout, L.cin_e, 3, 3), Bc, hc, wc, 1.0, 1, bs.dev,
                                    out=(flat[off:off + nw], flat[off + nw:off + n]), tap_masks=MASK_FWD if (L.strided and MASK_FWD) else None)
             descs.append(d)
@@ -772,12 +794,19 @@ class _WgradSet:
         return out
 
 
-def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
+def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params, group=None):
     """The backward pass as one launch list: per block (last to first) BatchNorm/LeakyReLU gradient -> [+ injected cotangent of y_l] -> data
     gradient.  dy_l / dz_l stay in the buffer set (the double backward reads them).  -> (d input fp32 or None, {layer: (dW, db)}, {layer:
-    (dgamma, dbeta)})"""
+    (dgamma, dbeta)}).  group = g (a grouped forward): only the g-th input's images are processed — the caller promises that d_feat is zero
+    elsewhere; the other rows of d input come back zero."""
     bs, training = S.bs, S.training
-    B, dev, n = bs.B, bs.dev, len(eng.layers)
+    dev, n = bs.dev, len(eng.layers)
+    if group is not None and bs.groups == 1:
+        group = None
+    G = bs.groups if group is None else 1                        # statistic groups of this pass's launches
+    g0 = 0 if group is None else group
+    b0, B = g0 * bs.Bg, (bs.B if group is None else bs.Bg)        # its images: [b0, b0 + B)
+    Bg = bs.Bg
     bnl = [i for i, L in enumerate(eng.layers) if L.bn is not None and training]
     pg = torch.empty(2 * sum(eng.layers[i].cout for i in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
     inj = tuple(g is not None for g in g_ys) if g_ys is not None else (False,) * n
@@ -787,11 +816,16 @@ def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
                 bs.g_y[i].copy_(g)
     ext = {}
     if d_feat is not None:
-        d_feat = d_feat.detach().float().contiguous()
+        d_feat = d_feat.detach().float().contiguous()[b0:b0 + B]
         ext['d_feat'] = d_feat
-    dx_in = torch.empty(bs.in_shape, dtype=torch.float32, device=dev) if want_dx else None
+    dx_full = (torch.empty if group is None else torch.zeros)(bs.in_shape, dtype=torch.float32, device=dev) if want_dx else None
+    dx_in = dx_full[b0:b0 + B] if want_dx else None
     if dx_in is not None:
         ext['dx_in'] = dx_in
+    # the images whose y_l cotangents exist: those the double backward pass ran on (it leaves the range on the state), inside this pass's range
+    ib0, inb = getattr(S, 'inj_rows', None) or (0, bs.B)
+    if group is not None:
+        ib0, inb = b0, B
     if pg is not None:
         ext['pg'] = pg
     bn_grads, pg_off = {}, 0
@@ -802,49 +836,63 @@ def _bwd_pass(eng, S, d_feat, g_ys, want_dx, want_params):
             pg_off += 2 * c
 
     def build(rec):
-        _zero_region(rec, bs, bs.bwd_zero)
+        # (a pass over one group leaves the other groups' sums alone: the double backward of another group may still need them)
+        if group is None:
+            _zero_region(rec, bs, bs.bwd_zero)
+        else:
+            for i in bnl:
+                rec.emit(_lib.OP_ZERO, _lib.CmdZero(bs.ptr(i, 'sums2', g0, eng), eng.layers[i].cout))        # C x 2 doubles = C 16-byte vectors
         dz = bs.dz[n - 1]
         if d_feat is None:
             rec.emit(_lib.OP_ZERO, _lib.CmdZero(dz.data_ptr(), dz.numel() // 8))
         else:
-            A.pack_nchw(d_feat, view_of(dz), 0, d_feat.shape[1])
+            A.pack_nchw(d_feat, view_of(dz, b0=b0), 0, d_feat.shape[1])
         for i in reversed(range(n)):
             L, y, dy, dz = eng.layers[i], bs.y[i], bs.dy[i], bs.dz[i]
             h, w = bs.hw[i]
-            st = bs.stats(eng, i, training)
+            st = bs.stats(eng, i, training, g0)
             if not st.const:
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=dz), 1, st.sums2)
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=dz, groups=G, b0=b0), 1, st.sums2)
                 if pg is not None:
-                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, None, None, 1, L.cout, B * h * w, bn_grads[i][0].data_ptr(),
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, None, None, G, L.cout, Bg * h * w, bn_grads[i][0].data_ptr(),
                                                                           bn_grads[i][1].data_ptr(), None), ('dgamma', 'dbeta'))
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=dz, out0=dy), 1)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=dz, out0=dy, groups=G, b0=b0), 1)
             if inj[i]:
-                A.act_combine(view_of(dy), B, A_=view_of(dy), alpha=1.0, Bv=view_of(bs.g_y[i]), beta=1.0, s=1)
+                A.act_combine(view_of(dy, b0=ib0), inb, A_=view_of(dy, b0=ib0), alpha=1.0, Bv=view_of(bs.g_y[i], b0=ib0), beta=1.0, s=1)
             if i > 0 or want_dx:
                 dx = bs.dz[i - 1] if i > 0 else bs.dx0
                 kw = dict(tap_mask_m=MASK_FLIPPED) if (L.strided and MASK_FLIPPED) else {}
-                vi, vo, Bc, hc, wc = conv_io(dy, dx, B, h, w)
+                vi, vo, Bc, hc, wc = conv_io(dy, dx, B, h, w, b0)
                 A.conv3x3(L.tr, vi, Bc, hc, wc, L.cin_e, out=vo, use_bias=False, reverse=False, k_split_ws=bs.ksw, **kw)
         if want_dx:
-            rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(bs.dx0), B, bs.in_shape[1], dx_in.data_ptr()), ('dst',))
-    _replay(bs, ('bwd', training, d_feat is not None, inj, want_dx, pg is not None), ext, build)
+            rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(bs.dx0, b0=b0), B, bs.in_shape[1], dx_in.data_ptr()), ('dst',))
+    _replay(bs, ('bwd', training, d_feat is not None, inj, want_dx, pg is not None, group, (ib0, inb)), ext, build)
     conv_grads = {}
     if want_params:
-        if 'bwd' not in bs.wg:
-            bs.wg['bwd'] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.z[i - 1] if i > 0 else bs.t0) for i, L in enumerate(eng.layers)])
-        conv_grads = bs.wg['bwd'].run()
-    return dx_in, conv_grads, bn_grads
+        wk = ('bwd', group)
+        if wk not in bs.wg:
+            bs.wg[wk] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.z[i - 1] if i > 0 else bs.t0) for i, L in enumerate(eng.layers)], b0, B)
+        conv_grads = bs.wg[wk].run()
+    return dx_full, conv_grads, bn_grads
 
 
-def _bwd2_pass(eng, S, u, want_params):
+def _bwd2_pass(eng, S, u, want_params, group=None):
     """The backward of the backward pass (u: cotangent of d input), first block to last: per block conv of the incoming cotangent -> gradient
-    of the BatchNorm/LeakyReLU gradient.  -> (cotangent of d features, [cotangent of y_l], {layer: dW (second order)}, {layer: g_gamma})"""
+    of the BatchNorm/LeakyReLU gradient.  -> (cotangent of d features, [cotangent of y_l], {layer: dW (second order)}, {layer: g_gamma}).
+    group = g: the backward pass it differentiates ran on the g-th input's images only (and u is zero elsewhere): so does this one."""
     bs, training = S.bs, S.training
-    B, dev, n = bs.B, bs.dev, len(eng.layers)
+    dev, n = bs.dev, len(eng.layers)
+    if group is not None and bs.groups == 1:
+        group = None
+    G = bs.groups if group is None else 1
+    g0 = 0 if group is None else group
+    b0, B = g0 * bs.Bg, (bs.B if group is None else bs.Bg)
+    Bg = bs.Bg
     bnl = [i for i, L in enumerate(eng.layers) if L.bn is not None and training and L.bn.weight is not None]
     gg_all = torch.empty(sum(eng.layers[i].cout for i in bnl), dtype=torch.float32, device=dev) if (want_params and bnl) else None
-    u = u.detach().float().contiguous()
-    g_dfeat = torch.empty(bs.feat_shape, dtype=torch.float32, device=dev)
+    u = u.detach().float().contiguous()[b0:b0 + B]
+    g_dfeat_full = (torch.empty if group is None else torch.zeros)(bs.feat_shape, dtype=torch.float32, device=dev)
+    g_dfeat = g_dfeat_full[b0:b0 + B]
     ext = {'u': u, 'g_dfeat': g_dfeat}
     g_gammas, off = {}, 0
     if gg_all is not None:
@@ -854,32 +902,39 @@ def _bwd2_pass(eng, S, u, want_params):
             off += eng.layers[i].cout
 
     def build(rec):
-        _zero_region(rec, bs, bs.bwd2_zero)
-        A.pack_nchw(u, view_of(bs.ut0), 0, u.shape[1])
+        if group is None:
+            _zero_region(rec, bs, bs.bwd2_zero)
+        else:
+            for i, L in enumerate(eng.layers):
+                if L.bn is not None and training:
+                    rec.emit(_lib.OP_ZERO, _lib.CmdZero(bs.ptr(i, 'sums3', g0, eng), (L.cout * 24 + 15) // 16))
+        A.pack_nchw(u, view_of(bs.ut0, b0=b0), 0, u.shape[1])
         ut = bs.ut0
         for i, L in enumerate(eng.layers):
             y, gdy = bs.y[i], bs.gdy[i]
             h, w = bs.hw[i]
-            st = bs.stats(eng, i, training)
+            st = bs.stats(eng, i, training, g0)
             kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
-            vi, vo, Bc, hc, wc = conv_io(ut, gdy, B, h, w)
+            vi, vo, Bc, hc, wc = conv_io(ut, gdy, B, h, w, b0)
             A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, use_bias=False, reverse=False, k_split_ws=bs.ksw, **kw)
             if not st.const:
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy), 2, st.sums3)
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy, groups=G, b0=b0), 2, st.sums3)
                 if i in g_gammas:
-                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, st.sums3, st.rstd, 1, L.cout, B * h * w, None, None, g_gammas[i].data_ptr()),
+                    rec.emit(_lib.OP_BN_PARAM_GRADS, _lib.CmdBnParamGrads(st.sums2, st.sums3, st.rstd, G, L.cout, Bg * h * w, None, None, g_gammas[i].data_ptr()),
                              ('g_gamma',))
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy, out0=bs.g_dz[i], out1=bs.g_y[i]), 2)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], dz=bs.dz[i], u=gdy, out0=bs.g_dz[i], out1=bs.g_y[i], groups=G, b0=b0), 2)
             ut = bs.g_dz[i]
-        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(ut), B, bs.feat_shape[1], g_dfeat.data_ptr()), ('dst',))
-    _replay(bs, ('bwd2', training, gg_all is not None), ext, build)
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(ut, b0=b0), B, bs.feat_shape[1], g_dfeat.data_ptr()), ('dst',))
+    _replay(bs, ('bwd2', training, gg_all is not None, group), ext, build)
+    S.inj_rows = (b0, B)                # only these images' g_y are defined: the backward pass that takes them in adds them there
     g_ys = [bs.g_y[i].detach() if (eng.layers[i].bn is not None and training) else None for i in range(n)]
     conv2 = {}
     if want_params:
-        if 'bwd2' not in bs.wg:
-            bs.wg['bwd2'] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.ut0 if i == 0 else bs.g_dz[i - 1]) for i, L in enumerate(eng.layers)])
-        conv2 = {k: v[0] for k, v in bs.wg['bwd2'].run().items()}
-    return g_dfeat, g_ys, conv2, g_gammas
+        wk = ('bwd2', group)
+        if wk not in bs.wg:
+            bs.wg[wk] = _WgradSet(eng, bs, [(L, bs.dy[i], bs.ut0 if i == 0 else bs.g_dz[i - 1]) for i, L in enumerate(eng.layers)], b0, B)
+        conv2 = {k: v[0] for k, v in bs.wg[wk].run().items()}
+    return g_dfeat_full, g_ys, conv2, g_gammas
 
 
 def _param_list(eng):
@@ -892,9 +947,9 @@ def _param_list(eng):
 
 class _CriticFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, training, x, *params):
+    def forward(ctx, eng, training, groups, x, *params):
         ctx.set_materialize_grads(False)
-        feat, S = _fwd_pass(eng, x.detach(), training)
+        feat, S = _fwd_pass(eng, x.detach(), training, groups)
         ctx.eng, ctx.S, ctx.np = eng, S, len(params)
         ys = tuple(y.detach() for y in S.bs.y)        # fresh tensor objects over the set's storage: autograd attaches its history to these
         ctx.save_for_backward(*[p for p in params if p is not None], *ys)
@@ -908,23 +963,25 @@ class _CriticFwd(torch.autograd.Function):
         it = iter(saved[:nreal])
         params = [next(it) if m else None for m in ctx.pmask]
         ys = saved[nreal:]
-        want_dx = ctx.needs_input_grad[2]
-        want_params = any(ctx.needs_input_grad[3:]) and not _state['input_grad_only']
-        outs = _CriticBwd.apply(ctx.eng, ctx.S, want_dx, want_params, d_feat, len(ys), *g_ys, *ys, *params)
+        want_dx = ctx.needs_input_grad[3]
+        want_params = any(ctx.needs_input_grad[4:]) and not _state['input_grad_only']
+        group = _state['group'] if ctx.S.bs.groups > 1 else None
+        outs = _CriticBwd.apply(ctx.eng, ctx.S, want_dx, want_params, group, d_feat, len(ys), *g_ys, *ys, *params)
         dx, pgrads = outs[0], outs[1:]
-        return (None, None, dx if want_dx else None) + tuple(g if (g is not None and ctx.needs_input_grad[3 + k]) else None for k, g in enumerate(pgrads))
+        return (None, None, None, dx if want_dx else None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None for k, g in enumerate(pgrads))
 
 
 class _CriticBwd(torch.autograd.Function):
     """(d input, parameter gradients) = backward pass of the critic, as a function of (d features, cotangents injected at the y_l, the y_l
     themselves, the parameters): differentiable once more (WGAN-GP)."""
+    NFIXED = 7            # eng, S, want_dx, want_params, group, d_feat, n
 
     @staticmethod
-    def forward(ctx, eng, S, want_dx, want_params, d_feat, n, *rest):
+    def forward(ctx, eng, S, want_dx, want_params, group, d_feat, n, *rest):
         ctx.set_materialize_grads(False)
         g_ys, params = rest[:n], rest[2 * n:]
-        dx, conv_grads, bn_grads = _bwd_pass(eng, S, d_feat, g_ys if any(g is not None for g in g_ys) else None, want_dx, want_params)
-        ctx.eng, ctx.S, ctx.n, ctx.nparams = eng, S, n, len(params)
+        dx, conv_grads, bn_grads = _bwd_pass(eng, S, d_feat, g_ys if any(g is not None for g in g_ys) else None, want_dx, want_params, group)
+        ctx.eng, ctx.S, ctx.n, ctx.nparams, ctx.group = eng, S, n, len(params), group
         ctx.had_dfeat = d_feat is not None
         pg = []
         for i, L in enumerate(eng.layers):
@@ -939,15 +996,15 @@ class _CriticBwd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, u, *u_params):
-        n = ctx.n
+        n, nf = ctx.n, _CriticBwd.NFIXED
         if u is None:
-            return (None,) * (6 + 2 * n + ctx.nparams)
-        want_params = any(ctx.needs_input_grad[6 + 2 * n:]) and not _state['input_grad_only']
-        g_dfeat, g_ys, conv2, g_gammas = _bwd2_pass(ctx.eng, ctx.S, u, want_params)
+            return (None,) * (nf + 2 * n + ctx.nparams)
+        want_params = any(ctx.needs_input_grad[nf + 2 * n:]) and not _state['input_grad_only']
+        g_dfeat, g_ys, conv2, g_gammas = _bwd2_pass(ctx.eng, ctx.S, u, want_params, ctx.group)
         pg = []
         for i, L in enumerate(ctx.eng.layers):
             pg += [conv2.get(i), None, g_gammas.get(i), None]
-        return (None, None, None, None, g_dfeat if ctx.had_dfeat else None, None) + (None,) * n + tuple(g_ys) + tuple(pg)
+        return (None,) * (nf - 2) + (g_dfeat if ctx.had_dfeat else None, None) + (None,) * n + tuple(g_ys) + tuple(pg)
 
 
 FUSED = os.environ.get('ESR_CRITIC_FUSED', '1') != '0'
@@ -959,11 +1016,29 @@ def critic_forward(eng, x):
     forward / backward / double backward (ESR_CRITIC_FUSED=0: one autograd node and several FFI calls per layer — the same kernels)."""
     if not FUSED:
         return _critic_forward_per_layer(eng, x)
-    A.require_gpu(x, 'critic input')
+    return critic_forward_group(eng, [x])[0]
+
+
+GROUPED = os.environ.get('ESR_CRITIC_GROUPED', '1') != '0'
+
+
+def critic_forward_group(eng, xs):
+    """[critic(x) for x in xs] for equally shaped batches — the same values as separate calls in this order (each batch is normalised with
+    its own batch statistics, the running statistics see the batches one after the other) — executed as ONE pass over the concatenated
+    images: the critic's 512-channel layers on 8x8 / 4x4 maps cost the same for 32 or 96 images, the weight gradients of all batches
+    become one launch, and autograd has one graph to walk.  The WGAN-GP step calls it with [real, fake, interpolated]
+    (models/SRRaGAN_model.py); `input_grad_only(group=2)` around the penalty's autograd.grad keeps that pass on the interpolated images."""
+    xs = list(xs)
+    if not FUSED or not GROUPED or any(x.shape != xs[0].shape for x in xs):
+        return [critic_forward(eng, x) for x in xs]
+    for x in xs:
+        A.require_gpu(x, 'critic input')
     net = eng.net
     eng.refresh()
-    if x.shape[1] != eng.layers[0].cin:
+    if xs[0].shape[1] != eng.layers[0].cin:
         raise EsrError('critic input: %d channels expected' % eng.layers[0].cin)
-    outs = _CriticFwd.apply(eng, net.training, x, *_param_list(eng))
+    x = xs[0] if len(xs) == 1 else torch.cat(xs)
+    outs = _CriticFwd.apply(eng, net.training, len(xs), x, *_param_list(eng))
     feat = outs[0]
-    return net.classifier(feat.reshape(feat.size(0), -1))
+    logits = net.classifier(feat.reshape(feat.size(0), -1))
+    return [logits] if len(xs) == 1 else list(logits.chunk(len(xs)))

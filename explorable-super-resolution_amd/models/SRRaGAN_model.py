@@ -23,7 +23,7 @@ import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
 from esr_hip import optim as esr_optim
-from esr_hip.critic import CriticEngine, critic_forward
+from esr_hip.critic import CriticEngine, critic_forward, critic_forward_group
 from esr_hip._lib import EsrError
 from models.modules.loss import CreateRangeLoss, FilterLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
@@ -299,6 +299,14 @@ class SRRaGANModel(BaseModel):
         with torch.autocast(device_type='cuda', dtype=self.D_dtype):
             return self.netD(x).float()
 
+    def _D_group(self, xs):
+        """[self._D(x) for x in xs] — on the library's kernels as ONE pass over the concatenated batches (same values: every batch keeps its own
+        BatchNorm statistics, the running statistics see them in this order; esr_hip.critic.critic_forward_group)."""
+        if self.D_engine is not None:
+            self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
+            return critic_forward_group(self.D_engine, xs)
+        return [self._D(x) for x in xs]
+
     def _tick(self, name):
         """Phase timer (only when self.timing is a dict): GPU time since the previous tick is charged to `name`."""
         if self.timing is None:
@@ -358,9 +366,17 @@ class SRRaGANModel(BaseModel):
                 if first_acc_D and first_dual:
                     self.optimizer_D.zero_grad()
                     self._d_acc = {k: [] for k in ('l_d_real', 'l_d_fake', 'D_real', 'D_fake', 'D_logits_diff')}
+                # the critic's calls of this step — real (first dual pass only), fake, and the penalty's interpolated batch — as one grouped pass
+                # (the reference calls netD three times, :345-368; its only random draw in between is the interpolation points)
+                d_inputs = ([self.var_ref] if first_dual else []) + [self.fake_H.detach()]
+                if train_opt['gan_type'] == 'wgan-gp':
+                    pt = self._draw_interp_points(self.var_ref.size(0))
+                    interp = (pt * self.fake_H.detach() + (1 - pt) * self.var_ref).requires_grad_(True)
+                    d_inputs.append(interp)
+                d_preds = self._D_group(d_inputs)
                 if first_dual:
-                    pred_d_real = self._D(self.var_ref)
-                pred_d_fake = self._D(self.fake_H.detach())
+                    pred_d_real = d_preds[0]
+                pred_d_fake = d_preds[1 if first_dual else 0]
                 if self.relativistic_D:
                     assert train_opt['hinge_threshold'] is None, 'Unsupported yet, should think whether it reuires special adaptation of hinge loss'
                     l_d_real = self.cri_gan(pred_d_real - torch.mean(pred_d_fake), True)
@@ -371,9 +387,7 @@ class SRRaGANModel(BaseModel):
                     l_d_fake = 2 * self.cri_gan(pred_d_fake, False, train_opt['hinge_threshold'])
                 l_d_total = (l_d_real + l_d_fake) / 2
                 if train_opt['gan_type'] == 'wgan-gp':
-                    pt = self._draw_interp_points(self.var_ref.size(0))
-                    interp = (pt * self.fake_H.detach() + (1 - pt) * self.var_ref).requires_grad_(True)
-                    l_d_gp = self.l_gp_w * self.cri_gp(interp, self._D(interp))
+                    l_d_gp = self.l_gp_w * self.cri_gp(interp, d_preds[-1], critic_group=len(d_inputs) - 1)
                     l_d_total = l_d_total + l_d_gp
                 logits_diff = torch.mean(pred_d_real.detach() - pred_d_fake.detach(), dim=list(range(1, pred_d_real.dim())))
                 self._d_acc['l_d_real'].append(l_d_real.detach()); self._d_acc['l_d_fake'].append(l_d_fake.detach())

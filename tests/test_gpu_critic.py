@@ -369,3 +369,55 @@ def test_split_k_convs_match_float64_like_the_unsplit_launch(precision):
         assert bool(torch.isfinite(ws[:4096]).all()), ('data gradient did not split', li)
         assert err[1] < 1.05 * err[0] + 1e-7 and err[0] < (1e-5 if precision == 'split' else 5e-3), (li, err)
         ws.fill_(float('nan'))
+
+
+@pytest.mark.parametrize('splitk', [False, True])
+def test_grouped_call_equals_separate_calls(monkeypatch, splitk):
+    """critic_forward_group([real, fake, interp]): one pass over the 3 x B images with per-batch statistics, the penalty's backward and double
+    backward restricted to the interpolated images (input_grad_only(group=2)), ONE weight-gradient launch for the three batches — against
+    three separate calls (the reference's form, SRRaGAN_model.py:345-368).  Same kernels on the same numbers: only fp32 / double summation
+    orders differ (batched weight gradient; with split K also the deep layers' sums, which the critic amplifies — see the split-K test)."""
+    from esr_hip import critic as K
+    monkeypatch.setattr(K, 'SPLITK', splitk)
+    netD = make_D(64)
+    real, fake = seeded_uniform((8, 3, 64, 64), 31).cuda(), seeded_uniform((8, 3, 64, 64), 32).cuda()
+    pt = seeded_uniform((8, 1, 1, 1), 33).cuda()
+    params = list(netD.parameters())
+    bns = [m for m in netD.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+
+    def step(grouped):
+        eng = K.CriticEngine(netD, 'split')
+        for p in params:
+            p.grad = None
+        for m in bns:
+            m.reset_running_stats()
+        interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
+        if grouped:
+            pr, pf, crit = K.critic_forward_group(eng, [real, fake, interp])
+        else:
+            pr, pf, crit = K.critic_forward(eng, real), K.critic_forward(eng, fake), K.critic_forward(eng, interp)
+        with K.input_grad_only(group=2 if grouped else None):
+            g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
+        gp = 10.0 * ((g.reshape(g.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
+        (pf.mean() - pr.mean() + gp).backward()
+        return [pr.detach().clone(), pf.detach().clone(), crit.detach().clone(), g.detach().clone(), gp.detach().clone()] + [p.grad.clone() for p in params] + \
+            [bns[0].running_mean.clone(), bns[-1].running_var.clone(), bns[3].num_batches_tracked.clone()]
+    a, b = step(False), step(True)
+    names = ['pred_real', 'pred_fake', 'pred_interp', 'dD/dx', 'gp'] + [n for n, _ in netD.named_parameters()] + ['running_mean', 'running_var', 'num_batches_tracked']
+    scale = max(float(g.norm()) for g in a[5:-3])
+    assert int(b[-1]) == 3
+    for name, u, v in zip(names, a, b):
+        if name == 'num_batches_tracked':
+            assert torch.equal(u, v)
+            continue
+        if name.startswith('pred'):
+            tol = 2e-4 if splitk else 2e-6
+        elif name in ('dD/dx', 'gp'):
+            tol = 5e-2 if splitk else 1e-4
+        elif name.startswith('running'):
+            tol = 1e-5
+        else:
+            if max(float(u.norm()), float(v.norm())) < 1e-3 * scale:
+                continue                      # analytically zero (conv bias in front of BatchNorm)
+            tol = 5e-2 if splitk else 2e-3
+        assert rel(v, u) < tol, (name, rel(v, u))

@@ -31,7 +31,7 @@ def timed(fn, n=10):
     return (time.perf_counter() - t0) / n * 1e3, th / n * 1e3
 
 
-def passes(run):
+def passes(run, grouped=False):
     def fwd():
         with torch.no_grad():
             run(real)
@@ -51,7 +51,19 @@ def passes(run):
             g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
         gp = 10.0 * ((g.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
         (pf.mean() - pr.mean() + gp).backward()
-    return [('forward', fwd), ('forward + backward', fwd_bwd), ('WGAN-GP critic step', d_step)]
+    def d_step_grouped():          # the three calls as one grouped pass (what SRRaGANModel.optimize_parameters does on the HIP engine)
+        for p in params:
+            p.grad = None
+        interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
+        pr, pf, crit = K.critic_forward_group(eng, [real, fake, interp])
+        with K.input_grad_only(group=2):
+            g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
+        gp = 10.0 * ((g.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
+        (pf.mean() - pr.mean() + gp).backward()
+    out = [('forward', fwd), ('forward + backward', fwd_bwd), ('WGAN-GP critic step', d_step)]
+    if grouped:
+        out.append(('critic step, grouped', d_step_grouped))
+    return out
 
 
 def stock(x):
@@ -65,9 +77,9 @@ if os.environ.get('CRITIC_ONLY') == 'hip':
     variants = variants[:1]
 if os.environ.get('CRITIC_ONLY') == 'step':          # profiling runs: the critic step alone, 10 + 3 iterations
     variants = []
-    timed(dict(passes(lambda x: K.critic_forward(eng, x)))['WGAN-GP critic step'])
+    timed(dict(passes(lambda x: K.critic_forward(eng, x), True))['critic step, grouped' if os.environ.get('CRITIC_GROUPED', '1') != '0' else 'WGAN-GP critic step'])
 for name, run in variants:
-    for what, fn in passes(run):
+    for what, fn in passes(run, name.startswith('hip')):
         wall, host = timed(fn)
         print('%-28s %-22s %7.2f ms   (host enqueue %6.2f ms)' % (name, what, wall, host))
 
