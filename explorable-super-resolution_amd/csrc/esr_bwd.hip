@@ -335,6 +335,7 @@ struct WgradArgs {
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
     int tapmode;               // 1: esr_wgrad_desc.tap_masks name the space-to-depth pattern (S2D_TAPS below); 0: all taps
+    int shape;                 // pixel tile of this layer: 0 = 8 rows x 32 columns, 1 = 16 x 16, 2 = 32 x 8 (narrow maps; S2D kernels only)
 };
 #ifdef ESR_TRACE
 // debug build only (make trace): per-workgroup phase stamps of the weight-gradient kernels, 64 slots per workgroup — [0] HW_ID, [1] stamps used,
@@ -382,8 +383,15 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
 
 // TM (compile time): the taps whose weight gradient is wanted (structurally zero blocks of the weights are skipped: the unrolled tap loop
 // drops their reads and MFMAs; their accumulators stay zero)
-template <int NPL, int NST, int FMT, int TM = 0x1FF>
+// SH (compile time): the 256-pixel tile's shape, 8 x 32 (0), 16 x 16 (1) or 32 x 8 (2) — a 16x16 / 8x8 / 4x4 feature map (the critic's deep
+// layers; the small ones stacked into one tall image) fills 100 / 80 / 40 % of its tiles instead of 50 / 20 / 10 %.  The dY plane stays the
+// tile's pixels in row-major order (K step j = pixels 16 j .. 16 j + 15), the haloed X tile has pitch TW + 2: a K step is half a row, a row,
+// or two rows of it.
+template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
+    constexpr int TW = 32 >> SH, TH = 8 << SH, LGW = 5 - SH;
+    constexpr int XPS = (TH + 2) * (TW + 2);                     // haloed pixels of this shape (<= XP, the plane stride)
+    static_assert(XPS <= XP && TW * TH == YP, "tile shapes share the LDS plane sizes");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cit = group / a.mt, cot = group % a.mt;            // input-channel tile, output-channel tile
@@ -410,7 +418,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
     const int rb2 = (grp16 & 1) * 2 + ((li & 3) >> 1);           // channel group (of the 32-channel tile's 4) this lane points into
     const int kb = (grp16 >> 1) * 8 + (li >> 2);                 // pixel inside the 16-pixel K step
     const int frag_off = kb * 16 + (li & 1) * 8;                 // + low / high 4 channels of the 16-byte vector
-    const int xs_off = rb2 * XP * 16 + frag_off;
+    // (32 x 8 tiles: the second half of a K step is the next row of the haloed tile, TW + 2 - 8 = 2 pixels further than contiguous)
+    const int xs_off = rb2 * XP * 16 + frag_off + (SH == 2 ? (kb >> 3) * 32 : 0);
     const int ys_off = NPL * WG_X_BYTES + rb2 * YPP * 16 + frag_off;
 
     // All DMA of one tile.  Wave w copies channel group w of both operands (hi and lo planes): 6 + 4 slots of 64 pixel vectors per
@@ -427,19 +436,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
         const int r1_ = (TILE) / a.tiles_x;                                                                                      \
         const int ty_ = r1_ % a.tiles_y;                                                                                         \
         const int b_ = r1_ / a.tiles_y;                                                                                          \
-        const int x0_ = tx_ * WG_TW, y0_ = ty_ * WG_TH;                                                                          \
+        const int x0_ = tx_ * TW, y0_ = ty_ * TH;                                                                                \
         const uint4* const xh_ = xv.hi + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs;                                                 \
         const uint4* const xl_ = NPL == 2 ? xv.lo + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs : nullptr;                            \
         const unsigned xd_ = (ST) + wave * XP * 16;                                                                              \
         _Pragma("unroll") for (int sl = 0; sl < XSLOTS; ++sl) {                                                                  \
             const int p = sl * 64 + lane;                                                                                        \
-            const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);                                                           \
+            const int rr = p / (TW + 2), cc = p - rr * (TW + 2);                                                                 \
             const int Yp = y0_ + rr, Xp = x0_ + cc;                 /* padded output-resolution coords of the haloed tile */     \
             int sy = Yp, sx = Xp;                                                                                                \
             if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }                                                          \
             else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }                                \
             const int off = (xhave && Yp < a.H + 2 && Xp < a.W + 2) ? sy * a.Wx_p + sx : 0;   /* 0: the zero border vector */    \
-            if (sl < XSLOTS - 1 || p < XP) {                                                                                     \
+            if (p < XPS) {                                                                                                       \
                 glds16w(xh_ + off, xd_ + sl * 1024);                                                                             \
                 if (NPL == 2) glds16w(xl_ + off, xd_ + WG_X_BYTES + sl * 1024);                                                  \
             }                                                                                                                    \
@@ -449,7 +458,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
         const unsigned yd_ = (ST) + NPL * WG_X_BYTES + wave * YPP * 16;                                                          \
         _Pragma("unroll") for (int sl = 0; sl < YSLOTS; ++sl) {                                                                  \
             const int p = sl * 64 + lane;                                                                                        \
-            const int Y = y0_ + (p >> 5), X = x0_ + (p & 31);                                                                    \
+            const int Y = y0_ + (p >> LGW), X = x0_ + (p & (TW - 1));                                                            \
             const int off = (yhave && Y < a.H && X < a.W) ? (Y + 1) * (a.W + 2) + (X + 1) : 0;                                   \
             glds16w(yh_ + off, yd_ + sl * 1024);                                                                                 \
             if (NPL == 2) glds16w(yl_ + off, yd_ + WG_Y_BYTES + sl * 1024);                                                      \
@@ -495,7 +504,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
             for (int ks = 0; ks < WG_TW / 16; ++ks) {
                 uint4 fa[NPL];
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
+                for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);      // K step j = 2 rr + ks
                 if (do_bias) {                                    // dY x ones: every column of the tile holds sum_k dY[row][k]
                     accb = mfma_e<FMT>(fa[0], ones, accb);
                     if (NPL == 2) accb = mfma_e<FMT>(fa[NPL - 1], ones, accb);
@@ -506,7 +515,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                     uint4 fb[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
-                        fb[pl] = frag_tr(sx + pl * WG_X_BYTES + ((rr + t / 3) * (WG_TW + 2) + ks * 16 + t % 3) * 16);
+                        fb[pl] = frag_tr(sx + pl * WG_X_BYTES + (SH == 0 ? ((rr + t / 3) * (TW + 2) + ks * 16 + t % 3)
+                                                                       : SH == 1 ? ((2 * rr + ks + t / 3) * (TW + 2) + t % 3)
+                                                                                 : ((4 * rr + 2 * ks + t / 3) * (TW + 2) + t % 3)) * 16);
                     if (NPL == 2) {
                         acc[t] = mfma_e<FMT>(fa[1], fb[0], acc[t]);
                         acc[t] = mfma_e<FMT>(fa[0], fb[NPL - 1], acc[t]);
@@ -575,18 +586,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 // tile i (one 32-channel quad of one parity) has non-zero weights only at the taps S2D_TAPS[i & 3] — five copies of the body, picked by a
 // uniform switch, each with its tap set as a compile-time constant
 constexpr int S2D_TAPS[4] = {432, 216, 54, 27};
+template <int NPL, int NST, int FMT, int SH>
+__device__ __forceinline__ void wgrad_dispatch_taps(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
+    const int cit = group / a.mt;
+    if (a.tapmode == 1 && cit < a.ncit_main) {
+        switch (cit & 3) {
+            case 0: wgrad_body<NPL, NST, FMT, S2D_TAPS[0], SH>(a, group, slice, smem); return;
+            case 1: wgrad_body<NPL, NST, FMT, S2D_TAPS[1], SH>(a, group, slice, smem); return;
+            case 2: wgrad_body<NPL, NST, FMT, S2D_TAPS[2], SH>(a, group, slice, smem); return;
+            default: wgrad_body<NPL, NST, FMT, S2D_TAPS[3], SH>(a, group, slice, smem); return;
+        }
+    }
+    wgrad_body<NPL, NST, FMT, 0x1FF, SH>(a, group, slice, smem);
+}
 template <int NPL, int NST, int FMT, bool S2D>
 __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     if constexpr (S2D) {
-        const int cit = group / a.mt;
-        if (a.tapmode == 1 && cit < a.ncit_main) {
-            switch (cit & 3) {
-                case 0: wgrad_body<NPL, NST, FMT, S2D_TAPS[0]>(a, group, slice, smem); return;
-                case 1: wgrad_body<NPL, NST, FMT, S2D_TAPS[1]>(a, group, slice, smem); return;
-                case 2: wgrad_body<NPL, NST, FMT, S2D_TAPS[2]>(a, group, slice, smem); return;
-                default: wgrad_body<NPL, NST, FMT, S2D_TAPS[3]>(a, group, slice, smem); return;
-            }
-        }
+        if (a.shape == 1) return wgrad_dispatch_taps<NPL, NST, FMT, 1>(a, group, slice, smem);
+        if (a.shape == 2) return wgrad_dispatch_taps<NPL, NST, FMT, 2>(a, group, slice, smem);
+        return wgrad_dispatch_taps<NPL, NST, FMT, 0>(a, group, slice, smem);
     }
     wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
 }
@@ -643,12 +661,24 @@ __global__ void wgrad_reduce_batch_kernel(const WgradArgs* __restrict__ table) {
 }
 
 // grid decomposition shared by the workspace query and the launch
-struct WgradPlan { int tiles_x, tiles_y, ncit_main, ncit, ngroups, nslices, mt; };
-static WgradPlan wgrad_plan(const esr_wgrad_desc* d, int target_wgs = 512) {
+struct WgradPlan { int tiles_x, tiles_y, ncit_main, ncit, ngroups, nslices, mt, shape; };
+static bool desc_is_s2d(const esr_wgrad_desc* d) {
+    return d->tap_masks[0] == 432 && d->tap_masks[1] == 216 && d->tap_masks[2] == 54 && d->tap_masks[3] == 27 && d->cin_main % 128 == 0 &&
+           d->dy.fmt != ESR_FMT_F16;
+}
+// shapes: the launch runs the kernel flavour that has the 16x16 / 32x8 pixel tiles (the space-to-depth one): take the shape with the fewest tiles
+static WgradPlan wgrad_plan(const esr_wgrad_desc* d, int target_wgs = 512, bool shapes = false) {
     WgradPlan p;
     p.mt = (d->cout + 31) / 32;
+    p.shape = 0;
     p.tiles_x = (d->W + WG_TW - 1) / WG_TW;
     p.tiles_y = (d->H + WG_TH - 1) / WG_TH;
+    if (shapes && (d->upsample <= 1))
+        for (int sh = 1; sh <= 2; ++sh) {
+            const int tw = WG_TW >> sh, th = WG_TH << sh;
+            const int tx = (d->W + tw - 1) / tw, ty = (d->H + th - 1) / th;
+            if ((long long)tx * ty < (long long)p.tiles_x * p.tiles_y) { p.tiles_x = tx; p.tiles_y = ty; p.shape = sh; }
+        }
     p.ncit_main = (d->cin_main + 31) / 32;
     const int lat = d->xlat.hi ? d->lat : 0;
     p.ncit = p.ncit_main + (lat ? 1 : 0);
@@ -676,6 +706,7 @@ static int wgrad_validate(const esr_wgrad_desc* d) {
 
 static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* ws) {
     WgradArgs a{};
+    a.shape = p.shape;
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
     a.xlat = to_dview(d->xlat);
@@ -699,6 +730,7 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     a.ws = ws;
     // (a hint: any other mask pattern accumulates all nine taps — zeros where the weights are structurally zero)
     a.tapmode = (d->tap_masks[0] == 432 && d->tap_masks[1] == 216 && d->tap_masks[2] == 54 && d->tap_masks[3] == 27 && d->cin_main % 128 == 0) ? 1 : 0;
+
     return a;
 }
 
@@ -720,8 +752,8 @@ static size_t wgrad_lds(int npl, int nst) {
 // it takes to keep a workgroup's share near total / 768 (three waves of workgroups over the chip): with hundreds of equal layers
 // that is one slice each (no partial sums at all), a few big high-resolution layers get several, a small net gets many.
 struct BatchPlan { int64_t unit, nwg, table_bytes, map_bytes, partial_floats; };
-static WgradPlan batch_entry_plan(const esr_wgrad_desc* d, int64_t unit) {
-    WgradPlan p = wgrad_plan(d, 1);
+static WgradPlan batch_entry_plan(const esr_wgrad_desc* d, int64_t unit, bool shapes) {
+    WgradPlan p = wgrad_plan(d, 1, shapes);
     const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * d->B;
     int64_t ns = (ntiles + unit - 1) / unit;
     if (ns > ntiles) ns = ntiles;
@@ -729,16 +761,22 @@ static WgradPlan batch_entry_plan(const esr_wgrad_desc* d, int64_t unit) {
     p.nslices = (int)ns;
     return p;
 }
+static bool batch_is_s2d(const esr_wgrad_desc* descs, int n) {
+    for (int i = 0; i < n; ++i)
+        if (desc_is_s2d(&descs[i])) return true;
+    return false;
+}
 static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
     BatchPlan b{};
     int64_t work = 0;
+    const bool shapes = batch_is_s2d(descs, n);
     for (int i = 0; i < n; ++i) {
-        const WgradPlan p = wgrad_plan(&descs[i], 1);
+        const WgradPlan p = wgrad_plan(&descs[i], 1, shapes);
         work += (int64_t)p.ngroups * p.tiles_x * p.tiles_y * descs[i].B;
     }
     b.unit = work / 768 > 0 ? work / 768 : 1;
     for (int i = 0; i < n; ++i) {
-        const WgradPlan p = batch_entry_plan(&descs[i], b.unit);
+        const WgradPlan p = batch_entry_plan(&descs[i], b.unit, shapes);
         b.nwg += (int64_t)p.ngroups * p.nslices;
         b.partial_floats += wgrad_partial_floats(p);
     }
@@ -754,7 +792,7 @@ extern "C" void esr_debug_trace_wgrad(void* buf) { (void)hipMemcpyToSymbol(HIP_S
 #endif
 extern "C" int64_t esr_conv3x3_wgrad_workspace_floats(const esr_wgrad_desc* d) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || d->cin_main <= 0) return ESR_E_ARG;
-    const int64_t n = wgrad_partial_floats(wgrad_plan(d));
+    const int64_t n = wgrad_partial_floats(wgrad_plan(d, 512, desc_is_s2d(d)));
     return n > 0 ? n : 1;
 }
 
@@ -762,7 +800,7 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const int rc = wgrad_validate(d);
     if (rc != ESR_OK) return rc;
     if (!d->workspace || d->workspace_floats < esr_conv3x3_wgrad_workspace_floats(d)) return ESR_E_ARG;
-    const WgradPlan p = wgrad_plan(d);
+    const WgradPlan p = wgrad_plan(d, 512, desc_is_s2d(d));
     const WgradArgs a = wgrad_args(d, p, d->workspace);
     const bool split = d->dy.lo != nullptr;
     const int nst = wgrad_stages();
@@ -806,11 +844,12 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     const BatchPlan b = batch_plan(descs, n);
     std::vector<WgradArgs> table(n);
     std::vector<int4> map((size_t)b.nwg);
+    const bool shapes = batch_is_s2d(descs, n);
     float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
     int64_t w = 0, pf = 0;
     int max_red = 0;
     for (int i = 0; i < n; ++i) {
-        const WgradPlan p = batch_entry_plan(&descs[i], b.unit);
+        const WgradPlan p = batch_entry_plan(&descs[i], b.unit, shapes);
         table[i] = wgrad_args(&descs[i], p, partials + pf);
         pf += wgrad_partial_floats(p);
         // slice-major inside a layer so that co-running workgroups of one layer read different images
