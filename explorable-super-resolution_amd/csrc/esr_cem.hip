@@ -12,6 +12,7 @@
 // These are HBM/L2-bound streaming kernels (<= 0.1 % of the generator's FLOPs): one output per thread, coalesced along W,
 // taps through the scalar cache.
 #include "esr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -425,6 +426,148 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
     }
 }
 
+// Streaming form of the separable downscale (round 3).  The tile kernel above stages a ((DT-1) sf + k)^2 window per 16x16 outputs — 109 KB of
+// LDS at sf = 8, k = 45: one workgroup per CU, every one of its seven load batches a full memory round trip (1.9 ms per configs[4] batch,
+// 0.43 TB/s).  Here a workgroup owns a strip of 32 output columns x DS_ROWS output rows and walks down the high-resolution rows 8 at a time:
+// load 8 window rows (coalesced 16-byte vectors, the next step's loads in flight under this step's arithmetic), horizontal pass (thread =
+// (row, output column): k taps out of the de-interleaved row images) into a ring of the last RING h-rows, then every output row whose k
+// h-rows are complete is emitted (vertical pass out of the ring).  ~18 KB of LDS: eight workgroups per CU cover each other's latencies; the
+// window overlap re-reads 1.1-1.2x of g instead of 1.7x.  Same index rules (clamped window = replicate padding, strided pick at `pre`),
+// same fused  lr_pad - D(y)  output as the tile kernel; the sums run in the same order (horizontal a0/a1 pairs, then vertical).
+constexpr int DS_COLS = 32, DS_ROWS = 64, DS_STEP = 8, DS_RPT = DS_STEP / 8;      // window rows per step; rows per thread in the horizontal pass
+template <int SFT>
+__global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* __restrict__ y, int h, int w, int sf_rt, int pre, const float* __restrict__ tv,
+                                                                 const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
+                                                                 float* __restrict__ d, int qpitch, int ring) {
+    extern __shared__ float tile[];          // [sf][DS_STEP][qpitch] de-interleaved window rows | ring [ring][DS_COLS + 1] of horizontal-pass rows
+    const int sf = SFT ? SFT : sf_rt;
+    const int p = k / 2, Hh = h * sf, Wh = w * sf;
+    const int j0 = blockIdx.x * DS_COLS, i0 = blockIdx.y * DS_ROWS;
+    const int nrow = min(DS_ROWS, h - i0);                   // output rows of this strip
+    const long long bc = blockIdx.z;
+    const float* src = y + bc * Hh * (long long)Wh;
+    const int Yb = sf * i0 + pre - p, Xb = sf * j0 + pre - p;
+    const int cols = (DS_COLS - 1) * sf + k;
+    const int nwin = (nrow - 1) * sf + k;                    // window rows of the strip
+    const int lg = (sf & (sf - 1)) == 0 ? __builtin_ctz(sf) : -1;
+    float* const hp = tile + sf * DS_STEP * qpitch;
+    // the taps out of LDS (broadcast reads): as global loads inside the tap loops they were a dependent L1 round trip per FMA, every step
+    float* const tvs = hp + ring * (DS_COLS + 1);
+    float* const ths = tvs + k;
+    for (int e = threadIdx.x; e < k; e += 256) { tvs[e] = tv[e]; ths[e] = th[e]; }
+    const int Xa = (Xb >> 2) << 2;                           // floor to a multiple of 4 (arithmetic shift: also for negative Xb)
+    const int nvec = (Xb + cols - Xa + 3) >> 2;
+    const bool vec_ok = (Wh & 3) == 0 && (((size_t)src) & 15) == 0;
+    constexpr int SB = 4;                                    // 16-byte vectors per thread per step: DS_STEP * nvec <= 256 * SB (checked by the host)
+    constexpr int PD = 2;                                    // steps of loads in flight (a step's arithmetic is much shorter than a memory round trip)
+    // A thread's SB vectors sit at the same (row of the step, column) every step: the index arithmetic (two integer divisions, the clamps, the
+    // de-interleaved LDS addresses of the four elements) is done ONCE — per step a vector costs one row clamp and one multiply.  (Recomputed
+    // every step it was ~1000 VALU instructions per thread and step: the kernel was bound by its own address arithmetic.)
+    int vr[SB], vx[SB], vdst[SB][4];
+    bool vfast[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+        const int e = threadIdx.x + u * 256;
+        const int r = e / nvec;
+        vr[u] = r < DS_STEP ? r : -1;
+        vx[u] = Xa + 4 * (e - r * nvec);
+        vfast[u] = vec_ok && vx[u] >= 0 && vx[u] + 3 < Wh;
+        const int c0 = vx[u] - Xb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = c0 + t;
+            const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+            vdst[u][t] = (r < DS_STEP && c >= 0 && c < cols) ? (ph * DS_STEP + r) * qpitch + q : -1;
+        }
+    }
+    float4 tmp[PD][SB];
+    auto issue = [&](auto SLOT, const int step) {
+        constexpr int S = decltype(SLOT)::value;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            tmp[S][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int wr = step * DS_STEP + vr[u];
+            if (vr[u] >= 0 && wr < nwin) {
+                const int x = vx[u];
+                const float* rowp = src + (long long)clampi(Yb + wr, 0, Hh - 1) * Wh;
+                if (vfast[u]) tmp[S][u] = *(const float4*)(rowp + x);
+                else tmp[S][u] = make_float4(rowp[clampi(x, 0, Wh - 1)], rowp[clampi(x + 1, 0, Wh - 1)], rowp[clampi(x + 2, 0, Wh - 1)], rowp[clampi(x + 3, 0, Wh - 1)]);
+            }
+        }
+    };
+    const int nsteps = (nwin + DS_STEP - 1) / DS_STEP;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int next_i = 0;                                          // first output row not emitted yet
+    auto body = [&](auto SLOT, const int step) {
+        constexpr int S = decltype(SLOT)::value;
+        // registers -> de-interleaved row images
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const float v[4] = {tmp[S][u].x, tmp[S][u].y, tmp[S][u].z, tmp[S][u].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (vdst[u][t] >= 0) tile[vdst[u][t]] = v[t];
+        }
+        __syncthreads();
+        if (step + PD < nsteps) issue(SLOT, step + PD);      // this slot's registers are free again: PD steps of loads stay in flight
+        {   // horizontal (strided) pass: thread (ty, tx) -> window row step*8 + ty, output column tx
+            // (taps in index order, eight LDS reads in flight per batch: as a nested run-time loop of dependent read -> FMA pairs the pass cost
+            // an LDS round trip per tap — 2.7 us per step, more than the step's memory traffic)
+            // each thread runs DS_RPT window rows (ty, ty + 8, ...) of its output column: a tap is read (and its phase / column computed) once
+            // per DS_RPT products
+            float acc[DS_RPT];
+#pragma unroll
+            for (int j = 0; j < DS_RPT; ++j) acc[j] = 0.f;
+            const float* const pl = tile + ty * qpitch + tx;
+#pragma unroll 4
+            for (int c = 0; c < k; ++c) {
+                const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+                const float tc = ths[c];
+                const float* const pc = pl + ph * DS_STEP * qpitch + q;
+#pragma unroll
+                for (int j = 0; j < DS_RPT; ++j) acc[j] = fmaf(tc, pc[j * 8 * qpitch], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < DS_RPT; ++j)
+                hp[((step * DS_STEP + ty + 8 * j) & (ring - 1)) * (DS_COLS + 1) + tx] = acc[j];
+        }
+        __syncthreads();
+        // vertical pass: output rows whose last window row (i sf + k - 1) is inside the rows done so far; up to DS_STEP of them per step
+        const int done = min((step + 1) * DS_STEP, nwin);
+        int last_i = (done - k) >= 0 ? (done - k) / sf : -1;
+        if (last_i > nrow - 1) last_i = nrow - 1;
+        for (int ib = next_i; ib <= last_i; ib += 8) {
+            const int il = ib + ty;
+            const int i = i0 + il, j = j0 + tx;
+            if (il <= last_i && j < w) {
+                float a0 = 0.f, a1 = 0.f;
+                const int r0 = il * sf;
+#pragma unroll 8
+                for (int a = 0; a < k; ++a) {
+                    const float v = tvs[a] * hp[((r0 + a) & (ring - 1)) * (DS_COLS + 1) + tx];
+                    if (a & 1) a1 += v; else a0 += v;
+                }
+                float acc = a0 + a1;
+                if (lr) {
+                    const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
+                    acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
+                }
+                d[(bc * h + i) * (long long)w + j] = acc;
+            }
+        }
+        if (last_i >= next_i) next_i = last_i + 1;
+        __syncthreads();                                     // the ring rows read above may be overwritten two steps from now; the tile right away
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    static_assert(PD == 2, "two register slots");
+    issue(I0{}, 0);
+    if (1 < nsteps) issue(I1{}, 1);
+    for (int step = 0; step < nsteps; step += PD) {
+        body(I0{}, step);
+        if (step + 1 < nsteps) body(I1{}, step + 1);
+    }
+}
+
 // Polyphase upscale, separable: the vertical pass combines, for every output ROW of the tile, the <= ceil(k/sf) window rows whose taps land on
 // samples (plus the pre == 0 replicate rule) into one row of window-column values; the horizontal pass does the same along the row.
 template <bool TWO, int SFT>
@@ -626,6 +769,33 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
                                      int lr_pad, float* d, esr_stream_t stream) {
     if (!y || !tv || !th || !d || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 1 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
     if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
+    if ((long long)B * C > 65535) return ESR_E_UNSUPPORTED;
+    {
+        // streaming kernel: strips of DS_COLS x DS_ROWS outputs, DS_STEP window rows per step
+        const int cols = (DS_COLS - 1) * sf + k;
+        int ring = 16;
+        while (ring < k + 2 * DS_STEP + sf) ring <<= 1;       // rows an un-emitted output still needs + the step being written
+        int qp = (cols + sf - 1) / sf + 1;
+        qp |= 1;
+        const size_t lds_s = ((size_t)sf * DS_STEP * qp + (size_t)ring * (DS_COLS + 1) + 2 * (size_t)k) * 4;
+        const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * 4 && lds_s <= 64 * 1024;
+        static const int force = getenv("ESR_CEM_DOWN") ? atoi(getenv("ESR_CEM_DOWN")) : 0;      // experiments: 1 = tile kernel, 2 = streaming kernel
+        // measured: configs[4] (sf 8, k 45: 109 KB tile window, one workgroup per CU) 1.88 -> 1.05 ms; configs[1] (sf 4, k 17: 24 KB)
+        // 111 -> 135 us — the streaming kernel pays ~1 us of barriers and LDS round trips per 8 rows, the tile kernel only loses where its
+        // window crowds the CU
+        const int rows_t = (DT - 1) * sf + k;
+        const size_t lds_tile = ((size_t)sf * rows_t * ((rows_t + sf - 1) / sf + 2) + (size_t)rows_t * (DT + 1)) * 4;
+        if (fits && (force == 2 || (force == 0 && lds_tile > 64 * 1024))) {
+            ESR_CLEAR_ERR();
+            void (*ks)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int) =
+                sf == 2 ? cem_downscale_stream_kernel<2> : sf == 3 ? cem_downscale_stream_kernel<3> : sf == 4 ? cem_downscale_stream_kernel<4>
+                : sf == 8 ? cem_downscale_stream_kernel<8> : cem_downscale_stream_kernel<0>;
+            hipLaunchKernelGGL(ks, dim3((w + DS_COLS - 1) / DS_COLS, (h + DS_ROWS - 1) / DS_ROWS, B * C), dim3(256), lds_s, (hipStream_t)stream, y, h, w, sf, pre, tv,
+                               th, k, lr, lr_pad, d, qp, ring);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
     const int rows = (DT - 1) * sf + k, qcols = (rows + sf - 1) / sf + 1;
     int qpitch = qcols;
     while ((sf * qpitch) % 32 != 16 && qpitch < qcols + 32) ++qpitch;

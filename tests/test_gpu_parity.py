@@ -350,6 +350,35 @@ def test_c2_rrdb23_probe_matches_reference_golden(precision, tol):
     assert e1 < tol and e2 < tol, (precision, e1, e2)
 
 
+@pytest.mark.parametrize('kernel', [None, 'blurry_cubic_2.0'])
+def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
+    """x8 kernels (k = 33 / 45) take the streaming form of the separable downscale (csrc/esr_cem.hip: strips of 32 x 64 outputs walked 8 window
+    rows at a time through a ring of horizontal-pass rows): 150 x 70 outputs = 3 x 3 strips with ragged last strips, plain and fused
+    (lr_pad - D(y)) outputs, against the k^2 2-D kernel."""
+    from esr_hip import cem_ops
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    import CEM.CEMnet as C
+    sf = 8
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    td = G.DownscaleOP.taps()
+    pre = sf - sf // 2 - 1
+    h, w = 150, 70
+    y = seeded_uniform((2, 3, sf * h, sf * w), 311).to(DEV)
+    lr = seeded_uniform((2, 3, h - 8, w - 8), 312).to(DEV)
+    try:
+        cem_ops.USE_SEPARABLE = True
+        a = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=4)]
+        cem_ops.USE_SEPARABLE = False
+        b = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=4)]
+    finally:
+        cem_ops.USE_SEPARABLE = True
+    imresize.kernels = {}
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max()))
+
+
 # ---- separable CEM fast path (rank-one taps: bicubic ds_kernel / inv_hTh) against the general 2-D kernels
 @pytest.mark.parametrize('sf,kernel', [(2, None), (3, None), (4, None), (8, None), (4, 'blurry_cubic_1.0')])
 def test_separable_cem_kernels_match_the_2d_kernels(sf, kernel):
