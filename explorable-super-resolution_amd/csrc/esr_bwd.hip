@@ -335,6 +335,7 @@ struct WgradArgs {
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
     int tapmode;               // 1: esr_wgrad_desc.tap_masks name the space-to-depth pattern (S2D_TAPS below); 0: all taps
+    int latk;                  // 1: the latent tile (lat <= 3 channels) runs the one-MFMA-tile form (wgrad_body<..., LATK>)
     int shape;                 // pixel tile of this layer: 0 = 8 rows x 32 columns, 1 = 16 x 16, 2 = 32 x 8 (narrow maps; S2D kernels only)
 };
 #ifdef ESR_TRACE
@@ -387,8 +388,12 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
 // layers; the small ones stacked into one tall image) fills 100 / 80 / 40 % of its tiles instead of 50 / 20 / 10 %.  The dY plane stays the
 // tile's pixels in row-major order (K step j = pixels 16 j .. 16 j + 15), the haloed X tile has pitch TW + 2: a K step is half a row, a row,
 // or two rows of it.
-template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0>
+// LATK (compile time; lat <= 3, 8 x 32 tiles): the workgroup owns the LATENT input tile.  Its <= 3 channels x 9 taps are <= 27 columns: they are
+// laid out as the N axis of ONE MFMA tile — lane n gathers channel n % 3 at tap n / 3 for its 8 pixels (ds_read_u16) — so a K step is 1 (3 in
+// split) MFMAs instead of 9 (27), and only wave 0 copies input (the one group there is).
+template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0, bool LATK = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
+    static_assert(!LATK || (SH == 0 && TM == 0x1FF), "the latent-tile form exists for the plain 8 x 32 tiles");
     constexpr int TW = 32 >> SH, TH = 8 << SH, LGW = 5 - SH;
     constexpr int XPS = (TH + 2) * (TW + 2);                     // haloed pixels of this shape (<= XP, the plane stride)
     static_assert(XPS <= XP && TW * TH == YP, "tile shapes share the LDS plane sizes");
@@ -441,6 +446,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
         const uint4* const xl_ = NPL == 2 ? xv.lo + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs : nullptr;                            \
         const unsigned xd_ = (ST) + wave * XP * 16;                                                                              \
         _Pragma("unroll") for (int sl = 0; sl < XSLOTS; ++sl) {                                                                  \
+            if (LATK && NST == 1 && wave > 0) break;                /* the latent tile is one group: nobody reads planes 1-3 */    \
             const int p = sl * 64 + lane;                                                                                        \
             const int rr = p / (TW + 2), cc = p - rr * (TW + 2);                                                                 \
             const int Yp = y0_ + rr, Xp = x0_ + cc;                 /* padded output-resolution coords of the haloed tile */     \
@@ -505,6 +511,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
                 uint4 fa[NPL];
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);      // K step j = 2 rr + ks
+                if constexpr (LATK) {
+                    // B fragment by gather: this lane's column n = lane & 31 -> (tap n / 3, channel n % 3); its 8 K values are pixels
+                    // kblk * 8 .. + 7 of the K step at that tap's shift
+                    const int n = lane & 31, tcol = n < 27 ? n / 3 : 8, ccol = n < 27 ? n % 3 : 0;
+                    const unsigned char* const gx = smem + cur * STAGE + ((rr + tcol / 3) * (TW + 2) + ks * 16 + (lane >> 5) * 8 + tcol % 3) * 16 + ccol * 2;
+                    uint4 fbk[NPL];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        const unsigned char* const g0 = gx + pl * WG_X_BYTES;
+                        uint32_t w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            w[q] = (uint32_t)(*(const unsigned short*)(g0 + (2 * q) * 16)) | ((uint32_t)(*(const unsigned short*)(g0 + (2 * q + 1) * 16)) << 16);
+                        fbk[pl] = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (NPL == 2) {
+                        acc[0] = mfma_e<FMT>(fa[1], fbk[0], acc[0]);
+                        acc[0] = mfma_e<FMT>(fa[0], fbk[NPL - 1], acc[0]);
+                    }
+                    acc[0] = mfma_e<FMT>(fa[0], fbk[0], acc[0]);
+                    continue;
+                }
                 if (do_bias) {                                    // dY x ones: every column of the tile holds sum_k dY[row][k]
                     accb = mfma_e<FMT>(fa[0], ones, accb);
                     if (NPL == 2) accb = mfma_e<FMT>(fa[NPL - 1], ones, accb);
@@ -538,6 +566,26 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
     float* const red = (float*)smem;                             // [wave][tap in pass][16][64]
     const bool direct = a.nslices == 1;
     float* const wsp = direct ? nullptr : a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
+    if constexpr (LATK) {
+        // one accumulator tile per wave: column n = (tap n / 3, channel n % 3); summed over the waves it is scattered to where the nine-tap form
+        // puts the same numbers (dW, or this slice's partial tiles — wgrad_reduce_body reads only the channels < lat of a latent tile)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[0][i];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += red[w4 * 1024 + e];
+            const int ln = e & 63, i = e >> 6, n = ln & 31, half = ln >> 5;
+            if (n >= 27) continue;
+            const int t = n / 3, c = n % 3;
+            if (c >= a.lat) continue;
+            const int co = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (direct) { if (co < a.cout) a.dw[((long long)co * a.cin_total + c) * 9 + t] += a.alpha * v; }
+            else wsp[t * 1024 + i * 64 + half * 32 + c] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int t0 = pass * 5, nt = pass == 0 ? 5 : 4;
@@ -606,11 +654,12 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int gro
         if (a.shape == 2) return wgrad_dispatch_taps<NPL, NST, FMT, 2>(a, group, slice, smem);
         return wgrad_dispatch_taps<NPL, NST, FMT, 0>(a, group, slice, smem);
     }
+    if (a.latk && group / a.mt >= a.ncit_main) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, true>(a, group, slice, smem);
     wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
 }
 
 template <int NPL, int NST, int FMT, bool S2D = false>
-__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     wgrad_dispatch<NPL, NST, FMT, S2D>(a, blockIdx.x / a.nslices, blockIdx.x % a.nslices, smem);
 }
@@ -619,7 +668,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_kernel(co
 // slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
 template <int NPL, int NST, int FMT, bool S2D = false>
-__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
+__global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
@@ -707,6 +756,8 @@ static int wgrad_validate(const esr_wgrad_desc* d) {
 static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* ws) {
     WgradArgs a{};
     a.shape = p.shape;
+    static const bool latk_off = getenv("ESR_WGRAD_LATK") && atoi(getenv("ESR_WGRAD_LATK")) == 0;       // experiments: the nine-tap form for the latent tile too
+    a.latk = (d->xlat.hi && d->lat > 0 && d->lat <= 3 && !latk_off) ? 1 : 0;
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
     a.xlat = to_dview(d->xlat);
@@ -738,9 +789,13 @@ static inline int64_t wgrad_partial_floats(const WgradPlan& p) {
     return p.nslices == 1 ? 0 : (int64_t)p.ngroups * p.nslices * (9 * 1024) + (int64_t)p.mt * p.nslices * 32;
 }
 
-static int wgrad_stages() {                 // experiments: ESR_WGRAD_STAGES=1|2
-    static const int v = getenv("ESR_WGRAD_STAGES") ? atoi(getenv("ESR_WGRAD_STAGES")) : 1;
-    return v == 2 ? 2 : 1;
+// LDS stages of the tile loop.  One-plane operands (bf16 / f16): two stages AND two workgroups per CU (2 x 2 x 38 KB + nothing else = the
+// 160 KB; four tiles of copies in flight per CU): generator launch 6.57 -> 6.14 ms, critic launches 675 -> 575 us at the configs[2] shapes.
+// hi+lo operands: one stage, two workgroups (two stages would leave one workgroup per CU: measured slower).  ESR_WGRAD_STAGES=1|2 forces one.
+static int wgrad_stages(bool one_plane) {
+    static const int v = getenv("ESR_WGRAD_STAGES") ? atoi(getenv("ESR_WGRAD_STAGES")) : 0;
+    if (v == 1 || v == 2) return v;
+    return one_plane ? 2 : 1;
 }
 static size_t wgrad_lds(int npl, int nst) {
     const size_t stages = (size_t)nst * npl * (WG_X_BYTES + WG_Y_BYTES), red = (size_t)4 * 5 * 1024 * 4;
@@ -803,8 +858,8 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     const WgradPlan p = wgrad_plan(d, 512, desc_is_s2d(d));
     const WgradArgs a = wgrad_args(d, p, d->workspace);
     const bool split = d->dy.lo != nullptr;
-    const int nst = wgrad_stages();
-    const bool f16 = d->dy.fmt == ESR_FMT_F16;                    // fp16 operands: single plane only (wgrad_validate)
+    const bool f16 = d->dy.fmt == ESR_FMT_F16;
+    const int nst = wgrad_stages(!split);                    // fp16 operands: single plane only (wgrad_validate)
     void (*k)(const WgradArgs) = f16 ? (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 1> : conv3x3_wgrad_kernel<1, 1, 1>)
                                : split ? (nst == 2 ? conv3x3_wgrad_kernel<2, 2, 0> : conv3x3_wgrad_kernel<2, 1, 0>)
                                        : (nst == 2 ? conv3x3_wgrad_kernel<1, 2, 0> : conv3x3_wgrad_kernel<1, 1, 0>);
@@ -878,8 +933,8 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
 extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
     if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int nst = wgrad_stages();
     const bool f16 = plan->f16 != 0, split = plan->split != 0;
+    const int nst = wgrad_stages(!split);
     void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
                                              : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
                                                      : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
