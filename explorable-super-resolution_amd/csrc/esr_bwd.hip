@@ -671,6 +671,7 @@ template <int NPL, int NST, int FMT, bool S2D = false>
 __global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
+    if (m.x < 0) return;                                         // padding of the XCD-aware order (uniform)
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
     wgrad_dispatch<NPL, NST, FMT, S2D>(a, group, slice, smem);
@@ -835,6 +836,7 @@ static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
         b.nwg += (int64_t)p.ngroups * p.nslices;
         b.partial_floats += wgrad_partial_floats(p);
     }
+    b.nwg = (b.nwg + 1023) / 1024 * 1024;                       // the grid: padded so that any run length of the XCD-aware order (<= 128) tiles it
     b.table_bytes = (((int64_t)n * sizeof(WgradArgs)) + 255) / 256 * 256;
     b.map_bytes = ((b.nwg * (int64_t)sizeof(int4)) + 255) / 256 * 256;
     return b;
@@ -898,7 +900,8 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
     const BatchPlan b = batch_plan(descs, n);
     std::vector<WgradArgs> table(n);
-    std::vector<int4> map((size_t)b.nwg);
+    std::vector<int4> work;                                      // the work list in its natural order: layer, slice, group
+    work.reserve((size_t)b.nwg);
     const bool shapes = batch_is_s2d(descs, n);
     float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
     int64_t w = 0, pf = 0;
@@ -909,8 +912,24 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
         pf += wgrad_partial_floats(p);
         // slice-major inside a layer so that co-running workgroups of one layer read different images
         for (int sl = 0; sl < p.nslices; ++sl)
-            for (int g = 0; g < p.ngroups; ++g) map[(size_t)w++] = make_int4(i, g, sl, 0);
+            for (int g = 0; g < p.ngroups; ++g) { work.push_back(make_int4(i, g, sl, 0)); ++w; }
         if (p.nslices > 1 && p.ngroups * 9 * 1024 + p.mt * 32 > max_red) max_red = p.ngroups * 9 * 1024 + p.mt * 32;
+    }
+    // Order of the work list over the XCDs.  The hardware deals workgroup b to XCD b % 8, so the groups of one layer (same dY tiles for a cot, same
+    // X tiles for a cit: neighbours in the list) run on eight different L2s: 25 GB of L2 misses per configs[2] launch (bf16) for 1.9 GB of distinct
+    // operands, hit rate 32 %.  Handing each XCD runs of `run` consecutive items cuts the misses (9 vs 12.5 M FETCH_SIZE units at a whole eighth per
+    // XCD) — and does NOT buy time: 6.26 (dealt) / 6.10 (runs of 4) / 6.20 (16) / 7.51 (64) / 7.09 ms (an eighth each; the critic's ten unequal
+    // layers 0.60 / 0.60 / 0.65 / 0.71 / 1.83 ms): long runs unbalance the XCDs, and the launch is bound by neither the fabric nor the MFMA pipe
+    // (37 % busy) but by each workgroup's copy -> wait -> multiply chain.  Runs of 4: the traffic saving that costs nothing.
+    std::vector<int4> map((size_t)b.nwg, make_int4(-1, 0, 0, 0));
+    {
+        // ESR_WGRAD_ORDER (experiments): 0 = the dealt order, n > 0 = runs of n consecutive work items per XCD, dealt round-robin
+        static const int run = getenv("ESR_WGRAD_ORDER") ? atoi(getenv("ESR_WGRAD_ORDER")) : 4;
+        for (int64_t blk = 0; blk < b.nwg; ++blk) {
+            const int64_t xcd = blk % 8, k = blk / 8;
+            const int64_t item = run <= 0 ? blk : ((k / run) * 8 + xcd) * run + k % run;
+            if (item < (int64_t)work.size()) map[(size_t)blk] = work[(size_t)item];
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     // pageable host memory: the runtime stages it before returning (the vectors go out of scope); a host-blocking copy, not graph-capturable —
