@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __re
         const float* row = tile + r * pitch + lx;
         float a0 = 0.f, a1 = 0.f;
         int c = 0;
+#pragma unroll 4
         for (; c + 1 < k; c += 2) { a0 = fmaf(th[c], row[c], a0); a1 = fmaf(th[c + 1], row[c + 1], a1); }
         if (c < k) a0 = fmaf(th[c], row[c], a0);
         hp[r * (LT_TX + 1) + lx] = a0 + a1;
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __re
         const float* col = hp + ty * (LT_TX + 1) + lx;
         float a0 = 0.f, a1 = 0.f;
         int a = 0;
+#pragma unroll 4
         for (; a + 1 < k; a += 2) { a0 = fmaf(tv[a], col[a * (LT_TX + 1)], a0); a1 = fmaf(tv[a + 1], col[(a + 1) * (LT_TX + 1)], a1); }
         if (a < k) a0 = fmaf(tv[a], col[a * (LT_TX + 1)], a0);
         const int Y = y0 + ty, X = x0 + lx;
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
         for (int ph = 0; ph < sf; ++ph) {
             const float* pl = tile + (ph * rows + r) * qpitch + tx;
             int c = ph, q = 0;
+#pragma unroll 4
             for (; c + sf < k; c += 2 * sf, q += 2) { a0 = fmaf(th[c], pl[q], a0); a1 = fmaf(th[c + sf], pl[q + 1], a1); }
             if (c < k) a0 = fmaf(th[c], pl[q], a0);
         }
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
         const float* col = hp + ty * sf * (DT + 1) + tx;
         float a0 = 0.f, a1 = 0.f;
         int a = 0;
+#pragma unroll 4
         for (; a + 1 < k; a += 2) { a0 = fmaf(tv[a], col[a * (DT + 1)], a0); a1 = fmaf(tv[a + 1], col[(a + 1) * (DT + 1)], a1); }
         if (a < k) a0 = fmaf(tv[a], col[a * (DT + 1)], a0);
         float acc = a0 + a1;
