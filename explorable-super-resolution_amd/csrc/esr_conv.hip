@@ -963,8 +963,13 @@ int launch(const ConvArgs& a, hipStream_t s) {
         const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
         if (!force && small && a.ncp >= (EPI == EPI_NCHW ? 8 : 16) && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
     }
-    const bool two = force ? force == 2 : small;
-    return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
+    // the tap-masked kernels with hi+lo operands (four / two copies of the chunk body with their own tap sets) do not fit the 256 registers of
+    // the two-workgroups-per-CU form — they spilled 34-168 VGPRs to scratch: always the two-stage form (one workgroup per CU, 512 registers)
+    if constexpr (TMODE != 0 && NPL == 2) return launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s);
+    else {
+        const bool two = force ? force == 2 : small;
+        return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
+    }
 }
 
 // the epilogue combinations the RRDB forward / backward plans use
