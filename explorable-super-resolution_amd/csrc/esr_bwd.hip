@@ -714,7 +714,16 @@ __device__ __forceinline__ void wgrad_block_body(const WgradArgs& a, const int c
     const int ys_off = ybase + co * WG_Y_BYTES + rb2 * YPP * 16 + frag_off;         // + pl * nco * WG_Y_BYTES
     const int nxs = nci * 4 * XSLOTS, nslots = nxs + nco * 4 * YSLOTS;              // copy slots per plane of a tile
 
+#ifdef ESR_TRACE
+    unsigned long long* const tr = (g_wtrace && blockIdx.x < 1792) ? g_wtrace + (size_t)(blockIdx.x + 2304) * 64 : nullptr;       // (slots 2304.. of the 4096: the per-pair launch of the same step uses the first ones)
+    int tslot = 2;
+    if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[62] = wall_clock64(); }
+#define ESR_BTR() do { if (tr && tid == 0 && tslot < 57) tr[tslot++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESR_BTR() do { } while (0)
+#endif
     for (int tile = slice; tile < ntiles; tile += a.nslices) {
+        ESR_BTR();
         const int tx_ = tile % a.tiles_x;
         const int r1_ = tile / a.tiles_x;
         const int ty_ = r1_ % a.tiles_y;
@@ -750,8 +759,11 @@ __device__ __forceinline__ void wgrad_block_body(const WgradArgs& a, const int c
                 if (NPL == 2) glds16w(a.dy.lo + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs + off, dst + nco * WG_Y_BYTES);
             }
         }
+        ESR_BTR();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ESR_BTR();
         __syncthreads();
+        ESR_BTR();
         if (active) {
             const unsigned char* const sx = smem + xs_off;
             const unsigned char* const sy = smem + ys_off;
@@ -781,8 +793,13 @@ __device__ __forceinline__ void wgrad_block_body(const WgradArgs& a, const int c
                 }
             }
         }
+        ESR_BTR();
         __syncthreads();
     }
+#ifdef ESR_TRACE
+    if (tr && tid == 0) { tr[1] = tslot; tr[63] = wall_clock64(); }
+#endif
+#undef ESR_BTR
     if (!active) return;
     // ---- every wave owns its pair for all pixels of the slice: straight into dW / db, or this slice's partial tiles in the per-pair kernel's layout
     const int group = cit * a.mt + cot;

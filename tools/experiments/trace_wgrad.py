@@ -27,6 +27,10 @@ lib.esr_debug_trace_wgrad(tb.data_ptr())
 m.feed_data(data); m.optimize_parameters(); torch.cuda.synchronize()
 lib.esr_debug_trace_wgrad(None)
 t = tb.cpu().numpy().reshape(nwg, 64).astype(np.int64)
+if os.environ.get('TRACE_BLOCKS') == '1':      # the block-form launch's slots (conv3x3_wgrad_block_kernel writes from slot 2304 on)
+    t = t[2304:]
+else:
+    t = t[:2304]
 t = t[t[:, 1] > 0]
 n = len(t)
 rt0, rt1 = t[:, 62], t[:, 63]
