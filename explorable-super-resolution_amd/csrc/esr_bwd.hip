@@ -335,6 +335,7 @@ struct WgradArgs {
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
     int tapmode;               // 1: esr_wgrad_desc.tap_masks name the space-to-depth pattern (S2D_TAPS below); 0: all taps
+    int slide;                 // 1: the plain body builds the horizontal taps' fragments by sliding one window in registers (wgrad_body<..., SLIDE>)
     int latk;                  // 1: the latent tile (lat <= 3 channels) runs the one-MFMA-tile form (wgrad_body<..., LATK>)
     int shape;                 // pixel tile of this layer: 0 = 8 rows x 32 columns, 1 = 16 x 16, 2 = 32 x 8 (narrow maps; S2D kernels only)
 };
@@ -391,8 +392,14 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
 // LATK (compile time; lat <= 3, 8 x 32 tiles): the workgroup owns the LATENT input tile.  Its <= 3 channels x 9 taps are <= 27 columns: they are
 // laid out as the N axis of ONE MFMA tile — lane n gathers channel n % 3 at tap n / 3 for its 8 pixels (ds_read_u16) — so a K step is 1 (3 in
 // split) MFMAs instead of 9 (27), and only wave 0 copies input (the one group there is).
-template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0, bool LATK = false>
+// SLIDE (compile time; plain 8 x 32 tiles, all taps): the three horizontal taps of a row are ONE window slid by 0 / 1 / 2 pixels.  The K axis
+// is pixels and a lane holds 8 consecutive ones of its channel, so the slid fragments are built in registers — the two K steps of a row and
+// the two halo pixels behind them are read once (5 transposing reads per plane and row of taps instead of 12), the next two pixels cross
+// the lane halves with v_permlane32_swap, dx = 1 is a 16-bit funnel shift (v_alignbit), dx = 2 a register rename.  The contraction issues
+// 2.2 ds_read_b64_tr_b16 per MFMA otherwise, on an LDS pipe its four waves and the copy engine share.
+template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0, bool LATK = false, bool SLIDE = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
+    static_assert(!SLIDE || (SH == 0 && TM == 0x1FF && !LATK), "the sliding-window form exists for the plain 8 x 32 tiles");
     static_assert(!LATK || (SH == 0 && TM == 0x1FF), "the latent-tile form exists for the plain 8 x 32 tiles");
     constexpr int TW = 32 >> SH, TH = 8 << SH, LGW = 5 - SH;
     constexpr int XPS = (TH + 2) * (TW + 2);                     // haloed pixels of this shape (<= XP, the plane stride)
@@ -506,6 +513,59 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #pragma unroll
         for (int rq = 0; rq < WG_TH / 4; ++rq) {
             const int rr = wave + rq * 4;
+            if constexpr (SLIDE) {
+                uint4 fa2[2][NPL];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) fa2[ks][pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
+                if (do_bias) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        accb = mfma_e<FMT>(fa2[ks][0], ones, accb);
+                        if (NPL == 2) accb = mfma_e<FMT>(fa2[ks][NPL - 1], ones, accb);
+                    }
+                }
+                const bool lower = lane < 32;
+                // (address of the halo read: every lane group points at the same 4 pixels — columns 32..35 of the haloed row)
+                const int e_off = rb2 * XP * 16 + (li >> 2) * 16 + (li & 1) * 8 - xs_off;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    uint4 w[2][3][NPL];                        // [K step][dx][plane]
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        const unsigned char* const rowp = sx + pl * WG_X_BYTES + ((rr + dy) * (TW + 2)) * 16;
+                        const uint4 f0 = frag_tr(rowp), f1 = frag_tr(rowp + 16 * 16);
+                        typedef __attribute__((address_space(3))) s16x4* lptr;
+                        const s16x4 er = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(size_t)(rowp + e_off + 32 * 16));
+                        const uint32_t e = __builtin_bit_cast(uint2, er).x;                       // pixels 32, 33 of this lane's channel
+                        const auto s01 = __builtin_amdgcn_permlane32_swap(f0.x, f1.x, false, false);   // [f0.lo | f1.lo], [f0.hi | f1.hi]
+                        const auto s1e = __builtin_amdgcn_permlane32_swap(f1.x, e, false, false);      // [f1.lo | e.lo],  [f1.hi | e.hi]
+                        const uint32_t n0 = lower ? s01[1] : s01[0];                               // pixels 8, 9 | 16, 17
+                        const uint32_t n1 = lower ? s1e[1] : e;                                    // pixels 24, 25 | 32, 33
+                        w[0][0][pl] = f0;
+                        w[0][1][pl] = make_uint4(__builtin_amdgcn_alignbit(f0.y, f0.x, 16), __builtin_amdgcn_alignbit(f0.z, f0.y, 16),
+                                                 __builtin_amdgcn_alignbit(f0.w, f0.z, 16), __builtin_amdgcn_alignbit(n0, f0.w, 16));
+                        w[0][2][pl] = make_uint4(f0.y, f0.z, f0.w, n0);
+                        w[1][0][pl] = f1;
+                        w[1][1][pl] = make_uint4(__builtin_amdgcn_alignbit(f1.y, f1.x, 16), __builtin_amdgcn_alignbit(f1.z, f1.y, 16),
+                                                 __builtin_amdgcn_alignbit(f1.w, f1.z, 16), __builtin_amdgcn_alignbit(n1, f1.w, 16));
+                        w[1][2][pl] = make_uint4(f1.y, f1.z, f1.w, n1);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int t = dy * 3 + dx;
+                            if (NPL == 2) {
+                                acc[t] = mfma_e<FMT>(fa2[ks][1], w[ks][dx][0], acc[t]);
+                                acc[t] = mfma_e<FMT>(fa2[ks][0], w[ks][dx][NPL - 1], acc[t]);
+                            }
+                            acc[t] = mfma_e<FMT>(fa2[ks][0], w[ks][dx][0], acc[t]);
+                        }
+                }
+                continue;
+            }
 #pragma unroll
             for (int ks = 0; ks < WG_TW / 16; ++ks) {
                 uint4 fa[NPL];
@@ -655,6 +715,7 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int gro
         return wgrad_dispatch_taps<NPL, NST, FMT, 0>(a, group, slice, smem);
     }
     if (a.latk && group / a.mt >= a.ncit_main) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, true>(a, group, slice, smem);
+    if (a.slide) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, false, true>(a, group, slice, smem);
     wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
 }
 
@@ -922,6 +983,10 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     a.shape = p.shape;
     static const bool latk_off = getenv("ESR_WGRAD_LATK") && atoi(getenv("ESR_WGRAD_LATK")) == 0;       // experiments: the nine-tap form for the latent tile too
     a.latk = (d->xlat.hi && d->lat > 0 && d->lat <= 3 && !latk_off) ? 1 : 0;
+    // EXPERIMENT, off by default (ESR_WGRAD_SLIDE=1): same results (all dW goldens), 2.4x fewer transposing LDS reads in the tap loop — and 5 %
+    // SLOWER (configs[2] launch, bf16: 6.26 vs 5.94 ms): the LDS reads are not what the launch waits for either
+    static const bool slide_on = getenv("ESR_WGRAD_SLIDE") && atoi(getenv("ESR_WGRAD_SLIDE")) == 1;
+    a.slide = slide_on ? 1 : 0;
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
     a.xlat = to_dview(d->xlat);
