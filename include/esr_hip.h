@@ -284,6 +284,8 @@ int esr_conv3x3_wgrad_batch(const esr_wgrad_desc* descs, int n, void* workspace,
  * allocator handing back the same dW storage): _upload writes the descriptor table into `workspace` (a host-blocking copy from pageable
  * memory: NOT capturable in a HIP graph) and fills `plan`; _run enqueues the launch from the table already on the device (capturable; no
  * host traffic).  esr_conv3x3_wgrad_batch == _upload followed by _run. */
+/* (plan fields are the library's own bookkeeping between _upload and _run — opaque to callers: nwg = workgroups of the per-pair launch, `reserved` =
+ * block-form items | their LDS KiB << 23 when the experimental block decomposition is enabled, 0 otherwise) */
 typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16, s2d, reserved; } esr_wgrad_batch_plan;
 int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                    esr_stream_t stream);
