@@ -8,7 +8,6 @@
 //   ReplicationPad2d            codes/CEM/CEMnet.py:70-71,286-295                           -> fold the pad ring into the edge pixels
 //   bilinear /sf of the latent  codes/models/modules/architecture.py:284                    -> spread each LR gradient over its taps
 #include "esr_common.h"
-#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -335,7 +334,6 @@ struct WgradArgs {
     float* db;
     float* ws;                 // partial sums: [group][slice][9*1024], then the bias partials [cout tile][slice][32]
     int tapmode;               // 1: esr_wgrad_desc.tap_masks name the space-to-depth pattern (S2D_TAPS below); 0: all taps
-    int slide;                 // 1: the plain body builds the horizontal taps' fragments by sliding one window in registers (wgrad_body<..., SLIDE>)
     int latk;                  // 1: the latent tile (lat <= 3 channels) runs the one-MFMA-tile form (wgrad_body<..., LATK>)
     int shape;                 // pixel tile of this layer: 0 = 8 rows x 32 columns, 1 = 16 x 16, 2 = 32 x 8 (narrow maps; S2D kernels only)
 };
@@ -392,14 +390,8 @@ __device__ __forceinline__ f32x16_t mfma_e(uint4 a, uint4 b, f32x16_t c) {
 // LATK (compile time; lat <= 3, 8 x 32 tiles): the workgroup owns the LATENT input tile.  Its <= 3 channels x 9 taps are <= 27 columns: they are
 // laid out as the N axis of ONE MFMA tile — lane n gathers channel n % 3 at tap n / 3 for its 8 pixels (ds_read_u16) — so a K step is 1 (3 in
 // split) MFMAs instead of 9 (27), and only wave 0 copies input (the one group there is).
-// SLIDE (compile time; plain 8 x 32 tiles, all taps): the three horizontal taps of a row are ONE window slid by 0 / 1 / 2 pixels.  The K axis
-// is pixels and a lane holds 8 consecutive ones of its channel, so the slid fragments are built in registers — the two K steps of a row and
-// the two halo pixels behind them are read once (5 transposing reads per plane and row of taps instead of 12), the next two pixels cross
-// the lane halves with v_permlane32_swap, dx = 1 is a 16-bit funnel shift (v_alignbit), dx = 2 a register rename.  The contraction issues
-// 2.2 ds_read_b64_tr_b16 per MFMA otherwise, on an LDS pipe its four waves and the copy engine share.
-template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0, bool LATK = false, bool SLIDE = false>
+template <int NPL, int NST, int FMT, int TM = 0x1FF, int SH = 0, bool LATK = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
-    static_assert(!SLIDE || (SH == 0 && TM == 0x1FF && !LATK), "the sliding-window form exists for the plain 8 x 32 tiles");
     static_assert(!LATK || (SH == 0 && TM == 0x1FF), "the latent-tile form exists for the plain 8 x 32 tiles");
     constexpr int TW = 32 >> SH, TH = 8 << SH, LGW = 5 - SH;
     constexpr int XPS = (TH + 2) * (TW + 2);                     // haloed pixels of this shape (<= XP, the plane stride)
@@ -513,59 +505,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #pragma unroll
         for (int rq = 0; rq < WG_TH / 4; ++rq) {
             const int rr = wave + rq * 4;
-            if constexpr (SLIDE) {
-                uint4 fa2[2][NPL];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fa2[ks][pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
-                if (do_bias) {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        accb = mfma_e<FMT>(fa2[ks][0], ones, accb);
-                        if (NPL == 2) accb = mfma_e<FMT>(fa2[ks][NPL - 1], ones, accb);
-                    }
-                }
-                const bool lower = lane < 32;
-                // (address of the halo read: every lane group points at the same 4 pixels — columns 32..35 of the haloed row)
-                const int e_off = rb2 * XP * 16 + (li >> 2) * 16 + (li & 1) * 8 - xs_off;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    uint4 w[2][3][NPL];                        // [K step][dx][plane]
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) {
-                        const unsigned char* const rowp = sx + pl * WG_X_BYTES + ((rr + dy) * (TW + 2)) * 16;
-                        const uint4 f0 = frag_tr(rowp), f1 = frag_tr(rowp + 16 * 16);
-                        typedef __attribute__((address_space(3))) s16x4* lptr;
-                        const s16x4 er = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(size_t)(rowp + e_off + 32 * 16));
-                        const uint32_t e = __builtin_bit_cast(uint2, er).x;                       // pixels 32, 33 of this lane's channel
-                        const auto s01 = __builtin_amdgcn_permlane32_swap(f0.x, f1.x, false, false);   // [f0.lo | f1.lo], [f0.hi | f1.hi]
-                        const auto s1e = __builtin_amdgcn_permlane32_swap(f1.x, e, false, false);      // [f1.lo | e.lo],  [f1.hi | e.hi]
-                        const uint32_t n0 = lower ? s01[1] : s01[0];                               // pixels 8, 9 | 16, 17
-                        const uint32_t n1 = lower ? s1e[1] : e;                                    // pixels 24, 25 | 32, 33
-                        w[0][0][pl] = f0;
-                        w[0][1][pl] = make_uint4(__builtin_amdgcn_alignbit(f0.y, f0.x, 16), __builtin_amdgcn_alignbit(f0.z, f0.y, 16),
-                                                 __builtin_amdgcn_alignbit(f0.w, f0.z, 16), __builtin_amdgcn_alignbit(n0, f0.w, 16));
-                        w[0][2][pl] = make_uint4(f0.y, f0.z, f0.w, n0);
-                        w[1][0][pl] = f1;
-                        w[1][1][pl] = make_uint4(__builtin_amdgcn_alignbit(f1.y, f1.x, 16), __builtin_amdgcn_alignbit(f1.z, f1.y, 16),
-                                                 __builtin_amdgcn_alignbit(f1.w, f1.z, 16), __builtin_amdgcn_alignbit(n1, f1.w, 16));
-                        w[1][2][pl] = make_uint4(f1.y, f1.z, f1.w, n1);
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int t = dy * 3 + dx;
-                            if (NPL == 2) {
-                                acc[t] = mfma_e<FMT>(fa2[ks][1], w[ks][dx][0], acc[t]);
-                                acc[t] = mfma_e<FMT>(fa2[ks][0], w[ks][dx][NPL - 1], acc[t]);
-                            }
-                            acc[t] = mfma_e<FMT>(fa2[ks][0], w[ks][dx][0], acc[t]);
-                        }
-                }
-                continue;
-            }
 #pragma unroll
             for (int ks = 0; ks < WG_TW / 16; ++ks) {
                 uint4 fa[NPL];
@@ -715,7 +654,6 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int gro
         return wgrad_dispatch_taps<NPL, NST, FMT, 0>(a, group, slice, smem);
     }
     if (a.latk && group / a.mt >= a.ncit_main) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, true>(a, group, slice, smem);
-    if (a.slide) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, false, true>(a, group, slice, smem);
     wgrad_body<NPL, NST, FMT>(a, group, slice, smem);
 }
 
@@ -736,169 +674,6 @@ __global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_w
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
     wgrad_dispatch<NPL, NST, FMT, S2D>(a, group, slice, smem);
-}
-
-// Block form (round 3).  The per-pair kernel above stages one X tile and one dY tile per 36 MFMAs of each wave — 265 B into LDS per
-// MFMA (bf16) — and its launch sits on the copy engine's per-CU rate (12.4 B/cycle/CU into LDS: 38 GB per configs[2] launch).  Here a workgroup
-// owns a BLOCK of up to four (input tile, output tile) pairs that share their tiles — 2 x 2, or up to 4 x 1 for the 32-channel convs — stages
-// the nci X tiles and nco dY tiles of a pixel tile once, and gives each WAVE one pair: all 16 K steps, all nine taps (+ the bias row for the
-// first input tile): the accumulators of the per-pair kernel, no cross-wave reduction, 132 B (2 x 2) / 180 B (4 x 1) per MFMA.
-// LDS: [plane][X tile] x 4 groups x XP vectors, then [plane][dY tile] x 4 groups x YPP vectors; one stage, vmcnt(0) waits (the copies per wave
-// vary with the block shape); two workgroups per CU where the stage allows it.
-template <int NPL, int FMT>
-__device__ __forceinline__ void wgrad_block_body(const WgradArgs& a, const int cit0, const int nci, const int cot0, const int nco, const int slice,
-                                                 unsigned char* const smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    const int ybase = NPL * nci * WG_X_BYTES;                    // start of the dY planes
-    const bool active = wave < nci * nco;
-    const int ci = active ? wave % nci : 0, co = active ? wave / nci : 0;
-    const int cit = cit0 + ci, cot = cot0 + co;
-
-    f32x16_t acc[9], accb;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accb[i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    const bool do_bias = active && (cit == 0) && a.db;
-    constexpr uint32_t ONE2 = FMT == ESR_FMT_F16 ? 0x3C003C00u : 0x3F803F80u;
-    const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
-    const int li = lane & 15, grp16 = lane >> 4;
-    const int rb2 = (grp16 & 1) * 2 + ((li & 3) >> 1);
-    const int kb = (grp16 >> 1) * 8 + (li >> 2);
-    const int frag_off = kb * 16 + (li & 1) * 8;
-    const int xs_off = ci * WG_X_BYTES + rb2 * XP * 16 + frag_off;                  // + pl * nci * WG_X_BYTES
-    const int ys_off = ybase + co * WG_Y_BYTES + rb2 * YPP * 16 + frag_off;         // + pl * nco * WG_Y_BYTES
-    const int nxs = nci * 4 * XSLOTS, nslots = nxs + nco * 4 * YSLOTS;              // copy slots per plane of a tile
-
-#ifdef ESR_TRACE
-    unsigned long long* const tr = (g_wtrace && blockIdx.x < 1792) ? g_wtrace + (size_t)(blockIdx.x + 2304) * 64 : nullptr;       // (slots 2304.. of the 4096: the per-pair launch of the same step uses the first ones)
-    int tslot = 2;
-    if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[62] = wall_clock64(); }
-#define ESR_BTR() do { if (tr && tid == 0 && tslot < 57) tr[tslot++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ESR_BTR() do { } while (0)
-#endif
-    for (int tile = slice; tile < ntiles; tile += a.nslices) {
-        ESR_BTR();
-        const int tx_ = tile % a.tiles_x;
-        const int r1_ = tile / a.tiles_x;
-        const int ty_ = r1_ % a.tiles_y;
-        const int b_ = r1_ / a.tiles_y;
-        const int x0_ = tx_ * WG_TW, y0_ = ty_ * WG_TH;
-        for (int sl = wave; sl < nslots; sl += 4) {                                  // (wave-uniform)
-            if (sl < nxs) {
-                const int grp = sl / XSLOTS, ss = sl - grp * XSLOTS;                 // group of the block's X tiles (4 per tile), slot inside it
-                const int xcg = cit0 * 4 + grp;
-                const bool xhave = xcg < a.x.ncg;
-                const int p = ss * 64 + lane;
-                const int rr = p / (WG_TW + 2), cc = p - rr * (WG_TW + 2);
-                const int Yp = y0_ + rr, Xp = x0_ + cc;
-                int sy = Yp, sx = Xp;
-                if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
-                else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-                const int off = (xhave && Yp < a.H + 2 && Xp < a.W + 2) ? sy * a.Wx_p + sx : 0;
-                if (p < XP) {
-                    const unsigned dst = lds0 + (unsigned)(grp * XP + ss * 64) * 16;
-                    glds16w(a.x.hi + b_ * a.x.bs + (xhave ? xcg : 0) * a.x.cs + off, dst);
-                    if (NPL == 2) glds16w(a.x.lo + b_ * a.x.bs + (xhave ? xcg : 0) * a.x.cs + off, dst + nci * WG_X_BYTES);
-                }
-            } else {
-                const int s2 = sl - nxs;
-                const int grp = s2 / YSLOTS, ss = s2 - grp * YSLOTS;
-                const int ycg = cot0 * 4 + grp;
-                const bool yhave = ycg < a.dy.ncg;
-                const int p = ss * 64 + lane;
-                const int Y = y0_ + (p >> 5), X = x0_ + (p & 31);
-                const int off = (yhave && Y < a.H && X < a.W) ? (Y + 1) * (a.W + 2) + (X + 1) : 0;
-                const unsigned dst = lds0 + (unsigned)ybase + (unsigned)(grp * YPP + ss * 64) * 16;
-                glds16w(a.dy.hi + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs + off, dst);
-                if (NPL == 2) glds16w(a.dy.lo + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs + off, dst + nco * WG_Y_BYTES);
-            }
-        }
-        ESR_BTR();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ESR_BTR();
-        __syncthreads();
-        ESR_BTR();
-        if (active) {
-            const unsigned char* const sx = smem + xs_off;
-            const unsigned char* const sy = smem + ys_off;
-#pragma unroll 2
-            for (int rr = 0; rr < WG_TH; ++rr) {
-#pragma unroll
-                for (int ks = 0; ks < WG_TW / 16; ++ks) {
-                    uint4 fa[NPL];
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * nco * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);
-                    if (do_bias) {
-                        accb = mfma_e<FMT>(fa[0], ones, accb);
-                        if (NPL == 2) accb = mfma_e<FMT>(fa[NPL - 1], ones, accb);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        uint4 fb[NPL];
-#pragma unroll
-                        for (int pl = 0; pl < NPL; ++pl)
-                            fb[pl] = frag_tr(sx + pl * nci * WG_X_BYTES + ((rr + t / 3) * (WG_TW + 2) + ks * 16 + t % 3) * 16);
-                        if (NPL == 2) {
-                            acc[t] = mfma_e<FMT>(fa[1], fb[0], acc[t]);
-                            acc[t] = mfma_e<FMT>(fa[0], fb[NPL - 1], acc[t]);
-                        }
-                        acc[t] = mfma_e<FMT>(fa[0], fb[0], acc[t]);
-                    }
-                }
-            }
-        }
-        ESR_BTR();
-        __syncthreads();
-    }
-#ifdef ESR_TRACE
-    if (tr && tid == 0) { tr[1] = tslot; tr[63] = wall_clock64(); }
-#endif
-#undef ESR_BTR
-    if (!active) return;
-    // ---- every wave owns its pair for all pixels of the slice: straight into dW / db, or this slice's partial tiles in the per-pair kernel's layout
-    const int group = cit * a.mt + cot;
-    const bool direct = a.nslices == 1;
-    float* const wsp = direct ? nullptr : a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
-    const int c = lane & 31;
-    const int cin_idx = (cit * 32 + c < a.cin_main) ? a.lat + cit * 32 + c : -1;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (direct) {
-                const int co_ = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (co_ < a.cout && cin_idx >= 0) a.dw[((long long)co_ * a.cin_total + cin_idx) * 9 + t] += a.alpha * acc[t][i];
-            } else {
-                wsp[t * 1024 + i * 64 + lane] = acc[t][i];
-            }
-        }
-    if (do_bias && c == 0) {
-        // column 0 of the dY x ones tile: row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (direct) { if (cot * 32 + row < a.cout) a.db[cot * 32 + row] += a.alpha * accb[i]; }
-            else a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = accb[i];
-        }
-    }
-}
-
-// map entry: x = table entry, y = cit0 | nci << 8 | cot0 << 16 | nco << 24, z = slice
-template <int NPL, int FMT>
-__global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv3x3_wgrad_block_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int4 m = map[blockIdx.x];
-    if (m.x < 0) return;
-    const int e = __builtin_amdgcn_readfirstlane(m.x), blk = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
-    const WgradArgs a = table[e];
-    wgrad_block_body<NPL, FMT>(a, blk & 0xFF, (blk >> 8) & 0xFF, (blk >> 16) & 0xFF, (blk >> 24) & 0xFF, slice, smem);
 }
 
 // dW += alpha * sum over slices of the partial tiles; one thread per (group, accumulator element), plus cout threads for the bias
@@ -981,12 +756,7 @@ static int wgrad_validate(const esr_wgrad_desc* d) {
 static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* ws) {
     WgradArgs a{};
     a.shape = p.shape;
-    static const bool latk_off = getenv("ESR_WGRAD_LATK") && atoi(getenv("ESR_WGRAD_LATK")) == 0;       // experiments: the nine-tap form for the latent tile too
-    a.latk = (d->xlat.hi && d->lat > 0 && d->lat <= 3 && !latk_off) ? 1 : 0;
-    // EXPERIMENT, off by default (ESR_WGRAD_SLIDE=1): same results (all dW goldens), 2.4x fewer transposing LDS reads in the tap loop — and 5 %
-    // SLOWER (configs[2] launch, bf16: 6.26 vs 5.94 ms): the LDS reads are not what the launch waits for either
-    static const bool slide_on = getenv("ESR_WGRAD_SLIDE") && atoi(getenv("ESR_WGRAD_SLIDE")) == 1;
-    a.slide = slide_on ? 1 : 0;
+    a.latk = (d->xlat.hi && d->lat > 0 && d->lat <= 3) ? 1 : 0;
     a.dy = to_dview(d->dy);
     a.x = to_dview(d->x);
     a.xlat = to_dview(d->xlat);
@@ -1020,12 +790,8 @@ static inline int64_t wgrad_partial_floats(const WgradPlan& p) {
 
 // LDS stages of the tile loop.  One-plane operands (bf16 / f16): two stages AND two workgroups per CU (2 x 2 x 38 KB + nothing else = the
 // 160 KB; four tiles of copies in flight per CU): generator launch 6.57 -> 6.14 ms, critic launches 675 -> 575 us at the configs[2] shapes.
-// hi+lo operands: one stage, two workgroups (two stages would leave one workgroup per CU: measured slower).  ESR_WGRAD_STAGES=1|2 forces one.
-static int wgrad_stages(bool one_plane) {
-    static const int v = getenv("ESR_WGRAD_STAGES") ? atoi(getenv("ESR_WGRAD_STAGES")) : 0;
-    if (v == 1 || v == 2) return v;
-    return one_plane ? 2 : 1;
-}
+// hi+lo operands: one stage, two workgroups (two stages would leave one workgroup per CU: measured slower).
+static int wgrad_stages(bool one_plane) { return one_plane ? 2 : 1; }
 static size_t wgrad_lds(int npl, int nst) {
     const size_t stages = (size_t)nst * npl * (WG_X_BYTES + WG_Y_BYTES), red = (size_t)4 * 5 * 1024 * 4;
     return stages > red ? stages : red;
@@ -1040,10 +806,6 @@ static WgradPlan batch_entry_plan(const esr_wgrad_desc* d, int64_t unit, bool sh
     WgradPlan p = wgrad_plan(d, 1, shapes);
     const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * d->B;
     int64_t ns = (ntiles + unit - 1) / unit;
-    // layers whose pairs run as 2 x 2 blocks: a workgroup does four pairs' work per tile — slice the pixel sum so that the block launch still
-    // has several workgroups per CU (their partial tiles go through the workspace like any sliced layer's)
-    static const bool blocks_off = !(getenv("ESR_WGRAD_BLOCKS") && atoi(getenv("ESR_WGRAD_BLOCKS")) >= 1);
-    if (!blocks_off && p.shape == 0 && !desc_is_s2d(d) && p.mt >= 2 && p.ncit_main >= 2) ns = (8 * ntiles + unit - 1) / unit;
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     p.nslices = (int)ns;
@@ -1054,42 +816,10 @@ static bool batch_is_s2d(const esr_wgrad_desc* descs, int n) {
         if (desc_is_s2d(&descs[i])) return true;
     return false;
 }
-// The work items of one layer: blocks of >= 3 (input tile, output tile) pairs sharing tiles (conv3x3_wgrad_block_kernel: 2 x 2, or up to 4 x 1
-// for 32-channel outputs with one-plane operands) and, for what is left (latent tile, remainders, space-to-depth layers, narrow-map shapes), the
-// per-pair items.  Block item: y = cit0 | nci << 8 | cot0 << 16 | nco << 24.
-static void entry_work(int i, const esr_wgrad_desc* d, const WgradPlan& p, bool split, std::vector<int4>& pairs, std::vector<int4>& blocks, size_t& lds_blocks) {
-    // OFF by default (ESR_WGRAD_BLOCKS=1: the 2 x 2 blocks, 2: also the n x 1 ones).  Measured at the configs[2] shape, bf16, same box: step 33.0-33.8
-    // vs 31.9-32.6 ms with the 2 x 2 blocks properly sliced (39-42 ms with too few workgroups, or with the 104 KB n x 1 blocks at one workgroup
-    // per CU): halving the bytes copied into LDS per MFMA buys nothing, so the copy engine's rate is not what limits the per-pair launch either
-    // (DESIGN 3.3 lists what the counters do and do not show).  Kept as the starting point for a form with two output tiles per WAVE (one
-    // tap-shifted X fragment feeding two MFMAs), the one register-level reuse this contraction still offers.
-    static const int mode = getenv("ESR_WGRAD_BLOCKS") ? atoi(getenv("ESR_WGRAD_BLOCKS")) : 0;
-    static const bool off = mode < 1;
-    static const bool only22 = mode != 2;
-    std::vector<char> covered((size_t)p.ngroups, 0);
-    std::vector<int> blk;
-    if (!off && p.shape == 0 && !desc_is_s2d(d)) {
-        const int npl = split ? 2 : 1;
-        for (int cot0 = 0; cot0 < p.mt; cot0 += 2) {
-            const int nco = p.mt - cot0 < 2 ? p.mt - cot0 : 2;
-            const int nci_max = nco == 2 ? 2 : (split ? 2 : 4);
-            for (int cit0 = 0; cit0 < p.ncit_main; cit0 += nci_max) {
-                const int nci = p.ncit_main - cit0 < nci_max ? p.ncit_main - cit0 : nci_max;
-                if (nci * nco < 3 || (only22 && nco != 2)) continue;
-                blk.push_back(cit0 | nci << 8 | cot0 << 16 | nco << 24);
-                for (int a = 0; a < nci; ++a)
-                    for (int c = 0; c < nco; ++c) covered[(size_t)(cit0 + a) * p.mt + cot0 + c] = 1;
-                const size_t lds = (size_t)npl * ((size_t)nci * WG_X_BYTES + (size_t)nco * WG_Y_BYTES);
-                if (lds > lds_blocks) lds_blocks = lds;
-            }
-        }
-    }
-    // slice-major inside a layer so that co-running workgroups of one layer read different images
-    for (int sl = 0; sl < p.nslices; ++sl) {
-        for (int b : blk) blocks.push_back(make_int4(i, b, sl, 0));
-        for (int g = 0; g < p.ngroups; ++g)
-            if (!covered[(size_t)g]) pairs.push_back(make_int4(i, g, sl, 0));
-    }
+// The work items of one layer, slice-major so that co-running workgroups of one layer read different images
+static void entry_work(int i, const WgradPlan& p, std::vector<int4>& pairs) {
+    for (int sl = 0; sl < p.nslices; ++sl)
+        for (int g = 0; g < p.ngroups; ++g) pairs.push_back(make_int4(i, g, sl, 0));
 }
 static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
     BatchPlan b{};
@@ -1105,7 +835,7 @@ static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
         b.nwg += (int64_t)p.ngroups * p.nslices;
         b.partial_floats += wgrad_partial_floats(p);
     }
-    b.nwg = (b.nwg + 1023) / 1024 * 1024 + 1024;                // map entries: the per-pair items padded to whole rounds of the XCD-aware order, then the blocks
+    b.nwg = (b.nwg + 1023) / 1024 * 1024;                       // map entries: the work items padded to whole rounds of the XCD-aware order
     b.table_bytes = (((int64_t)n * sizeof(WgradArgs)) + 255) / 256 * 256;
     b.map_bytes = ((b.nwg * (int64_t)sizeof(int4)) + 255) / 256 * 256;
     return b;
@@ -1169,9 +899,8 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
     const BatchPlan b = batch_plan(descs, n);
     std::vector<WgradArgs> table(n);
-    std::vector<int4> work, blocks;                              // the per-pair work list in its natural order (layer, slice, group); the block items
+    std::vector<int4> work;                                      // the work list in its natural order (layer, slice, group)
     work.reserve((size_t)b.nwg);
-    size_t lds_blocks = 0;
     const bool shapes = batch_is_s2d(descs, n);
     float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
     int64_t pf = 0;
@@ -1180,7 +909,7 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
         const WgradPlan p = batch_entry_plan(&descs[i], b.unit, shapes);
         table[i] = wgrad_args(&descs[i], p, partials + pf);
         pf += wgrad_partial_floats(p);
-        entry_work(i, &descs[i], p, split, work, blocks, lds_blocks);
+        entry_work(i, p, work);
         if (p.nslices > 1 && p.ngroups * 9 * 1024 + p.mt * 32 > max_red) max_red = p.ngroups * 9 * 1024 + p.mt * 32;
     }
     // Order of the work list over the XCDs.  The hardware deals workgroup b to XCD b % 8, so the groups of one layer (same dY tiles for a cot, same
@@ -1190,17 +919,13 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     // layers 0.60 / 0.60 / 0.65 / 0.71 / 1.83 ms): long runs unbalance the XCDs, and the launch is bound by neither the fabric nor the MFMA pipe
     // (37 % busy) but by each workgroup's copy -> wait -> multiply chain.  Runs of 4: the traffic saving that costs nothing.
     std::vector<int4> map((size_t)b.nwg, make_int4(-1, 0, 0, 0));
-    const int64_t npair = ((int64_t)work.size() + 1023) / 1024 * 1024;       // grid of the per-pair launch (0: everything went into blocks)
-    if (npair + (int64_t)blocks.size() > b.nwg || blocks.size() >= (1u << 23)) return ESR_E_UNSUPPORTED;
-    for (size_t k = 0; k < blocks.size(); ++k) map[(size_t)npair + k] = blocks[k];
-    {
-        // ESR_WGRAD_ORDER (experiments): 0 = the dealt order, n > 0 = runs of n consecutive work items per XCD, dealt round-robin
-        static const int run = getenv("ESR_WGRAD_ORDER") ? atoi(getenv("ESR_WGRAD_ORDER")) : 4;
-        for (int64_t blk = 0; blk < npair; ++blk) {
-            const int64_t xcd = blk % 8, k = blk / 8;
-            const int64_t item = run <= 0 ? blk : ((k / run) * 8 + xcd) * run + k % run;
-            if (item < (int64_t)work.size()) map[(size_t)blk] = work[(size_t)item];
-        }
+    const int64_t npair = ((int64_t)work.size() + 1023) / 1024 * 1024;       // grid of the launch
+    if (npair > b.nwg) return ESR_E_UNSUPPORTED;
+    constexpr int64_t run = 4;
+    for (int64_t blk = 0; blk < npair; ++blk) {
+        const int64_t xcd = blk % 8, k = blk / 8;
+        const int64_t item = ((k / run) * 8 + xcd) * run + k % run;
+        if (item < (int64_t)work.size()) map[(size_t)blk] = work[(size_t)item];
     }
     hipStream_t s = (hipStream_t)stream;
     // pageable host memory: the runtime stages it before returning (the vectors go out of scope); a host-blocking copy, not graph-capturable —
@@ -1216,23 +941,14 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     plan->f16 = descs[0].dy.fmt == ESR_FMT_F16 ? 1 : 0;
     plan->s2d = 0;
     for (const WgradArgs& t : table) plan->s2d |= t.tapmode == 1 ? 1 : 0;
-    plan->reserved = (int32_t)blocks.size() | (int32_t)((lds_blocks + 1023) / 1024) << 23;      // block items (map entries nwg ...) | their LDS in KiB
+    plan->reserved = 0;
     return ESR_OK;
 }
 
 extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
-    const int nblk = plan ? (plan->reserved & ((1 << 23) - 1)) : 0;
-    if (!workspace || !plan || plan->n <= 0 || plan->nwg < 0 || (plan->nwg == 0 && nblk == 0)) return ESR_E_ARG;
+    if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = plan->f16 != 0, split = plan->split != 0;
-    if (nblk > 0) {
-        void (*kb)(const WgradArgs*, const int4*) = f16 ? conv3x3_wgrad_block_kernel<1, 1> : split ? conv3x3_wgrad_block_kernel<2, 0> : conv3x3_wgrad_block_kernel<1, 0>;
-        (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        ESR_CLEAR_ERR();
-        hipLaunchKernelGGL(kb, dim3((unsigned)nblk), dim3(256), (size_t)((unsigned)plan->reserved >> 23) * 1024, s, (const WgradArgs*)workspace,
-                           (const int4*)((const char*)workspace + plan->table_bytes) + plan->nwg);
-        ESR_CHECK_LAUNCH();
-    }
     const int nst = wgrad_stages(!split);
     void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
                                              : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
@@ -1241,12 +957,10 @@ extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgra
         k = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0, true> : conv3x3_wgrad_batch_kernel<2, 1, 0, true>)
                   : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0, true> : conv3x3_wgrad_batch_kernel<1, 1, 0, true>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
-    if (plan->nwg > 0) {
-        ESR_CLEAR_ERR();
-        hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
-                           (const int4*)((const char*)workspace + plan->table_bytes));
-        ESR_CHECK_LAUNCH();
-    }
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
+                       (const int4*)((const char*)workspace + plan->table_bytes));
+    ESR_CHECK_LAUNCH();
     if (plan->max_red > 0) {
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((plan->max_red + 255) / 256), (unsigned)plan->n), dim3(256), 0, s,
                            (const WgradArgs*)workspace);

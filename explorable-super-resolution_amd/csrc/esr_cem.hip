@@ -783,13 +783,12 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
         qp |= 1;
         const size_t lds_s = ((size_t)sf * DS_STEP * qp + (size_t)ring * (DS_COLS + 1) + 2 * (size_t)k) * 4;
         const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * 4 && lds_s <= 64 * 1024;
-        static const int force = getenv("ESR_CEM_DOWN") ? atoi(getenv("ESR_CEM_DOWN")) : 0;      // experiments: 1 = tile kernel, 2 = streaming kernel
         // measured: configs[4] (sf 8, k 45: 109 KB tile window, one workgroup per CU) 1.88 -> 1.05 ms; configs[1] (sf 4, k 17: 24 KB)
         // 111 -> 135 us — the streaming kernel pays ~1 us of barriers and LDS round trips per 8 rows, the tile kernel only loses where its
         // window crowds the CU
         const int rows_t = (DT - 1) * sf + k;
         const size_t lds_tile = ((size_t)sf * rows_t * ((rows_t + sf - 1) / sf + 2) + (size_t)rows_t * (DT + 1)) * 4;
-        if (fits && (force == 2 || (force == 0 && lds_tile > 64 * 1024))) {
+        if (fits && lds_tile > 64 * 1024) {
             ESR_CLEAR_ERR();
             void (*ks)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int) =
                 sf == 2 ? cem_downscale_stream_kernel<2> : sf == 3 ? cem_downscale_stream_kernel<3> : sf == 4 ? cem_downscale_stream_kernel<4>

@@ -24,7 +24,6 @@
 //                  (data-gradient use), re-split to hi/lo via v_cvt_pk_bf16_f32, pairs of channel groups exchanged with
 //                  v_permlane32_swap so that every lane stores one full 16-byte pixel vector
 #include "esr_common.h"
-#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -59,37 +58,7 @@ constexpr int WGS_MT1 = ESR_WGS_MT1, WGS_MT2 = ESR_WGS_MT2;   // resident workgr
 constexpr int r_of(int mt) { return mt == 1 ? ESR_R_MT1 : 3; }
 constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE; }
 
-// EXPERIMENT (-DESR_WREG=1; off by default): the weight fragments of the kernels with ONE weight plane (bf16 / f16 / the dense-block convs of
-// 'mixed') bypass LDS — every wave loads the A fragments of the next chunk straight from L2 into registers (global_load_dwordx4: the pack
-// order IS the fragment order) while it multiplies the current one.  Motivation: these kernels looked paced by the per-CU LDS-DMA ingest rate
-// (~26 KB per chunk against 864-1728 MFMA cycles) and the weights are a third of those bytes and a quarter of the LDS operand
-// reads.  Measured, same GPU, results bit-identical (profiles/r02_wreg_ab.log): C2 forward in 'mixed' 39.2 vs 38.7 ms, C3 generator step in
-// bf16 32.1 vs 32.0 ms, C5 inference in f16 78.3 vs 70.8 ms — the 36-72 extra live registers cost more (occupancy of the one-plane 64-channel
-// kernels) than the LDS-DMA bytes they save.  Kept as a build knob because the next attempt at the ingest limit starts from it.
-#ifndef ESR_WREG
-#define ESR_WREG 0
-#endif
-constexpr bool wreg_of(int npw) { return ESR_WREG != 0 && npw == 1; }
-// EXPERIMENT (-DESR_PC=1 builds the variants, ESR_CONV_STAGES=3 selects them at run time): producer / consumer waves for the launches with
-// one workgroup per CU, see NST == 3 at conv3x3_tile_kernel.  Measured at the 32 x 52x52 training shape (same GPU, bit-identical results):
-// 19 % fewer shader cycles per chunk for the split 32-channel kernel (4806 -> 3893) at a 15 % lower shader clock (1.79 -> 1.53 GHz) —
-// 27.9 -> 26.2 us per launch; 72.5 -> 72.5 us for the split 64-channel kernel; bf16 13.3 -> 14.8 and 36.1 -> 30.1 us; whole training step
-// 47.7 -> 47.3 ms (split), 24.5 -> 25.8 ms (bf16) — while the two-stage kernel with the exact, balanced copies of dma_share() alone runs that
-// step in 45.6 ms.  With a ring of THREE stages where they fit (the producers one chunk further ahead, nobody waits at the barrier): split
-// 26.6 / 82.0 us (vs 26.6 / 70.9 two-stage), bf16 15.6 / 31.1 us (vs 14.4 / 37.6), step 46.1 vs 43.7 ms split, 23.4 vs 23.3 ms bf16.
-// The chip gives the saved cycles back as clock, so it is not the default.
-#ifndef ESR_PC
-#define ESR_PC 0
-#endif
-
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-// asynchronous 16-byte global load into a register quad, hidden from the compiler like glds16 (same reason: no vmcnt(0) drains); the value
-// is only valid after the next s_waitcnt vmcnt(...) that covers it — pin_frag() below ties the uses to that wait
-__device__ __forceinline__ void gload16(u32x4& dst, const uint4* src) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-}
-__device__ __forceinline__ void pin_frag(u32x4& f) { asm volatile("" : "+v"(f)); }
-
 // epilogue feature bits (template parameter EPI)
 constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
 // residual 1 is a channel-group slice of the conv's own input (RDB conv5: out = 0.2*conv + x, block.py:235): it is added to the
@@ -113,7 +82,6 @@ struct ConvArgs {
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
-    int pc_stages;                  // producer / consumer kernels (NST == 3): LDS stages in the ring, 2 or 3 (what fits)
     int nslices;                    // cout / 64 when cout > 64, else 1
     long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
     // split K (esr_conv3x3_desc.k_split_ws): blockIdx.z = which run of `ncp` chunks (kz_groups channel groups) of the input this workgroup
@@ -121,6 +89,7 @@ struct ConvArgs {
     int ksplit, kz_groups;
     long long kz_slab;              // floats between two slabs
     int nchw_ctot;                  // channels of the fp32 NCHW destination (== cout unless the launch covers output slices)
+    int stages_hint;                // esr_conv3x3_desc.lds_stages
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -376,18 +345,14 @@ __device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const Con
 // TM0 / TM1 (compile time): 9-bit masks of the taps whose weights are not structurally zero for M tile 0 / 1 of this chunk; the unrolled
 // loops below drop the dead MFMAs and the fragment reads nobody needs (no run-time branches: those cost more than the MFMAs they save)
 template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP, int TM0 = 0x1FF, int TM1 = 0x1FF>
-__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes,
-                                           u32x4 (&wa)[9 * MT], const uint4* wnext) {
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes) {
     constexpr int TMU = TM0 | (MT == 2 ? TM1 : 0);      // taps any M tile needs: the activation fragments to read
 #define ESR_TAP_LIVE(t, m) ((((m) == 0 ? TM0 : TM1) >> (t)) & 1)
-    // wa / wnext (weights-in-registers kernels): wa holds this chunk's A fragments [tap][mtile]; once a tap's MFMAs are issued its slots are
-    // refilled with the NEXT chunk's fragments from wnext (nullptr: last chunk) — in flight for the rest of this chunk's MFMA phase
-    constexpr bool WREG = wreg_of(NPW);
     constexpr int NPB = XLO ? NPL : 1;                                   // activation planes read
     constexpr int NT_FULL = 1 + (NPW == 2 ? 1 : 0) + (NPB == 2 ? 1 : 0);
     constexpr int NTERM = NT_FULL < NTERM_CAP ? NT_FULL : NTERM_CAP;      // NTERM_CAP < 3 only in ablation builds
     constexpr int NM = MT * R * NTERM;
-    constexpr int NLA = WREG ? 0 : MT * NPW, NLB = R * NPB, NL = NLA + NLB;
+    constexpr int NLA = MT * NPW, NLB = R * NPB, NL = NLA + NLB;
     constexpr int NSLOT = NM > NL ? NM : NL;
     uint4 fa[2][MT][NPW], fb[2][R][NPB];
     // read order inside a tap: [A plane of the first term x MT, B hi x R, then the other A plane x MT (if any), B lo x R (if any)] — what
@@ -395,11 +360,6 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
     auto load_frag = [&](int t, int k, int buf) {
         const int tapoff = ((t / 3) * P + (t % 3)) * 16;
         if (!((TMU >> t) & 1)) return;               // nobody multiplies this tap
-        if (WREG) {                                  // only activation fragments come from LDS: [B hi x R, then B lo x R (if any)]
-            if (k < R) fb[buf][k][0] = *(const uint4*)(sb + k * NW * 512 + tapoff);
-            else fb[buf][k - R][NPB - 1] = *(const uint4*)(sb + (k - R) * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
-            return;
-        }
         if (k < MT) {
             const int pl = NPW == 2 ? 1 : 0;
             if (ESR_TAP_LIVE(t, k)) fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
@@ -430,15 +390,9 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
                 const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
                 if (!ESR_TAP_LIVE(t, m)) {
                     // this tap's weights for M tile m are structurally zero (compile-time: t and m are unrolled constants)
-                } else if (WREG) acc[m][r] = mfma<FMT>(__builtin_bit_cast(uint4, wa[t * MT + m]), fb[cb][r][pb], acc[m][r]);
-                else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+                } else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
             }
             if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (WREG && wnext) {                          // this tap's MFMAs are issued: its register slots take the next chunk's fragments
-#pragma unroll
-            for (int m = 0; m < MT; ++m) gload16(wa[t * MT + m], wnext + (t * MT + m) * 64);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -456,14 +410,11 @@ constexpr int S2D_FWD[4] = {432, 216, 54, 27}, S2D_FLIP[4] = {27, 54, 216, 432};
 //   NST == 2: two LDS stages, the DMA of chunk c+1 is issued before the MFMAs of chunk c (counted s_waitcnt keeps it in flight).
 //             Launches with no more tiles than CUs (small images, the 52x52 training crops), where a workgroup has its CU to itself
 //             and nobody else covers its DMA waits.
-//   NST == 3: a ring of two or three LDS stages (what fits) with EIGHT waves: waves 4-7 ("producers") only issue the DMA of the chunks ahead and
-//             wait for the next one, waves 0-3 ("consumers") only multiply chunk c and run the epilogue; one barrier per chunk.  A 1-KiB global_load_lds occupies its in-order
-//             wave for 90-150 cycles (profiles/microbench/ingest_paths.hip: copy and MFMA time ADD UP inside one wave wherever the copies are
-//             placed), so only a second wave on the same SIMD can multiply meanwhile.
+//   NST == 4: a ring of four stages, three chunks of copies in flight: few, small tiles with a long K axis (the critic's deep layers).
 // TMODE: 0 all taps; 1 the K chunks' tap sets follow S2D_FWD by the parity (cp >> 1) & 3 of their channel quad (forward of an embedded stride-2
 // conv); 2 the M tiles' tap sets follow S2D_FLIP by the parity of output tile 2 * slice + m (its data gradient)
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
-__global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
+__global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
     // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
     // same staged input.  All workgroups of all slices are in flight together: a 512-channel layer on an 8x8 map is one launch of
     // 32 x 8 workgroups instead of eight launches of 32.  (Everything below is uniform: the shifts are scalar adds; slice 0 adds zero.)
@@ -495,18 +446,13 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr bool PC = NST == 3;                                  // producer / consumer waves
     constexpr int NSTAGES = NST == 1 ? 1 : (NST == 4 ? 4 : 2);
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = PC && wave_all >= NW;
-    const int wave = PC ? (wave_all % NW) : wave_all;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
-    constexpr bool WREG = wreg_of(NPW);
-    static_assert(!(PC && WREG), "the weights-in-registers experiment has no producer/consumer form");
-    constexpr int NWI = WREG ? 0 : 9 * MT * NPW;                   // weight fragments staged in LDS per chunk
+    constexpr int NWI = 9 * MT * NPW;                              // weight fragments staged in LDS per chunk
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    const int nstg = PC ? a.pc_stages : NSTAGES;
+    constexpr int nstg = NSTAGES;
     float* const s_bias = (float*)(smem + nstg * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
@@ -533,20 +479,12 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
-    static_assert(!(TMODE != 0 && NST == 3), "no producer / consumer form of the tap-masked kernels");
     static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
     constexpr int NTERM_CAP = 3;
-    static_assert(TMODE == 0 || !WREG, "the tap-masked kernels stage their weights through LDS");
     // which 2x2 block of taps chunk c's weights live in (dma_chunk)
     auto tsel_of = [&](const int c) { return TMODE == 1 ? ((c >> 1) & 3) : (TMODE == 2 ? (int)(blockIdx.y & 1) : 0); };
-    u32x4 wa[9 * MT];                                // (WREG) the current chunk's A fragments
-    const uint4* const wbase = a.wpack + lane;       // fragment f of chunk cp: wbase + (cp * 9 * MT + f) * 64
-    if (WREG) {
-#pragma unroll
-        for (int f = 0; f < 9 * MT; ++f) gload16(wa[f], wbase + f * 64);
-    }
     if (NST == 2) {                           // prologue: chunk 0 -> stage 0
         const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
         dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks, tsel_of(0), wave);
@@ -560,47 +498,15 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
                 dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + c * stage_bytes, plane_bytes, true, tsel_of(c), wave);
             }
     }
-    // (producer waves) issue all copies of chunk cp into its ring stage; returns how many this wave issued
-    auto produce = [&](const int cp) {
-        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
-        const bool xl = !PARTLO || cp < a.lo_chunks;
-        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + (cp % nstg) * stage_bytes, plane_bytes, xl, tsel_of(cp), wave);
-        return dma_count<NPL, MT, NPW, TMODE>(share, xl);
-    };
-    if (PC) {
-        if (producer) {
-            produce(0);
-            int ahead = 0;
-            if (nstg == 3 && a.ncp > 1) ahead = produce(1);
-            wait_vm_upto(ahead);                // chunk 0 has landed; chunk 1 may still be in flight
-        }
-        __syncthreads();
-    }
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
     // plane.  The chunks with a lo plane come first, so the K loop is two loops over the same step with XLO = true / false: a run-time
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
     auto step = [&](auto XLO_T, const int cp) {
         constexpr bool xlo = decltype(XLO_T)::value;
-        const int st = PC ? cp % nstg : (NST == 4 ? (cp & 3) : (NST >= 2 ? (cp & 1) : 0));
+        const int st = NST == 4 ? (cp & 3) : (NST >= 2 ? (cp & 1) : 0);
         const unsigned char* const sb = sb0 + st * stage_bytes;
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
-        if constexpr (PC) {
-            // the stage refilled now was last read in iteration cp-1, closed by that iteration's barrier; at THIS iteration's barrier chunk
-            // cp+1 must have landed (with three stages chunk cp+2, just issued, stays in flight)
-            if (producer) {
-                int ahead = 0;
-                if (cp + nstg - 1 < a.ncp) ahead = produce(cp + nstg - 1);
-                wait_vm_upto(nstg == 3 ? ahead : 0);
-            } else {
-                ESR_TR(); ESR_TR(); ESR_TR();
-                chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, nullptr);
-                if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
-            }
-            ESR_TR();
-            __syncthreads();
-            return;
-        }
         if (NST == 1) {
             const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
             DmaShare sh = share;
@@ -633,23 +539,18 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
         ESR_TR();
         __syncthreads();
         ESR_TR();
-        if (WREG) {              // every wait above covers the fragment loads issued during the previous chunk: from here on wa is valid
-#pragma unroll
-            for (int f = 0; f < 9 * MT; ++f) pin_frag(wa[f]);
-        }
-        const uint4* const wnx = (WREG && cp + 1 < a.ncp) ? wbase + (size_t)(cp + 1) * (9 * MT) * 64 : nullptr;
         if constexpr (TMODE == 1) {
             switch ((cp >> 1) & 3) {                 // uniform: four copies of the chunk body, each with its own compile-time tap set
-                case 0: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[0], S2D_FWD[0]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
-                case 1: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[1], S2D_FWD[1]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
-                case 2: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[2], S2D_FWD[2]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
-                default: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[3], S2D_FWD[3]>(acc, sa, sb, P, plane_bytes, wa, wnx); break;
+                case 0: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[0], S2D_FWD[0]>(acc, sa, sb, P, plane_bytes); break;
+                case 1: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[1], S2D_FWD[1]>(acc, sa, sb, P, plane_bytes); break;
+                case 2: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[2], S2D_FWD[2]>(acc, sa, sb, P, plane_bytes); break;
+                default: chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FWD[3], S2D_FWD[3]>(acc, sa, sb, P, plane_bytes); break;
             }
         } else if constexpr (TMODE == 2) {
-            if (blockIdx.y & 1) chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[2], S2D_FLIP[3]>(acc, sa, sb, P, plane_bytes, wa, wnx);
-            else chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[0], S2D_FLIP[1]>(acc, sa, sb, P, plane_bytes, wa, wnx);
+            if (blockIdx.y & 1) chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[2], S2D_FLIP[3]>(acc, sa, sb, P, plane_bytes);
+            else chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP, S2D_FLIP[0], S2D_FLIP[1]>(acc, sa, sb, P, plane_bytes);
         } else {
-            chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes, wa, wnx);
+            chunk_mfma<NPL, MT, R, NPW, FMT, xlo, NTERM_CAP>(acc, sa, sb, P, plane_bytes);
         }
         if constexpr ((EPI & EPI_RESIN) != 0) resin_accumulate<NPL, MT, R, FMT>(acc, a, smem + st * stage_bytes, cp, xlo, P, plane_bytes, wave, lane);
         ESR_TR();
@@ -660,7 +561,6 @@ __global__ __launch_bounds__(NST == 3 ? 2 * NTHREADS : NTHREADS, NST >= 2 ? 1 : 
     if constexpr (PARTLO)
         for (int cp = lo_end; cp < a.ncp; ++cp) step(std::false_type{}, cp);
     ESR_TR();
-    if (PC && producer) return;
     {
         // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
         // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
@@ -935,13 +835,11 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMODE>;
     ESR_ALLOW_160K_LDS(k);
     const int nslices = a.wslice ? a.nslices : 1;
-    const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)(wreg_of(NPW) ? 0 : 9 * MT * NPW) * 1024;
-    ConvArgs b = a;
-    b.pc_stages = (NST == 3 && 3 * stage + (size_t)MT * 32 * 4 <= 160 * 1024) ? 3 : 2;
-    const size_t lds = (NST == 1 ? 1 : (NST == 3 ? b.pc_stages : (NST == 4 ? 4 : 2))) * stage + (size_t)MT * 32 * 4;
+    const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
+    const size_t lds = (NST == 1 ? 1 : (NST == 4 ? 4 : 2)) * stage + (size_t)MT * 32 * 4;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NST == 3 ? 2 * NTHREADS : NTHREADS), lds, s, b);
+    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -951,15 +849,10 @@ int launch(const ConvArgs& a, hipStream_t s) {
     // no more tiles than CUs (+25 %): every workgroup is alone on its CU, so it pipelines its own DMA (two stages fit: the tile
     // geometry is chosen for two resident single-stage workgroups)
     const int ntiles = a.tiles_x * a.tiles_y * a.B * (a.wslice ? a.nslices : 1) * (a.ksplit > 1 ? a.ksplit : 1);
-    static const int force = getenv("ESR_CONV_STAGES") ? atoi(getenv("ESR_CONV_STAGES")) : 0;     // experiments: 1 or 2
+    const int force = a.stages_hint;                 // esr_conv3x3_desc.lds_stages: 0 = by launch size, 1 / 2 = that form
     const bool small = ntiles <= 320;
-#if ESR_PC
-    if constexpr (!wreg_of(NPW) && TMODE == 0) {
-        if (force == 3) return launch_nst<NPL, MT, EPI, 3, FMT, NPW, PARTLO>(a, s);
-    }
-#endif
     // few small tiles, long K: the four-stage ring where it fits (plain bf16 kernels — what the critic's deep layers launch)
-    if constexpr ((EPI == 0 || EPI == EPI_NCHW) && !PARTLO && FMT == 0 && !wreg_of(NPW) && MT == 2) {
+    if constexpr ((EPI == 0 || EPI == EPI_NCHW) && !PARTLO && FMT == 0 && MT == 2) {
         const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
         if (!force && small && a.ncp >= (EPI == EPI_NCHW ? 8 : 16) && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
     }
@@ -1167,6 +1060,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_cg1 = d->mask_cg1;
     a.mask_slope = d->mask_slope;
     a.reverse = d->reverse_order;
+    a.stages_hint = (d->lds_stages == 1 || d->lds_stages == 2) ? d->lds_stages : 0;
     a.ps = ps;
     a.ps_rg0 = d->ps_rowgroup0;
 #ifdef ESR_TRACE

@@ -32,7 +32,6 @@ extern "C" int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t str
             } break;
             case ESR_OP_WGRAD_BATCH_RUN: rc = esr_conv3x3_wgrad_batch_run(c.u.wgrad_batch_run.workspace, &c.u.wgrad_batch_run.plan, stream); break;
             case ESR_OP_PACK_BATCH_RUN: rc = esr_pack_batch_run(c.u.pack_batch_run.workspace, c.u.pack_batch_run.n, c.u.pack_batch_run.nblocks, stream); break;
-            case ESR_OP_WGRAD_RDB_RUN: rc = esr_wgrad_rdb_run(c.u.wgrad_rdb_run.workspace, &c.u.wgrad_rdb_run.plan, stream); break;
             case ESR_OP_ZERO: rc = esr_zero(c.u.zero.p, c.u.zero.n16, stream); break;
             case ESR_OP_UNPACK_NCHW: rc = esr_unpack_nchw(&c.u.unpack_nchw.src, c.u.unpack_nchw.B, c.u.unpack_nchw.nc, c.u.unpack_nchw.dst, stream); break;
             case ESR_OP_WGRAD: rc = esr_conv3x3_wgrad(&c.u.wgrad, stream); break;

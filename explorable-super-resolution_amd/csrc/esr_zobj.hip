@@ -146,7 +146,7 @@ __global__ __launch_bounds__(IS_THREADS) void img_stats_kernel(const float* __re
 //   kind 1: c0 * (sgn(v - v[x+1]) - sgn(v[x-1] - v)) + c1 * (sgn(v - v[y+1]) - sgn(v[y-1] - v))       (c0 = g / Nx, c1 = g / Ny)
 //   kind 2: with a(ix, iy) = c0 ix + c2 iy  (d/d ix),  b(ix, iy) = c1 iy + c2 ix  (d/d iy)  on the (H-1) x (W-1) frame:
 //           -a(y, x) - b(y, x) + a(y, x-1) + b(y-1, x)       (c0 = 2 g0 / N, c1 = 2 g1 / N, c2 = g2 / N)
-// dv/dx = mask * [0 < x < 1] (clamp) as asked.
+// dv/dx = mask * [0 <= x <= 1] (torch.clamp's inclusive gradient) as asked.
 template <int KIND>
 __global__ __launch_bounds__(IS_THREADS) void img_stats_grad_kernel(const float* __restrict__ x, int C, int H, int W, const float* __restrict__ mask, int clamp01,
                                                                     const float* __restrict__ coef, float* __restrict__ dx, int accumulate) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(IS_THREADS) void img_stats_grad_kernel(const float*
         if (yy > 0 && xx + 1 < W) g += Bf(yy - 1, xx);
     }
     const float raw = img[((long long)c * H + yy) * W + xx];
-    if (clamp01 && !(raw > 0.f && raw < 1.f)) g = 0.f;            // torch.clamp's gradient: 1 inside, 0 outside and AT the bounds
+    if (clamp01 && !(raw >= 0.f && raw <= 1.f)) g = 0.f;          // torch.clamp's gradient: 1 inside and AT the bounds ((x >= min) & (x <= max)), 0 outside (NaN: 0)
     if (mask) g *= mask[(long long)yy * W + xx];
     float* o = dx + (long long)b * n + i;
     *o = accumulate ? *o + g : g;

@@ -26,7 +26,7 @@ class Conv3x3Desc(C.Structure):
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
                 ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32),
                 ('pixel_shuffle', C.c_int32), ('ps_rowgroup0', C.c_int32), ('tap_mask_k', C.c_int32 * 4), ('tap_mask_k_shift', C.c_int32),
-                ('tap_mask_m', C.c_int32 * 4), ('k_split_ws', C.c_void_p), ('k_split_ws_floats', C.c_int64)]
+                ('tap_mask_m', C.c_int32 * 4), ('k_split_ws', C.c_void_p), ('k_split_ws_floats', C.c_int64), ('lds_stages', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -47,16 +47,6 @@ class PackDesc(C.Structure):
                 ('mtiles', C.c_int32), ('transposed', C.c_int32), ('split', C.c_int32), ('scale', C.c_float), ('wpack', C.c_void_p)]
 
 
-class WgradRdbDesc(C.Structure):
-    """esr_wgrad_rdb_desc (include/esr_hip.h)."""
-    _fields_ = [('x', ActView), ('g', ActView), ('z', ActView), ('lat', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('dw', C.c_void_p * 5), ('db', C.c_void_p * 5), ('alpha', C.c_float * 5)]
-
-
-class WgradRdbPlan(C.Structure):
-    _fields_ = [('nwg', C.c_int64), ('n', C.c_int32), ('nslices', C.c_int32), ('split', C.c_int32), ('f16', C.c_int32), ('reserved', C.c_int32)]
-
-
 class BnDesc(C.Structure):
     """esr_bn_desc (include/esr_hip.h)."""
     _fields_ = [('y', ActView), ('dz', ActView), ('u', ActView), ('out0', ActView), ('out1', ActView), ('B', C.c_int32), ('groups', C.c_int32),
@@ -71,7 +61,7 @@ class AdamTensor(C.Structure):
 
 # ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
 OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
-    OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS, OP_WGRAD_RDB_RUN = range(1, 18)
+    OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS = range(1, 17)
 
 
 class CmdPackNchw(C.Structure):
@@ -133,15 +123,11 @@ class CmdBnParamGrads(C.Structure):
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('g_gamma', C.c_void_p)]
 
 
-class CmdWgradRdbRun(C.Structure):
-    _fields_ = [('workspace', C.c_void_p), ('plan', WgradRdbPlan)]
-
-
 class CmdUnion(C.Union):
     _fields_ = [('conv', Conv3x3Desc), ('pack_nchw', CmdPackNchw), ('unpack_grad_nchw', CmdUnpackGradNchw), ('act_combine', CmdActCombine),
                 ('pixel_unshuffle', CmdPixelUnshuffle), ('grad_absmax', CmdGradAbsmax), ('grad_scale', CmdGradScale),
                 ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero), ('unpack_nchw', CmdUnpackNchw),
-                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads), ('wgrad_rdb_run', CmdWgradRdbRun)]
+                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads)]
 
 
 class Cmd(C.Structure):
@@ -152,7 +138,7 @@ class Cmd(C.Structure):
 CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW: 'unpack_grad_nchw', OP_ACT_COMBINE: 'act_combine',
               OP_PIXEL_UNSHUFFLE: 'pixel_unshuffle', OP_GRAD_ABSMAX: 'grad_absmax', OP_GRAD_SCALE: 'grad_scale',
               OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero', OP_UNPACK_NCHW: 'unpack_nchw',
-              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads', OP_WGRAD_RDB_RUN: 'wgrad_rdb_run'}
+              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads'}
 
 
 _SIGS = {
@@ -194,10 +180,6 @@ _SIGS = {
     'esr_conv3x3_wgrad_batch_upload': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.POINTER(WgradBatchPlan), C.c_void_p]),
     'esr_conv3x3_wgrad_batch_run': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_void_p]),
     'esr_conv3x3_wgrad_batch_rebase': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_int64, C.c_void_p]),
-    'esr_wgrad_rdb_workspace_bytes': (C.c_int64, [C.c_int]),
-    'esr_wgrad_rdb_upload': (C.c_int, [C.POINTER(WgradRdbDesc), C.c_int, C.c_void_p, C.c_int64, C.POINTER(WgradRdbPlan), C.c_void_p]),
-    'esr_wgrad_rdb_run': (C.c_int, [C.c_void_p, C.POINTER(WgradRdbPlan), C.c_void_p]),
-    'esr_wgrad_rdb_rebase': (C.c_int, [C.c_void_p, C.POINTER(WgradRdbPlan), C.c_int64, C.c_void_p]),
     'esr_soft_hist_slabs': (C.c_int64, [C.c_int64]),
     'esr_soft_hist_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'esr_soft_hist_bwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

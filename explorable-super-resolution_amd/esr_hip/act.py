@@ -2,7 +2,6 @@
 and packed conv weights.  PyTorch is only the allocator / stream provider here."""
 import ctypes as C
 import functools
-import os
 import threading
 
 import torch
@@ -455,7 +454,7 @@ class PackedSum:
 
 
 _launch_parity = 0
-ALTERNATE_ORDER = os.environ.get('ESR_ALTERNATE_ORDER', '1') != '0'
+ALTERNATE_ORDER = True        # module attribute (experiments may clear it): consecutive launches walk the tile space in opposite directions
 
 
 def reset_launch_parity():

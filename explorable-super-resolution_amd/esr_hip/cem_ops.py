@@ -1,7 +1,6 @@
 """Host wrappers of the CEM kernels (csrc/esr_cem.hip).  fp32 NCHW in/out.  Differentiable: every op is linear with
 fixed taps, so its backward is the adjoint filter (esr_hip/autograd.py)."""
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -17,7 +16,7 @@ def _prep(x, what):
     return x.contiguous()
 
 
-USE_SEPARABLE = os.environ.get('ESR_CEM_SEPARABLE', '1') != '0'
+USE_SEPARABLE = True          # module attribute: the tests compare the separable kernels with the 2-D ones by clearing it
 
 
 def _taps_entry(t, dev):

@@ -15,7 +15,6 @@ Each op is a torch.autograd.Function whose backward is built from the other Func
 through the backward pass with the same kernels: conv <-> data-gradient are each other's adjoint, the weight gradient is bilinear.
 The two Linear layers of the classifier stay on torch (rocBLAS): 51 MFLOP of the critic's 2.2 GFLOP per image."""
 import ctypes as C
-import os
 import weakref
 
 import torch
@@ -72,9 +71,7 @@ def _tap_masks():
     return fwd, flipped
 
 
-MASK_FWD, MASK_FLIPPED = _tap_masks()
-if os.environ.get('ESR_CRITIC_MASKS') == '0':          # experiments: multiply the structural zeros too (same results)
-    MASK_FWD = MASK_FLIPPED = None
+MASK_FWD, MASK_FLIPPED = _tap_masks()       # (module attributes; None: multiply the structural zeros too — same results)
 
 
 def view_of(t, cg0=0, ncg=None, b0=0):
@@ -126,10 +123,10 @@ def conv_io(t_in, t_out, B, h, w, b0=0):
     return view_of(t_in, b0=b0), view_of(t_out, b0=b0), B, h, w
 
 
-STACK_MAX = int(os.environ.get('ESR_CRITIC_STACK', '8'))       # feature maps up to this height are stacked (0: never)
+STACK_MAX = 8       # feature maps up to this height are stacked (0: never)
 # fused passes lend every conv launch an fp32 workspace: the library splits the K axis of the deep layers' launches (24-100 workgroups walking
 # 32-128 chunks each) over 2-8 workgroup sets (esr_conv3x3_desc.k_split_ws); 0: never
-SPLITK = os.environ.get('ESR_CRITIC_SPLITK', '1') != '0'
+SPLITK = True
 SPLITK_MAX_FLOATS = 16 << 20
 
 
@@ -177,6 +174,18 @@ class CriticEngine:
         self._wgb = {}
         self._free_sets = {}
         self.set_precision(precision)
+
+    def unsupported_input(self, H, W):
+        """None when the kernels run an H x W input, otherwise the reason (what _BufSet would raise): the stride-2 convs are 3x3 convs over the
+        space-to-depth map of their input, which needs even sizes.  (The reference's module floors instead — and then fails in its Linear
+        classifier unless the input is 128 x 128, codes/models/modules/architecture.py:446-508.)"""
+        h, w = int(H), int(W)
+        for L in self.layers:
+            if L.strided:
+                if h % 2 or w % 2:
+                    return 'critic: odd feature-map size %dx%d in front of a stride-2 conv (input %dx%d)' % (h, w, H, W)
+                h, w = h // 2, w // 2
+        return None
 
     # ------------------------------------------------------------------ weights
     def set_precision(self, precision):
@@ -1007,19 +1016,19 @@ class _CriticBwd(torch.autograd.Function):
         return (None,) * (nf - 2) + (g_dfeat if ctx.had_dfeat else None, None) + (None,) * n + tuple(g_ys) + tuple(pg)
 
 
-FUSED = os.environ.get('ESR_CRITIC_FUSED', '1') != '0'
+FUSED = True        # False: one autograd node and several FFI calls per layer (the readable definition; cross-checked by the tests)
 _critic_forward_per_layer = critic_forward
 
 
 def critic_forward(eng, x):
     """Logits [B, 1] of the critic for fp32 NCHW images `x`, differentiable to the order the WGAN-GP step needs.  Three launch lists per
-    forward / backward / double backward (ESR_CRITIC_FUSED=0: one autograd node and several FFI calls per layer — the same kernels)."""
+    forward / backward / double backward (FUSED = False: one autograd node and several FFI calls per layer — the same kernels)."""
     if not FUSED:
         return _critic_forward_per_layer(eng, x)
     return critic_forward_group(eng, [x])[0]
 
 
-GROUPED = os.environ.get('ESR_CRITIC_GROUPED', '1') != '0'
+GROUPED = True      # False: a grouped call runs its batches one by one
 
 
 def critic_forward_group(eng, xs):

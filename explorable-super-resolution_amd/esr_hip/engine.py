@@ -14,7 +14,6 @@ Inference rotates three RDB buffers; a forward that must be differentiated keeps
 activations) and the backward re-uses the same conv kernel with transposed/flipped weight packs (data gradient), a
 pixel-contraction MFMA kernel (weight gradient) and the gradient buffers laid out exactly like the activations.
 """
-import os
 import weakref
 
 import torch
@@ -34,8 +33,6 @@ class RRDBEngine:
     def __init__(self, net):
         self.net = net
         self.split = True
-        if os.environ.get('ESR_DEFAULT_PRECISION'):        # experiments / whole-suite checks of a non-default mode
-            self.split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[os.environ['ESR_DEFAULT_PRECISION']]
         self._convs_cache = None
         self._params_cache, self._params_probe = None, None
         self._packed = None
@@ -49,13 +46,19 @@ class RRDBEngine:
         self._pack_gen = [0, 0, 0]   # the value of _pack_sets when the forward / data-gradient / dense-block data-gradient dict was made
         self._wgb = {}       # this engine's uploaded weight-gradient descriptor tables (A.conv3x3_wgrad_batch)
         # launch lists (esr_run): a pass over a cached buffer set is recorded once and replayed with one C call per segment afterwards;
-        # ESR_PLANS=0 issues every launch from Python instead (the recording path itself, used by the tests as the reference)
-        self.use_plans = os.environ.get('ESR_PLANS', '1') != '0'
+        # use_plans = False issues every launch from Python instead (the recording path itself, used by the tests as the reference)
+        self.use_plans = True
         # what a differentiable forward keeps for its backward when NO parameter wants a gradient (the Z search: frozen generator): 'masks' —
         # three rotating dense-block buffers as in inference plus, per RDB, a ONE-plane copy of its four intermediate activations, of which the
         # data gradient reads nothing but the signs (LeakyReLU'); 'full' — every RDB's whole 24-group hi+lo buffer, as training needs (the
         # weight gradient contracts the activations themselves).  Same gradients bit for bit; 1/3 of the memory per RDB.
-        self.stash = os.environ.get('ESR_STASH', 'masks')
+        self.stash = 'masks'
+        # 'mixed' only: format of its backward pass, 'f16' (as the forward) or 'bf16' (hi+lo gradients, 3 MFMAs per product); see _bwd_split
+        self.mixed_bwd = 'f16'
+        # 'mixed' only: which dense-block convs multiply the residual stream's lo plane as well: 'none' (default), 'conv4' or 'all' 
+        self.mixed_xlo = 'none'
+        # 'mixed' backward: renormalise the fp16 gradient of every RRDB's input (False: one scale for the whole pass)
+        self.grad_renorm = True
         self._ptr_fp, self._ptr_epoch = None, 0   # parameter storages the recorded descriptors point into; epoch moves when any changes
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
@@ -143,10 +146,10 @@ class RRDBEngine:
     def _bwd_split(self):
         """Buffer format of the backward pass.  'mixed' back-propagates (to the input only) the way it runs forward: fp16 planes, the
         gradient of the residual stream stored hi+lo, one-plane operands inside the dense blocks, with the incoming gradient scaled by a
-        power of two into fp16's range (run_backward).  ESR_MIXED_BWD=bf16 selects the earlier variant: bf16 hi+lo gradients (3 MFMAs
+        power of two into fp16's range (run_backward).  mixed_bwd = 'bf16' selects the earlier variant: bf16 hi+lo gradients (3 MFMAs
         per product), the saved fp16 activations serving as LeakyReLU' masks only."""
         if self.split == 'mixed':
-            return True if os.environ.get('ESR_MIXED_BWD', 'f16') == 'bf16' else 'mixed'
+            return True if self.mixed_bwd == 'bf16' else 'mixed'
         return self.split
 
     def _bwd_wfmt(self, rdb):
@@ -384,7 +387,7 @@ class RRDBEngine:
         # the RDB input (groups 0:8, the residual stream) keeps hi+lo.  Their lo planes are never written (they stay zero).
         mixed = self.split == 'mixed'
         lo8 = dict(in1_lo_groups=8) if mixed else {}
-        xlo_mode = os.environ.get('ESR_MIXED_XLO', 'none')
+        xlo_mode = self.mixed_xlo
         lo_in = lo8 if xlo_mode == 'all' else dict(in1_lo_groups=-1)
         lo_c4 = lo8 if xlo_mode in ('all', 'conv4') else dict(in1_lo_groups=-1)
         if not mixed:
@@ -427,7 +430,7 @@ class RRDBEngine:
     def run_backward(self, x_shape, pad, bufs, dg, need_dx=True, need_dw=False):
         """Gradients of sum(g * dg): returns (dx or None, {param: grad} or None).  `bufs` = run_forward(..., keep=True)[1]."""
         if self.split == 'mixed' and need_dw and self._bwd_split != 'mixed':
-            raise NotImplementedError("precision 'mixed' with ESR_MIXED_BWD=bf16 back-propagates to the INPUT only (Z optimisation): its saved "
+            raise NotImplementedError("precision 'mixed' with mixed_bwd = 'bf16' back-propagates to the INPUT only (Z optimisation): its saved "
                                       "activations are fp16, the gradients bf16 — the weight-gradient kernel contracts one element format")
         if self.split in ('f16', 'f16x2'):
             raise NotImplementedError("the fp16 precisions are inference modes: fp16 gradients underflow without loss scaling; "
@@ -622,17 +625,14 @@ class RRDBEngine:
                 G = G_cur
                 name = 'rrdb%d.rdb%d' % (r, k)
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
-                per_layer = need_dw and not wg.use_rdb
-                if per_layer:
+                if need_dw:
                     wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
                 for c in (3, 2, 1, 0):
                     g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
                     conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
                          mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
-                    if per_layer:
+                    if need_dw:
                         wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
-                if need_dw and not per_layer:         # G' is complete: the block's five weight gradients as one work item list
-                    wg.rdb(name, G.view(0, 24), X.view(0, 24), zview('zlr') if lat else None, h, w, s_out, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
                     conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
@@ -644,7 +644,7 @@ class RRDBEngine:
                 kw = dict(res2=G_rrdb.view(0, 8), beta2=1.0) if k == 0 else {}
                 conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw, **hi_only)
                 G_cur = G_next
-            if f16_bwd and os.environ.get('ESR_GRAD_RENORM', '1') != '0':
+            if f16_bwd and self.grad_renorm:
                 # d(input of RRDB r) is complete and not yet recorded anywhere: renormalise it (and the latent gradient accumulated so far)
                 scaler.rescale(B, [G_cur.view(0, 8)] + ([GZ_lr.view()] if zgrad and not zfirst else []), 10)
                 gscale = scaler.current
@@ -708,10 +708,6 @@ class WGrad:
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
         self.descs, self.keep, self.permuted = [], [], []
-        # ESR_WGRAD_RDB=1: dense blocks through the block-level launch (esr_wgrad_rdb_*: one input tile against all the output tiles that
-        # pair with it).  Correct (same tests) and a third of the on-chip operand traffic, but measured 9-18 % SLOWER than the per-pair
-        # batched launch at the configs[2] shape (7.3 + 0.6 vs 6.7 ms in bf16) — off by default.
-        self.rdb_descs, self.use_rdb = [], os.environ.get('ESR_WGRAD_RDB', '0') == '1'
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0
@@ -721,33 +717,6 @@ class WGrad:
             self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(self.mods.values())).weight.device)
             self._sizes = [k for c in self.mods.values() for k in (c.weight.numel(), c.weight.shape[0])]
             self._params = [(c.weight, c.bias) for c in self.mods.values()]
-
-    def rdb(self, name, G, X, x_lat, H, W, s_out, keep=()):
-        """All five convs of dense block `name` ('rrdbR.rdbK'): X its 24-group activation buffer view, G its 24-group gradient buffer view
-        [dy conv4 | dy conv3 | dy conv2 | dy conv1 | dy conv0] (complete when this is called), s_out the scale of its output in the RRDB sum."""
-        if not self.enabled:
-            return
-        if self.hi_only:
-            G, X, x_lat = A.hi_plane(G), A.hi_plane(X), A.hi_plane(x_lat)
-        d = _lib.WgradRdbDesc()
-        d.x, d.g = X, G
-        lat = self.lats[name + '.conv0'] if x_lat is not None else 0
-        d.z = x_lat if x_lat is not None else A.NO_VIEW
-        d.lat, d.B, d.H, d.W = lat, self.B, H, W
-        for i in range(5):
-            lname = '%s.conv%d' % (name, i)
-            c = self.mods[lname]
-            o, nw, co = self.offsets[lname], c.weight.numel(), c.weight.shape[0]
-            assert c.weight.shape[1] == lat + 64 + 32 * i and co == (64 if i == 4 else 32)
-            dw, db = self.flat[o:o + nw].view(c.weight.shape), self.flat[o + nw:o + nw + co]
-            d.dw[i], d.db[i], d.alpha[i] = dw.data_ptr(), db.data_ptr(), (0.2 * s_out if i == 4 else 1.0)
-            if self.gscale is not None:
-                self.scaled.append((o, nw + co, self.gscale))
-            self.grads[c.weight] = dw
-            if c.bias is not None:
-                self.grads[c.bias] = db
-        self.rdb_descs.append(d)
-        self.keep.extend(keep)
 
     def conv(self, name, dy, x_main, x_lat, H, W, alpha=1.0, upsample=1, keep=(), rows=None):
         """rows: dy's channels are a permutation of the layer's output channels (pixel-shuffle convs): dy channel i is output channel rows[i]."""
@@ -775,24 +744,14 @@ class WGrad:
         else:
             self.keep.append(db)
 
-    def _rdb_upload(self, dev):
-        """Upload the dense blocks' descriptor table: (workspace tensor, plan)."""
-        arr = (_lib.WgradRdbDesc * len(self.rdb_descs))(*self.rdb_descs)
-        need = _lib.lib.esr_wgrad_rdb_workspace_bytes(len(arr))
-        _lib.check(min(need, 0), 'esr_wgrad_rdb_workspace_bytes')
-        ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
-        plan = _lib.WgradRdbPlan()
-        _lib.check(_lib.lib.esr_wgrad_rdb_upload(arr, len(arr), ws.data_ptr(), ws.numel(), C.byref(plan), A.stream_ptr()), 'esr_wgrad_rdb_upload')
-        return ws, plan
-
     def result(self):
-        if self.enabled and (self.descs or self.rdb_descs):
+        if self.enabled and self.descs:
             rec = A._rec()
             dev = self.flat.device
             if rec is not None:
                 # recorded pass: the descriptor tables go to the device now, their launches into the list; rebind() serves the replays
                 self._flat_ptr = self.flat.data_ptr()
-                self._ws = self._plan = self._rdb_ws = self._rdb_plan = None
+                self._ws = self._plan = None
                 if self.descs:
                     self._arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
                     need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self._arr, len(self.descs))
@@ -801,21 +760,13 @@ class WGrad:
                     self._upload()
                     rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(self._ws.data_ptr(), self._plan))
                     rec.keep.append(self._ws)
-                if self.rdb_descs:
-                    self._rdb_ws, self._rdb_plan = self._rdb_upload(dev)
-                    rec.emit(_lib.OP_WGRAD_RDB_RUN, _lib.CmdWgradRdbRun(self._rdb_ws.data_ptr(), self._rdb_plan))
-                    rec.keep.append(self._rdb_ws)
                 rec.keep.extend(self.keep)
                 assert not self.permuted and not self.scaled
                 self._n, self._dev = self.flat.numel(), dev
-                grads, self.descs, self.rdb_descs, self.keep, self.flat, self.grads = self.grads, [], [], [], None, None      # hold no reference to a step's gradients
+                grads, self.descs, self.keep, self.flat, self.grads = self.grads, [], [], None, None      # hold no reference to a step's gradients
                 return grads
             if self.descs:
                 A.conv3x3_wgrad_batch(self.descs, dev, cache=self.engine._wgb)
-            if self.rdb_descs:
-                ws, plan = self._rdb_upload(dev)
-                _lib.check(_lib.lib.esr_wgrad_rdb_run(ws.data_ptr(), C.byref(plan), A.stream_ptr()), 'esr_wgrad_rdb_run')
-                self.keep.append(ws)
             for (tdw, tdb), (dw, db), rows in self.permuted:
                 dw.index_copy_(0, rows, tdw)
                 db.index_copy_(0, rows, tdb)
@@ -828,7 +779,7 @@ class WGrad:
                     runs.append([o, n, g])
             for o, n, g in runs:
                 self.flat[o:o + n].div_(g)
-            self.descs, self.rdb_descs, self.keep = [], [], []
+            self.descs, self.keep = [], []
         return self.grads
 
     def _upload(self):
@@ -846,8 +797,6 @@ class WGrad:
         if delta:             # the tables' dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
             if self._ws is not None:
                 _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self._ws.data_ptr(), C.byref(self._plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
-            if self._rdb_ws is not None:
-                _lib.check(_lib.lib.esr_wgrad_rdb_rebase(self._rdb_ws.data_ptr(), C.byref(self._rdb_plan), delta, A.stream_ptr()), 'esr_wgrad_rdb_rebase')
             self._flat_ptr += delta
         parts = flat.split(self._sizes)
         grads = {}

@@ -44,13 +44,14 @@ class Adam(torch.optim.Optimizer):
             # every tensor that has a gradient steps together (a parameter that sat out earlier steps would need its own bias
             # corrections): the group's tensors SHARE one 'step' tensor object, re-established after load_state_dict's deep copies
             first = self.state[ps[0]]['step']
-            if self.state[ps[-1]]['step'] is not first:
+            if any(self.state[p]['step'] is not first for p in ps):        # (identity checks of ~700 objects: microseconds)
                 if any(float(self.state[p]['step']) != float(first) for p in ps):
                     raise _lib.EsrError('parameters of one group have stepped a different number of times: put them into separate groups')
                 for p in ps:
                     self.state[p]['step'] = first
             t = float(first) + 1
-            fp = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(ps, grads))
+            # everything the uploaded table points at: parameters, gradients AND both moment tensors (load_state_dict replaces the latter)
+            fp = tuple((p.data_ptr(), g.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p, g in zip(ps, grads))
             tab = self._tables.get(gi)
             if tab is None or tab[0] != fp:
                 arr = (_lib.AdamTensor * len(ps))()
@@ -70,3 +71,12 @@ class Adam(torch.optim.Optimizer):
             # the kernel wrote the parameters behind torch's back: tell the version counters (weight packs, autograd's saved-tensor checks)
             torch.autograd.graph.increment_version(ps)
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}           # the loaded moment tensors are new storages
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, '_tables'):
+            self._tables = {}

@@ -68,7 +68,7 @@ class SRRaGANModel(BaseModel):
         self.generator_changed = True
         self.generator_started_learning = False
         self.optimalZ_loss_type = None
-        self.D_engine = None
+        self.D_engine, self.D_engine_mode, self.D_engine_fallback = None, None, None
         self.timing = None               # set to {} to accumulate per-phase GPU milliseconds of optimize_parameters (bench.py --workload c3)
         if self.is_train:
             if train_opt['feature_weight'] is not None:
@@ -105,27 +105,27 @@ class SRRaGANModel(BaseModel):
                 self.netD.train()
                 # network_D.precision = 'bf16': the critic's convolutions run under bf16 autocast (fp32 parameters, fp32 losses; configs[2] of
                 # BASELINE.json names bf16); default: fp32 like the reference.  network_D.channels_last: NHWC activations for MIOpen.
-                self.D_dtype = torch.bfloat16 if (net_D.get('precision') or os.environ.get('ESR_D_PRECISION')) == 'bf16' else None
-                if net_D.get('channels_last') or os.environ.get('ESR_D_CHANNELS_LAST') == '1':
+                self.D_dtype = torch.bfloat16 if net_D.get('precision') == 'bf16' else None
+                if net_D.get('channels_last'):
                     self.netD = self.netD.to(memory_format=torch.channels_last)
-                # network_D.engine: 'hip' (default where the kernels cover the architecture: conv 3x3 s1 / 4x4 s2 + BatchNorm + LeakyReLU
-                # blocks, Linear classifier) runs the critic, its backward and the penalty's double backward on the library's kernels;
-                # 'stock' keeps the nn.Module on MIOpen.  Asking for 'hip' on an architecture outside that set raises.
-                want = net_D.get('engine') or os.environ.get('ESR_D_ENGINE') or 'auto'
+                # network_D.engine: 'hip' runs the critic, its backward and the penalty's double backward on the library's kernels (conv 3x3 s1 /
+                # 4x4 s2 + BatchNorm + LeakyReLU blocks, Linear classifier: Discriminator_VGG_128); 'stock' keeps the nn.Module on MIOpen; 'auto'
+                # (default) = 'hip' where the kernels cover the architecture and the input size, otherwise 'stock' — and it SAYS so: the reason is
+                # printed, logged and kept in self.D_engine_fallback (None while the library's kernels are the ones running).  'hip' raises instead.
+                want = net_D.get('engine') or 'auto'
                 if want not in ('auto', 'hip', 'stock'):
                     raise NotImplementedError("network_D.engine = %r: 'hip', 'stock' or 'auto'" % (want,))
+                self.D_engine_mode, self.D_engine_fallback = want, ('network_D.engine = stock' if want == 'stock' else None)
                 if want != 'stock' and self.device.type == 'cuda':
                     try:
                         self.D_engine = CriticEngine(self.netD)
-                    except EsrError:
+                    except EsrError as e:                # (the constructor checks the architecture only)
                         if want == 'hip':
                             raise
-                # network_D.miopen_find: let MIOpen time its kernels once and keep the fastest (configs[2] shapes, bf16 critic: 30.7 -> 20.0 ms per
-                # D step; costs tens of seconds of search the first time a shape is seen, so it is opt-in)
-                find = bool(net_D.get('miopen_find'))
-                if os.environ.get('ESR_D_MIOPEN_FIND') in ('0', '1'):          # override (tests keep start-up short)
-                    find = os.environ['ESR_D_MIOPEN_FIND'] == '1'
-                if find:
+                        self._D_fall_back(str(e))
+                # network_D.miopen_find (stock critic only): let MIOpen time its kernels once and keep the fastest (configs[2] shapes, bf16 critic:
+                # 30.7 -> 20.0 ms per D step; costs tens of seconds of search the first time a shape is seen, so it is opt-in)
+                if net_D.get('miopen_find'):
                     torch.backends.cudnn.benchmark = True
             self.cri_pix = None
             if train_opt['pixel_weight'] is not None:
@@ -177,7 +177,9 @@ class SRRaGANModel(BaseModel):
             self.grad_reducer = esr_dist.GradBucketAllReducer(optim_params)
             if self.D_exists:
                 wd_D = train_opt['weight_decay_D'] if train_opt['weight_decay_D'] else 0
-                self.optimizer_D = Adam(self.netD.parameters(), lr=self.lr_D, weight_decay=wd_D,
+                # (the one-launch Adam steps contiguous fp32 tensors: a channels_last critic keeps torch's)
+                plain = all(p.is_contiguous() and p.dtype == torch.float32 for p in self.netD.parameters())
+                self.optimizer_D = (Adam if plain else torch.optim.Adam)(self.netD.parameters(), lr=self.lr_D, weight_decay=wd_D,
                                         betas=(train_opt['beta1_D'] or 0.9, train_opt['beta2_D'] if train_opt['beta2_D'] is not None else 0.999), **fused)
                 self.optimizers.append(self.optimizer_D)
                 self.grad_reducer_D = esr_dist.GradBucketAllReducer(list(self.netD.parameters()))
@@ -215,6 +217,7 @@ class SRRaGANModel(BaseModel):
             import gc
             gc.collect()
             gc.freeze()
+            self._gc_frozen = True          # close() undoes it
         print('---------- Model initialized ------------------')
 
     # ------------------------------------------------------------------ input packing (reference :224-278)
@@ -287,13 +290,42 @@ class SRRaGANModel(BaseModel):
         replay the reference's draws."""
         return torch.rand(batch_size, 1, 1, 1, device=self.device)
 
+    def close(self):
+        """Undo the process-wide side effect of construction (gc.freeze(), see __init__): a process that builds a second model — validation,
+        the GUI — calls this when it drops a trained one, so that its objects become collectable again."""
+        if getattr(self, '_gc_frozen', False):
+            import gc
+            gc.unfreeze()
+            self._gc_frozen = False
+
+    def _D_fall_back(self, reason):
+        """network_D.engine = 'auto' leaving the library's kernels for the stock nn.Module: never silently."""
+        import logging
+        self.D_engine, self.D_engine_fallback = None, reason
+        msg = "network_D.engine = 'auto': the critic runs as the stock nn.Module on MIOpen, NOT on libesr_hip (%s)" % reason
+        logging.getLogger('base').warning(msg)
+        print('WARNING: ' + msg)
+
+    def _D_engine_for(self, x):
+        """The critic engine if it runs inputs of x's size (CriticEngine.unsupported_input), else the documented fallback / error."""
+        if self.D_engine is None:
+            return None
+        reason = self.D_engine.unsupported_input(x.shape[-2], x.shape[-1])
+        if reason is not None:
+            if self.D_engine_mode == 'hip':
+                raise EsrError("network_D.engine = 'hip': " + reason)
+            self._D_fall_back(reason)
+            return None
+        self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
+        return self.D_engine
+
     def _D(self, x):
         """The critic's logits in fp32: on the library's kernels (esr_hip/critic.py; 'bf16' operands when network_D.precision = 'bf16', the
         fp32-class 'split' otherwise), or — network_D.engine = 'stock', or an architecture the kernels do not cover — the nn.Module on
         MIOpen (under bf16 autocast for 'bf16')."""
-        if self.D_engine is not None:
-            self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
-            return critic_forward(self.D_engine, x)
+        eng = self._D_engine_for(x)
+        if eng is not None:
+            return critic_forward(eng, x)
         if self.D_dtype is None:
             return self.netD(x)
         with torch.autocast(device_type='cuda', dtype=self.D_dtype):
@@ -302,9 +334,9 @@ class SRRaGANModel(BaseModel):
     def _D_group(self, xs):
         """[self._D(x) for x in xs] — on the library's kernels as ONE pass over the concatenated batches (same values: every batch keeps its own
         BatchNorm statistics, the running statistics see them in this order; esr_hip.critic.critic_forward_group)."""
-        if self.D_engine is not None:
-            self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
-            return critic_forward_group(self.D_engine, xs)
+        eng = self._D_engine_for(xs[0])
+        if eng is not None:
+            return critic_forward_group(eng, xs)
         return [self._D(x) for x in xs]
 
     def _tick(self, name):

@@ -1,10 +1,10 @@
 """Building blocks of the RRDB generator — same names, signatures, module tree and state_dict keys as the reference's
 codes/models/modules/block.py, re-implemented over the gfx950 kernels of libesr_hip.so.
 
-The classes here are parameter containers with the reference's structure; a stand-alone call of a block
-(`RRDB(...)(x)`) runs layer by layer through `HipConv2d` (one HIP conv launch per layer, layout conversion at both
-ends).  The fast path is `architecture.RRDBNet.forward`, which plans the whole generator with zero-copy dense-block
-buffers and fused epilogues (esr_hip/engine.py).
+The block classes here are parameter containers with the reference's structure: what executes them is
+`architecture.RRDBNet.forward`, which plans the whole generator with zero-copy dense-block buffers and fused epilogues
+(esr_hip/engine.py).  A block called on its own raises `EsrError` — there is no second, torch-op implementation of the
+path to fall into; a single layer can be run through `HipConv2d` (one HIP conv launch, layout conversion at both ends).
 """
 from collections import OrderedDict
 
@@ -12,6 +12,12 @@ import torch
 import torch.nn as nn
 
 from esr_hip import act as _act
+from esr_hip._lib import EsrError
+
+
+def _engine_only(self, *args, **kwargs):
+    raise EsrError('%s is executed by RRDBNet.forward (esr_hip.engine.RRDBEngine) on the HIP kernels; it has no stand-alone forward'
+                   % type(self).__name__)
 
 
 class HipConv2d(nn.Conv2d):
@@ -95,18 +101,7 @@ class ShortcutBlock(nn.Module):
         self.sub = submodule
         self.num_latent_channels = latent_input_channels
 
-    def forward(self, x):
-        if isinstance(self.sub, nn.ModuleList):
-            if self.num_latent_channels > 0:
-                latent_input = x[:, :self.num_latent_channels, ...]
-            output = x
-            for i, module in enumerate(self.sub):
-                if i > 0 and self.num_latent_channels > 0:
-                    output = torch.cat([latent_input, output], 1)
-                output = module(output)
-        else:
-            output = self.sub(x)
-        return x[:, self.num_latent_channels:, ...] + output
+    forward = _engine_only
 
     def __repr__(self):
         return 'Identity + \n|' + self.sub.__repr__().replace('\n', '\n|')
@@ -125,11 +120,7 @@ class ResidualDenseBlock_5C(nn.Module):
                        pad_type=pad_type, norm_type=norm_type, act_type=act_type if i < 4 else last_act, mode=mode)
             for i in range(5)])
 
-    def forward(self, x):
-        outputs = [x]
-        for layer in self.convs:
-            outputs.append(layer(torch.cat(outputs, 1)))
-        return outputs[-1].mul(0.2) + outputs[0][:, -outputs[-1].size()[1]:, ...]
+    forward = _engine_only
 
 
 class RRDB(nn.Module):
@@ -143,16 +134,7 @@ class RRDB(nn.Module):
         self.RDB2 = ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias, pad_type, norm_type, act_type, mode, latent_input_channels)
         self.RDB3 = ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias, pad_type, norm_type, act_type, mode, latent_input_channels)
 
-    def forward(self, x):
-        z = x[:, :self.num_latent_channels, ...]
-        out = self.RDB1(x)
-        if self.num_latent_channels > 0:
-            out = torch.cat([z, out], 1)
-        out = self.RDB2(out)
-        if self.num_latent_channels > 0:
-            out = torch.cat([z, out], 1)
-        out = self.RDB3(out)
-        return out.mul(0.2) + x[:, -out.size()[1]:, ...]
+    forward = _engine_only
 
 
 def pixelshuffle_block(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True, pad_type='zero', norm_type=None,
@@ -170,8 +152,7 @@ class Upsampler(nn.Module):
         self.upscale_factor = upscale_factor
         self.mode = mode
 
-    def forward(self, input):
-        return nn.functional.interpolate(input, scale_factor=self.upscale_factor, mode=self.mode)
+    forward = _engine_only          # (nearest x2 / x3 is fused into the following conv's input fetch: esr_conv3x3_desc.upsample)
 
 
 def upconv_blcok(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True, pad_type='zero', norm_type=None,

@@ -134,6 +134,9 @@ typedef struct {
      * bf16 formats, cout a multiple of 64).  The result differs from the unsplit launch by fp32 summation order only. */
     float* k_split_ws;
     int64_t k_split_ws_floats;
+    /* scheduling hint, no effect on the result: 0 = the library picks the form by launch size (launches with no more workgroups than CUs
+     * pipeline their own LDS-DMA through two stages, larger ones run two single-stage workgroups per CU); 1 / 2 = force that form. */
+    int32_t lds_stages;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
@@ -294,27 +297,6 @@ int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_pla
  * flat buffer for this pass): patch the table on the device — one tiny launch, no host traffic, stream-ordered behind the previous run. */
 int esr_conv3x3_wgrad_batch_rebase(void* workspace, const esr_wgrad_batch_plan* plan, int64_t delta_bytes, esr_stream_t stream);
 
-/* ---- weight / bias gradients of a whole ResidualDenseBlock_5C (codes/models/modules/block.py:230-235) in one work decomposition ----
- * x: the block's 24-group activation buffer [x (64 ch) | conv0 out | conv1 out | conv2 out | conv3 out]; g: its 24-group gradient buffer
- * [dy conv4 (64 ch) | dy conv3 | dy conv2 | dy conv1 | dy conv0] (gradients w.r.t. the convs' pre-activation outputs); z: the latent group
- * (lat channels, hi == NULL when lat == 0).  dw[c] ([cout_c][lat + 64 + 32 c][3][3], cout = 32, 32, 32, 32, 64) and db[c] ([cout_c], may be
- * NULL) are fp32 and ACCUMULATED into, scaled by alpha[c].  A workgroup owns one 32-channel tile of x against ALL the output tiles whose
- * convs read it (csrc/esr_wgrad_rdb.hip) — what esr_conv3x3_wgrad_batch computes for the same fifteen (layer, operand) pairs, with a third of
- * the on-chip operand traffic.  upload: HOST descriptor array -> caller-owned device workspace (>= _workspace_bytes(n)), host-blocking; run:
- * no host traffic; rebase: every dw / db moved by the same byte offset (a new flat gradient buffer), patched on the device. */
-typedef struct {
-    esr_act_view x, g, z;
-    int32_t lat, B, H, W;
-    float* dw[5];
-    float* db[5];
-    float alpha[5];
-} esr_wgrad_rdb_desc;
-typedef struct { int64_t nwg; int32_t n, nslices, split, f16, reserved; } esr_wgrad_rdb_plan;
-int64_t esr_wgrad_rdb_workspace_bytes(int n);
-int esr_wgrad_rdb_upload(const esr_wgrad_rdb_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_rdb_plan* plan, esr_stream_t stream);
-int esr_wgrad_rdb_run(const void* workspace, const esr_wgrad_rdb_plan* plan, esr_stream_t stream);
-int esr_wgrad_rdb_rebase(void* workspace, const esr_wgrad_rdb_plan* plan, int64_t delta_bytes, esr_stream_t stream);
-
 /* ---- Z-objective kernels (reference: codes/Z_optimization.py:170-209, SoftHistogramLoss.ComputeSoftHistogram, gray-scale / patch-size-1
  * form).  Soft histogram of n values with K bins whose centres run from lo to hi:  h[k] = (1/n) sum_i exp(-(d(v_i, c_k) + eps)^2 / T), the
  * distance wrapped with period hi as the reference does.  The forward writes one partial (un-normalised) histogram of K doubles per slab of
@@ -402,8 +384,7 @@ int esr_bn_param_grads(const double* sums2, const double* sums3, const float* rs
 enum {
     ESR_OP_CONV3X3 = 1, ESR_OP_PACK_NCHW = 2, ESR_OP_UNPACK_GRAD_NCHW = 3, ESR_OP_ACT_COMBINE = 4, ESR_OP_PIXEL_UNSHUFFLE = 5,
     ESR_OP_GRAD_ABSMAX = 6, ESR_OP_GRAD_SCALE = 7, ESR_OP_WGRAD_BATCH_RUN = 8, ESR_OP_PACK_BATCH_RUN = 9, ESR_OP_ZERO = 10,
-    ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16,
-    ESR_OP_WGRAD_RDB_RUN = 17
+    ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16
 };
 typedef struct { const float* src; int64_t src_batch_stride; int32_t B, C, h, w, c0, nc, pad, down; esr_act_view dst; } esr_cmd_pack_nchw;
 typedef struct { esr_act_view G; float* dst; int64_t dst_batch_stride; int32_t B, C, h, w, c0, nc, pad, down, accumulate; } esr_cmd_unpack_grad_nchw;
@@ -414,7 +395,6 @@ typedef struct { esr_act_view v; int32_t B; uint32_t* slot; } esr_cmd_grad_absma
 typedef struct { esr_act_view src, dst; int32_t B; const uint32_t* slot; int32_t exp; const float* scale_in; const float* scale_den; float* scale_out; } esr_cmd_grad_scale;
 typedef struct { const void* workspace; esr_wgrad_batch_plan plan; } esr_cmd_wgrad_batch_run;
 typedef struct { const void* workspace; int32_t n; int64_t nblocks; } esr_cmd_pack_batch_run;
-typedef struct { const void* workspace; esr_wgrad_rdb_plan plan; } esr_cmd_wgrad_rdb_run;
 typedef struct { void* p; int64_t n16; } esr_cmd_zero;
 typedef struct { esr_act_view src; int32_t B, nc; float* dst; } esr_cmd_unpack_nchw;
 typedef struct { esr_bn_desc d; int32_t mode; double* sums; } esr_cmd_bn;                 /* esr_bn_reduce (sums) / esr_bn_apply */
@@ -441,7 +421,6 @@ typedef struct {
         esr_cmd_bn bn;
         esr_cmd_bn_finalize bn_finalize;
         esr_cmd_bn_param_grads bn_param_grads;
-        esr_cmd_wgrad_rdb_run wgrad_rdb_run;
     } u;
 } esr_cmd;
 int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);

@@ -123,16 +123,15 @@ def test_rrdb_input_gradient_matches_reference_golden(name, nb, sf, lat):
 
 
 @pytest.mark.parametrize('bwd_fmt', ['f16', 'bf16'])
-def test_mixed_precision_input_gradient_against_oracle_autograd(bwd_fmt, monkeypatch):
+def test_mixed_precision_input_gradient_against_oracle_autograd(bwd_fmt):
     """'mixed' back-propagates to the input (the Z search) in its own fp16 format: gradient of the residual stream stored hi+lo, hi-plane
     operands inside the dense blocks, the incoming gradient scaled by a power of two into fp16's range.  Checked against autograd through
     the fp32 CPU oracle at training-scale weights (kaiming x0.1, RRDB-6, latent 3) with a cotangent of size 1e-7 — a mean-reduced loss,
     far below fp16's smallest subnormal without the scaling.  Measured (RRDB-23): relative L2 8.5e-6 (f16), 9.2e-6 (the bf16 hi+lo variant
-    ESR_MIXED_BWD=bf16), split 9.2e-5."""
+    mixed_bwd = 'bf16'), split 9.2e-5."""
     import models.modules.architecture as arch
     import models.networks as N
     from oracle import rrdb_oracle as ro
-    monkeypatch.setenv('ESR_MIXED_BWD', bwd_fmt)
     nb, lat = 6, 3
     torch.manual_seed(5)
     net = arch.RRDBNet(3, 3, 64, nb, gc=32, upscale=4, latent_input='all_layers_HR_downscaled', num_latent_channels=lat)
@@ -145,6 +144,7 @@ def test_mixed_precision_input_gradient_against_oracle_autograd(bwd_fmt, monkeyp
     (ro.rrdb_forward(sd, xc, nb, 4, lat) * cot).sum().backward()
     net = net.to(DEV)
     net.set_precision('mixed')
+    net.engine.mixed_bwd = bwd_fmt
     for p in net.parameters():
         p.requires_grad_(False)
     xg = x0.clone().to(DEV).requires_grad_(True)
@@ -439,21 +439,3 @@ def test_gradients_meet_the_bar_under_the_gpu_activation_pattern(nb, sf, lat):
         worst = max(worst, e)
         assert e < 1e-3, (k, e)
     print('flips %d of %d activations; dx rel_l2 %.2e; worst parameter-gradient rel_l2 %.2e' % (flips, sum(s.numel() for s in stored), rel_l2(dx.cpu().numpy(), xg.grad.numpy()), worst))
-
-
-@pytest.mark.parametrize('precision', ['split', 'bf16'])
-def test_block_level_weight_gradient_matches_the_per_pair_launch(precision, monkeypatch):
-    """esr_wgrad_rdb_* (a dense block's five weight gradients from one work decomposition: one input tile against all the output tiles that pair
-    with it) against esr_conv3x3_wgrad_batch (one workgroup per pair) on the same backward pass: same dW / db up to summation order."""
-    outs = {}
-    for flag in ('0', '1'):
-        monkeypatch.setenv('ESR_WGRAD_RDB', flag)
-        net = _rrdb(2, 4, 3).to(DEV)
-        net.set_precision(precision)
-        x = seeded_uniform((3, 3 + 3 * 16, 20, 37), 1301, -1.0, 1.0).to(DEV)
-        y = net(x)
-        (y * seeded_uniform(tuple(y.shape), 1302, -1.0, 1.0).to(DEV)).sum().backward()
-        outs[flag] = {n: p.grad.clone() for n, p in net.named_parameters()}
-    for n in outs['0']:
-        a, b = outs['1'][n].double(), outs['0'][n].double()
-        assert float((a - b).norm()) <= 2e-5 * max(float(b.norm()), 1e-6 * float(max(v.norm() for v in outs['0'].values()))), n

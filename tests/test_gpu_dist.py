@@ -107,7 +107,7 @@ def test_two_ranks_on_one_gpu_average_the_generator_gradients_in_place():
 def _run_bench(extra, timeout):
     import json
     import subprocess
-    env = dict(os.environ, ESR_BENCH_SHARE_GPU='1', ESR_D_MIOPEN_FIND='0', OMP_NUM_THREADS='4')
+    env = dict(os.environ, ESR_BENCH_SHARE_GPU='1', OMP_NUM_THREADS='4')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'] + extra, env=env, cwd=ROOT,
@@ -204,7 +204,7 @@ def test_sharded_z_search_on_the_real_generator_matches_one_process():
 def _worker_gan(rank, world, port, q):
     try:
         _paths()
-        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', ESR_D_MIOPEN_FIND='0')
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
         torch.cuda.set_device(0)
         from esr_hip import dist as D
         D.init_from_env(backend='gloo')
