@@ -158,6 +158,36 @@ def cpu_baseline(G, cem):
                          'sample': 'median of 5 runs, %d threads' % best}}, x, y, gen
 
 
+def kernel_set_id():
+    """Identity of the kernel sources a counter summary was taken on: sha256 over the conv / CEM kernel translation units and the shared
+    header (the files whose code the static PMC fields of the headline describe), first 16 hex digits.  tools/summarise_*.py stamp it into
+    every summary they write; this file prints a static PMC field only when the stamp equals the current sources'."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('esr_conv.hip', 'esr_cem.hip', 'esr_common.h'):
+        with open(os.path.join(ROOT, 'explorable-super-resolution_amd', 'csrc', f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def git_blob_id(path):
+    """git's blob id of a file's current content (sha1 of 'blob <size>\\0' + bytes): lets a reader find the exact committed summary."""
+    import hashlib
+    data = open(path, 'rb').read()
+    return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
+
+
+def _static_pmc(path, key):
+    """(value, provenance) of a committed counter summary — value None when the summary carries no kernel-set stamp or was taken on other
+    kernel sources than the ones in the tree now (the provenance then says so instead of a stale number being printed)."""
+    d = json.load(open(path))
+    prov = {'file': os.path.basename(path), 'git_blob': git_blob_id(path), 'kernel_set': d.get('kernel_set'), 'kernel_set_now': kernel_set_id()}
+    if d.get('kernel_set') != prov['kernel_set_now']:
+        prov['stale'] = 'csrc changed since these counters were taken: not printed'
+        return None, prov
+    return d.get(key), prov
+
+
 def newest_pmc(precision):
     """HBM bytes per conv launch measured with rocprofv3 PMC passes of this same command on an earlier run (FETCH_SIZE / WRITE_SIZE, separate
     --pmc runs, FETCH_SIZE x2 on gfx950; tools/summarise_profiles.py): the newest summary committed under profiles/ for this precision."""
@@ -168,7 +198,7 @@ def newest_pmc(precision):
                  key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])    # r01_v9 < r01_v11 < r02_v1
     if not pmc or precision not in ('split', 'mixed'):
         return None, None
-    return json.load(open(pmc[-1]))['hbm_bytes_per_launch'], os.path.basename(pmc[-1])
+    return _static_pmc(pmc[-1], 'hbm_bytes_per_launch')
 
 
 def newest_pmc_mfma(precision):
@@ -182,7 +212,7 @@ def newest_pmc_mfma(precision):
                 key=lambda f: [int(n) for n in re.findall(r'\d+', os.path.basename(f))])
     if not fs:
         return None, None
-    return json.load(open(fs[-1])).get('all_conv_launches'), os.path.basename(fs[-1])
+    return _static_pmc(fs[-1], 'all_conv_launches')
 
 
 # ---------------------------------------------------------------------------------------------------------------- main
@@ -240,7 +270,7 @@ def main(argv=None):
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or 'WORLD_SIZE' in os.environ:        # under a launcher the collectives run whatever the world size is (one rank: RCCL all the same)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if select_backend(os.environ) == 'gloo':
@@ -376,6 +406,8 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
     if traffic:
         out['roofline']['frac_physical_static'] = traffic / t_launch / HBM_PEAK      # bytes the mode really moves (static PMC figure) / measured time
     pm, pm_src = newest_pmc_mfma(precision) if BATCH == 32 else (None, None)
+    if pm_src and not pm:
+        out['roofline']['mfma_counters_source'] = pm_src         # stale summary: the provenance says why nothing is printed
     if pm:
         # counters of an earlier rocprofv3 run of this command (a profiled run clocks ~2 % lower): fraction of cycles the MFMA pipes were busy
         # and GRBM_GUI_ACTIVE / wall time; 32 busy cycles per v_mfma_f32_32x32x16

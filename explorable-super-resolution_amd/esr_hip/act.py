@@ -454,6 +454,7 @@ class PackedSum:
 
 
 _launch_parity = 0
+LDS_STAGES = 0              # esr_conv3x3_desc.lds_stages of every launch built here: 0 = the library picks by launch size, 1 / 2 = that form
 ALTERNATE_ORDER = True        # module attribute (experiments may clear it): consecutive launches walk the tile space in opposite directions
 
 
@@ -491,6 +492,7 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
         reverse = bool(_launch_parity & 1) and ALTERNATE_ORDER
         _launch_parity += 1
     d.reverse_order = 1 if reverse else 0
+    d.lds_stages = LDS_STAGES
     d.weight_planes = {0: 1, 1: 2, 2: 1, 3: 2}[fmt_code(pc.split)]
     d.in1_lo_groups = in1_lo_groups
     d.pixel_shuffle, d.ps_rowgroup0 = pixel_shuffle, ps_rowgroup0

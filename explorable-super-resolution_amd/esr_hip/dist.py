@@ -14,7 +14,11 @@ import torch.distributed as dist
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True once a process group exists — ALSO at world size 1: a job started by a launcher (torchrun / bench.py --gpus N) runs the same
+    collectives whatever N is, so that the one-GPU box the tests have executes the RCCL code path itself (with one rank every collective
+    is the identity: results are bit-identical to the plain single process, tests/test_gpu_dist.py).  A plain process without a launcher has
+    no group and skips them."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def rank():
@@ -27,9 +31,8 @@ def world_size():
 
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun-style env vars (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world <= 1 or (dist.is_available() and dist.is_initialized()):
-        return
+    if 'WORLD_SIZE' not in os.environ or 'RANK' not in os.environ or (dist.is_available() and dist.is_initialized()):
+        return                    # not under a launcher (plain single process), or already initialised
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:

@@ -92,6 +92,11 @@ def main():
         out['all_conv_launches'] = {'wall_s_sum': tot['wall'], 'effective_clock_ghz': tot['GRBM_GUI_ACTIVE_per_xcd'] / tot['wall'] / 1e9,
                                     'mfma_busy_frac': tot['SQ_VALU_MFMA_BUSY_CYCLES'] / N_SIMD / tot['GRBM_GUI_ACTIVE_per_xcd'] if tot['SQ_VALU_MFMA_BUSY_CYCLES'] else None,
                                     'mfma_issue_pflops_bf16': tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 32 * 32768 / tot['wall'] / 1e15 if tot['SQ_VALU_MFMA_BUSY_CYCLES'] else None}
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    out['kernel_set'] = bench.kernel_set_id()        # the sources these counters describe (bench.py prints them only while it matches)
+    out['library'] = os.environ.get('ESR_HIP_LIBRARY') or 'libesr_hip.so'
     path = os.path.join(ROOT, 'profiles', a.tag + '_pmc_mfma.json')
     json.dump(out, open(path, 'w'), indent=1)
     print(json.dumps(out.get('all_conv_launches'), indent=1))

@@ -80,6 +80,10 @@ def main():
         if a.sq:
             sq, ns = counter_sum(a.sq)
             d['sq_counters_sum_over_%d_launches' % ns] = dict(sq)
+        import sys
+        sys.path.insert(0, ROOT)
+        import bench
+        d['kernel_set'] = bench.kernel_set_id()      # the sources these counters describe (bench.py prints them only while it matches)
         json.dump(d, open(os.path.join(out, a.tag + '_pmc_traffic.json'), 'w'), indent=1)
         print(json.dumps(d, indent=1))
 
