@@ -430,3 +430,23 @@ def test_anisotropic_kernels_keep_the_2d_path():
     G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
     assert cem_ops._taps_entry(G.DownscaleOP.taps(), torch.device(DEV, 0))[1] is None
     imresize.kernels = {}
+
+
+def test_chunked_projection_equals_the_whole_batch_projection():
+    """cem_ops.project runs the three CEM kernels per chunk of a few images when the generator output is larger than the Infinity Cache share it
+    is given (the second read of `g` then hits the cache): same kernels per image, so the result must not change by a bit — also for a
+    batch that is not a multiple of the chunk."""
+    from esr_hip import cem_ops
+    net = _cem(4, None, None).WrapArchitecture_PyTorch(generated_image=None).to(DEV).eval()
+    lr = seeded_uniform((5, 3, 20, 24), 31).to(DEV)
+    gen = seeded_uniform((5, 3, 4 * 20, 4 * 24), 32).to(DEV)            # (eval mode pads both by the CEM margins)
+    keep = cem_ops.PROJECT_CHUNK_IMAGES, cem_ops.PROJECT_CHUNK_BYTES
+    try:
+        with torch.no_grad():
+            cem_ops.PROJECT_CHUNK_IMAGES = 0
+            whole = net([lr, gen]).clone()
+            cem_ops.PROJECT_CHUNK_IMAGES, cem_ops.PROJECT_CHUNK_BYTES = 2, 3 * (4 * 40) * (4 * 44) * 4 * 2
+            chunked = net([lr, gen])
+    finally:
+        cem_ops.PROJECT_CHUNK_IMAGES, cem_ops.PROJECT_CHUNK_BYTES = keep
+    assert whole.shape == chunked.shape and torch.equal(whole, chunked)
