@@ -511,6 +511,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) fa[pl] = frag_tr(sy + pl * WG_Y_BYTES + (rr * WG_TW + ks * 16) * 16);      // K step j = 2 rr + ks
                 if constexpr (LATK) {
+                    if (do_bias) {                                // (a main input of <= 3 channels run in this form: its workgroups own the bias too)
+                        accb = mfma_e<FMT>(fa[0], ones, accb);
+                        if (NPL == 2) accb = mfma_e<FMT>(fa[NPL - 1], ones, accb);
+                    }
                     // B fragment by gather: this lane's column n = lane & 31 -> (tap n / 3, channel n % 3); its 8 K values are pixels
                     // kblk * 8 .. + 7 of the K step at that tap's shift
                     const int n = lane & 31, tcol = n < 27 ? n / 3 : 8, ccol = n < 27 ? n % 3 : 0;
@@ -583,6 +587,20 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
             if (direct) { if (co < a.cout) a.dw[((long long)co * a.cin_total + c) * 9 + t] += a.alpha * v; }
             else wsp[t * 1024 + i * 64 + half * 32 + c] = v;
         }
+        if (do_bias) {                                            // uniform; column 0 of the dY x ones tile, as below
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = accb[i];
+            __syncthreads();
+            if (tid < 32) {
+                const int row = tid, i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
+                float v = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 16 + i) * 64 + ln];
+                if (direct) { if (cot * 32 + row < a.cout) a.db[cot * 32 + row] += a.alpha * v; }
+                else a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = v;
+            }
+        }
         return;
     }
 #pragma unroll
@@ -649,6 +667,7 @@ __device__ __forceinline__ void wgrad_dispatch_taps(const WgradArgs& a, const in
 template <int NPL, int NST, int FMT, bool S2D>
 __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, const int group, const int slice, unsigned char* const smem) {
     if constexpr (S2D) {
+        if (a.latk && group / a.mt >= a.ncit_main) return wgrad_body<NPL, NST, FMT, 0x1FF, 0, true>(a, group, slice, smem);
         if (a.shape == 1) return wgrad_dispatch_taps<NPL, NST, FMT, 1>(a, group, slice, smem);
         if (a.shape == 2) return wgrad_dispatch_taps<NPL, NST, FMT, 2>(a, group, slice, smem);
         return wgrad_dispatch_taps<NPL, NST, FMT, 0>(a, group, slice, smem);
@@ -711,6 +730,10 @@ __global__ void wgrad_reduce_batch_kernel(const WgradArgs* __restrict__ table) {
 
 // grid decomposition shared by the workspace query and the launch
 struct WgradPlan { int tiles_x, tiles_y, ncit_main, ncit, ngroups, nslices, mt, shape; };
+// A MAIN input of <= 3 channels and no latent segment (the critic's first conv on RGB, codes/models/modules/architecture.py:452): its one input
+// tile is run in the latent tile's form — the 27 (tap, channel) columns as ONE MFMA tile (wgrad_body<..., LATK>) — instead of nine 32-wide tiles
+// that are 3/32 full: the layer is presented to the kernel as "no main tiles + a latent tile of cin_main channels".
+static bool main_as_latk(const esr_wgrad_desc* d) { return !d->xlat.hi && d->cin_main <= 3 && d->upsample <= 1; }
 static bool desc_is_s2d(const esr_wgrad_desc* d) {
     return d->tap_masks[0] == 432 && d->tap_masks[1] == 216 && d->tap_masks[2] == 54 && d->tap_masks[3] == 27 && d->cin_main % 128 == 0 &&
            d->dy.fmt != ESR_FMT_F16;
@@ -722,7 +745,7 @@ static WgradPlan wgrad_plan(const esr_wgrad_desc* d, int target_wgs = 512, bool 
     p.shape = 0;
     p.tiles_x = (d->W + WG_TW - 1) / WG_TW;
     p.tiles_y = (d->H + WG_TH - 1) / WG_TH;
-    if (shapes && (d->upsample <= 1))
+    if (shapes && (d->upsample <= 1) && !main_as_latk(d))
         for (int sh = 1; sh <= 2; ++sh) {
             const int tw = WG_TW >> sh, th = WG_TH << sh;
             const int tx = (d->W + tw - 1) / tw, ty = (d->H + th - 1) / th;
@@ -731,6 +754,7 @@ static WgradPlan wgrad_plan(const esr_wgrad_desc* d, int target_wgs = 512, bool 
     p.ncit_main = (d->cin_main + 31) / 32;
     const int lat = d->xlat.hi ? d->lat : 0;
     p.ncit = p.ncit_main + (lat ? 1 : 0);
+    if (main_as_latk(d)) { p.ncit_main = 0; p.ncit = 1; }
     p.ngroups = p.ncit * p.mt;
     const int ntiles = p.tiles_x * p.tiles_y * d->B;
     int ns = (target_wgs + p.ngroups - 1) / p.ngroups;   // single launch: ~2 workgroups per CU in total (one resident at a time)
@@ -780,6 +804,12 @@ static WgradArgs wgrad_args(const esr_wgrad_desc* d, const WgradPlan& p, float* 
     a.ws = ws;
     // (a hint: any other mask pattern accumulates all nine taps — zeros where the weights are structurally zero)
     a.tapmode = (d->tap_masks[0] == 432 && d->tap_masks[1] == 216 && d->tap_masks[2] == 54 && d->tap_masks[3] == 27 && d->cin_main % 128 == 0) ? 1 : 0;
+    if (main_as_latk(d)) {
+        a.xlat = a.x;
+        a.lat = d->cin_main;
+        a.cin_main = 0;
+        a.latk = 1;
+    }
 
     return a;
 }

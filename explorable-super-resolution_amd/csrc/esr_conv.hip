@@ -82,8 +82,13 @@ struct ConvArgs {
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
-    int nslices;                    // cout / 64 when cout > 64, else 1
-    long long wslice;               // cout > 64: 16-byte vectors between the weight packs of consecutive 64-channel output slices (blockIdx.y)
+    int nslices;                    // output slices of this launch (blockIdx.y): cout / 64 when cout > 64; 2 for a 64-channel layer run as two 32-channel halves
+    long long wslice;               // 16-byte vectors between the weight fragments of consecutive output slices (0: no slices)
+    // where chunk cp's / tap t's fragments sit in the pack: normally 9 * MT * NPW and MT * NPW fragments apart.  A 64-channel layer of a SMALL
+    // launch is run as two 32-channel slices by the MT = 1 kernel out of the same [chunk][tap][M tile][plane] pack: slice s starts s * NPW
+    // fragments in and its taps are 2 * NPW fragments apart
+    long long wchunk;               // 16-byte vectors between the fragments of consecutive chunks
+    int wtap;                       // fragments between consecutive taps
     // split K (esr_conv3x3_desc.k_split_ws): blockIdx.z = which run of `ncp` chunks (kz_groups channel groups) of the input this workgroup
     // contracts; its fp32 partial sums go to slab z of the workspace ([B][nchw_ctot][H][W] each, EPI_NCHW store), bias in slab 0 only
     int ksplit, kz_groups;
@@ -179,13 +184,15 @@ template <int NPL>
 struct Bases {
     const uint4* p[2 * NPL];
     const uint4* w;
+    int wtap;
 };
 template <int NPL, int MT, int NPW>
 __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b, int lane) {
     Bases<NPL> r;
 #pragma unroll
     for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
-    r.w = a.wpack + (size_t)cp * (9 * MT * NPW) * 64;          // uniform: the lane's 16 bytes are the copy's per-lane offset
+    r.w = a.wpack + (size_t)cp * a.wchunk;                     // uniform: the lane's 16 bytes are the copy's per-lane offset
+    r.wtap = a.wtap;
     return r;
 }
 
@@ -240,7 +247,10 @@ __device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>&
         }
     }
     const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
-    if constexpr (TMODE == 0) {
+    if constexpr (TMODE == 0 && MT == 1) {
+        // (the pack may be a wider layer's: fragment j = tap * NPW + plane sits (tap * wtap + plane) fragments in — ConvArgs.wtap)
+        for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + ((j / NPW) * bs.wtap + j % NPW) * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+    } else if constexpr (TMODE == 0) {
         for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
     } else {
         static_assert(TMODE == 0 || NW == 4, "one live tap per wave");
@@ -420,13 +430,14 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // 32 x 8 workgroups instead of eight launches of 32.  (Everything below is uniform: the shifts are scalar adds; slice 0 adds zero.)
     ConvArgs a = a_in;
     {
-        const long long sl = blockIdx.y;
+        const long long sl = blockIdx.y;                            // a slice is this kernel's MT * 32 output channels
         a.wpack += sl * a.wslice;
-        if (a.bias) a.bias += sl * 64;
-        auto shift = [&](DView& v) { if (v.hi) { v.hi += sl * 8 * v.cs; if (v.lo) v.lo += sl * 8 * v.cs; } };
+        if (a.bias) a.bias += sl * (MT * 32);
+        auto shift = [&](DView& v) { if (v.hi) { v.hi += sl * (MT * 4) * v.cs; if (v.lo) v.lo += sl * (MT * 4) * v.cs; } };
         shift(a.out); shift(a.out2); shift(a.res1); shift(a.res2); shift(a.mask);
+        if constexpr ((EPI & EPI_RESIN) != 0) a.resin_g0 += (int)sl * (MT * 4);      // the slice's residual groups: further along the input
         if constexpr ((EPI & EPI_NCHW) != 0) {
-            a.out_nchw += sl * 64 * (long long)a.H * a.W;           // (slices with an fp32 destination: the split-K partial sums, B == 1 per image row below)
+            a.out_nchw += sl * (MT * 32) * (long long)a.H * a.W;           // (slices with an fp32 destination: the split-K partial sums, B == 1 per image row below)
             if (a.ksplit > 1) {
                 const long long kz = blockIdx.z;
                 a.in1.hi += kz * a.kz_groups * a.in1.cs;
@@ -1039,9 +1050,22 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.H = d->H;
     a.W = d->W;
     const int npl = split ? 2 : 1;
-    const int wgs_per_cu = mt == 1 ? WGS_MT1 : WGS_MT2;
-    const TileCfg t = pick_tile(d->H, d->W, npl, mt, wgs_per_cu);
+    // A 64-channel layer whose launch would leave every workgroup alone on its CU (no more tiles than CUs: the 52 x 52 training crops, a single
+    // image of the Z search) runs as TWO 32-channel output slices of the MT = 1 kernel instead (grid y; same pack, ConvArgs.wtap): twice the
+    // workgroups, so that two are resident per CU and cover each other's copy issue and waits — at the price of staging the input tile twice
+    // (the second copy comes out of the same XCD's L2).  Same arithmetic per output channel: results are bit-identical to the 64-channel form.
+    bool mslice = false;
+    auto all_taps = [](const int32_t (&m)[4]) { return (m[0] == 0 || m[0] == 0x1FF) && (m[1] == 0 || m[1] == 0x1FF) && (m[2] == 0 || m[2] == 0x1FF) && (m[3] == 0 || m[3] == 0x1FF); };
+    if (nslices == 1 && mt == 2 && d->cout == 64 && !d->out_nchw && !ps && d->lds_stages == 0 && !d->k_split_ws && all_taps(d->tap_mask_k) &&
+        all_taps(d->tap_mask_m) && (!d->mask_src.hi || (d->mask_cg0 == 0 && d->mask_cg1 >= 8))) {
+        const TileCfg t2 = pick_tile(d->H, d->W, npl, 2, WGS_MT2);
+        mslice = t2.TH != 0 && (long long)t2.tiles_x * t2.tiles_y * d->B <= 320;
+    }
+    const int mt_k = mslice ? 1 : mt;                              // M tiles per workgroup of the kernel that runs
+    const int wgs_per_cu = mt_k == 1 ? WGS_MT1 : WGS_MT2;
+    const TileCfg t = pick_tile(d->H, d->W, npl, mt_k, wgs_per_cu);
     if (t.TH == 0) return ESR_E_UNSUPPORTED;
+    if (mslice) { a.cout = 32; a.nslices = 2; }
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     a.ncp = (a.in0.ncg + a.in1.ncg + 1) / 2;
@@ -1091,6 +1115,9 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (wpl == 0) wpl = f16 ? 1 : npl;
     if (wpl < 1 || wpl > npl || (!f16 && wpl != npl)) return ESR_E_ARG;
     a.wslice = nslices > 1 ? (long long)a.ncp * 9 * 2 * wpl * 64 : 0;
+    a.wchunk = (long long)9 * mt * wpl * 64;
+    a.wtap = mt * wpl;
+    if (mslice) a.wslice = (long long)wpl * 64;                   // slice s = M tile s of every (chunk, tap) block of the 64-row pack
     // which leading chunks of the concatenated input carry a lo plane
     a.lo_chunks = a.ncp;
     bool partlo = false;
@@ -1148,11 +1175,11 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
         return split ? launch<2, 2, 0, 0, 2, false, 1>(a, s) : launch<1, 2, 0, 0, 1, false, 1>(a, s);
     if (tm2)
         return split ? launch<2, 2, 0, 0, 2, false, 2>(a, s) : launch<1, 2, 0, 0, 1, false, 2>(a, s);
-    if (f16 && split && partlo && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
-    if (f16 && split && partlo) return mt == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
-    if (f16 && split && wpl == 2) return mt == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);
-    if (f16 && split) return mt == 1 ? launch_epi<2, 1, 1, 1>(a, epi, s) : launch_epi<2, 2, 1, 1>(a, epi, s);
-    if (f16) return mt == 1 ? launch_epi<1, 1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1, 1>(a, epi, s);
-    if (split) return mt == 1 ? launch_epi<2, 1, 0, 2>(a, epi, s) : launch_epi<2, 2, 0, 2>(a, epi, s);
-    return mt == 1 ? launch_epi<1, 1, 0, 1>(a, epi, s) : launch_epi<1, 2, 0, 1>(a, epi, s);
+    if (f16 && split && partlo && wpl == 2) return mt_k == 1 ? launch_epi<2, 1, 1, 2, true>(a, epi, s) : launch_epi<2, 2, 1, 2, true>(a, epi, s);
+    if (f16 && split && partlo) return mt_k == 1 ? launch_epi<2, 1, 1, 1, true>(a, epi, s) : launch_epi<2, 2, 1, 1, true>(a, epi, s);
+    if (f16 && split && wpl == 2) return mt_k == 1 ? launch_epi<2, 1, 1, 2>(a, epi, s) : launch_epi<2, 2, 1, 2>(a, epi, s);
+    if (f16 && split) return mt_k == 1 ? launch_epi<2, 1, 1, 1>(a, epi, s) : launch_epi<2, 2, 1, 1>(a, epi, s);
+    if (f16) return mt_k == 1 ? launch_epi<1, 1, 1, 1>(a, epi, s) : launch_epi<1, 2, 1, 1>(a, epi, s);
+    if (split) return mt_k == 1 ? launch_epi<2, 1, 0, 2>(a, epi, s) : launch_epi<2, 2, 0, 2>(a, epi, s);
+    return mt_k == 1 ? launch_epi<1, 1, 0, 1>(a, epi, s) : launch_epi<1, 2, 0, 1>(a, epi, s);
 }

@@ -85,11 +85,34 @@ struct BnArgs {
     int const_stats;                  // the affine is a constant of y (eval-mode BatchNorm / no norm): no mean terms in the gradients
     long long npg;                    // elements per channel and group: (B/groups) * H * W
     int nsplit;
+    int chunks;                       // bn_apply: blocks per (image, channel group) plane
 };
+
+// raw 16-byte vectors of one pixel (hi [+ lo]) and their decoding: loads are issued for several pixels before the first is decoded
+struct Raw8 { uint4 h, l; };
+__device__ __forceinline__ Raw8 ldraw(const CView& v, long long o) {
+    Raw8 r;
+    r.h = v.hi[o];
+    r.l = v.lo ? v.lo[o] : make_uint4(0, 0, 0, 0);
+    return r;
+}
+__device__ __forceinline__ void dec8(const CView& v, const Raw8& r, float* f) {
+    const uint32_t hw[4] = {r.h.x, r.h.y, r.h.z, r.h.w}, lw[4] = {r.l.x, r.l.y, r.l.z, r.l.w};
+    const bool lo = v.lo != nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t hb = (e & 1) ? (hw[e >> 1] >> 16) : (hw[e >> 1] & 0xFFFF), lb = (e & 1) ? (lw[e >> 1] >> 16) : (lw[e >> 1] & 0xFFFF);
+        f[e] = v.fmt == ESR_FMT_F16 ? h2f(hb) + (lo ? h2f(lb) : 0.f) : bf2f(hb) + (lo ? bf2f(lb) : 0.f);
+    }
+}
 
 // MODE 0: sum y, sum y^2                      (forward statistics)
 // MODE 1: sum dyb, sum dyb*xh                 (backward)
 // MODE 2: sum u, sum u*xh, sum u*dyb          (double backward)
+// Block = (channel group, statistics group, one of nsplit interleaved shares of the group's pixels); every thread walks its pixels two at a
+// time (both pixels' loads in flight together), keeps fp32 partial sums, and the block folds them in double: 16 threads per value, each adding 16
+// of the 256 per-thread partials, then four shuffles — the fold used to be ONE thread per value walking all 256 (a ~20 k-cycle tail behind a
+// main loop of 16-32 pixels per thread).
 template <int MODE, bool S2D>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
     constexpr int K = MODE == 2 ? 3 : 2;
@@ -111,98 +134,165 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
         rs[e] = (ok && a.rstd) ? a.rstd[g * a.C + c] : 1.f;
     }
     const long long hw = (long long)a.H * a.W;
-    for (long long p = (long long)sp * 256 + threadIdx.x; p < a.npg; p += (long long)a.nsplit * 256) {
+    const long long step = (long long)a.nsplit * 256;
+    auto offs = [&](long long p, long long& oy, long long& od, long long& ou) {
         const int b = g * Bg + (int)(p / hw);
         const int r = (int)(p % hw), yy = r / a.W, xx = r % a.W;
-        float fy[8];
-        ld8(a.y, voff<false>(a.y, b, cg, yy, xx), fy);
+        oy = voff<false>(a.y, b, cg, yy, xx);
+        od = MODE >= 1 ? voff<S2D>(a.dz, b, cg, yy, xx) : 0;
+        ou = MODE == 2 ? voff<false>(a.u, b, cg, yy, xx) : 0;
+    };
+    auto add = [&](const Raw8& ry, const Raw8& rd, const Raw8& ru) {
+        float fy[8], fd[8], fu[8];
+        dec8(a.y, ry, fy);
         if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { acc[0][e] += fy[e]; acc[1][e] += fy[e] * fy[e]; }
-        } else {
-            float fd[8];
-            ld8(a.dz, voff<S2D>(a.dz, b, cg, yy, xx), fd);
-            float fu[8];
-            if (MODE == 2) ld8(a.u, voff<false>(a.u, b, cg, yy, xx), fu);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pre = sc[e] * fy[e] + sh[e];
-                const float dyb = fd[e] * (pre > 0.f ? 1.f : a.slope);
-                const float xh = (fy[e] - mu[e]) * rs[e];
-                if (MODE == 1) { acc[0][e] += dyb; acc[1][e] += dyb * xh; }
-                else { acc[0][e] += fu[e]; acc[1][e] += fu[e] * xh; acc[2][e] += fu[e] * dyb; }
-            }
+            return;
         }
+        dec8(a.dz, rd, fd);
+        if (MODE == 2) dec8(a.u, ru, fu);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pre = sc[e] * fy[e] + sh[e];
+            const float dyb = fd[e] * (pre > 0.f ? 1.f : a.slope);
+            const float xh = (fy[e] - mu[e]) * rs[e];
+            if (MODE == 1) { acc[0][e] += dyb; acc[1][e] += dyb * xh; }
+            else { acc[0][e] += fu[e]; acc[1][e] += fu[e] * xh; acc[2][e] += fu[e] * dyb; }
+        }
+    };
+    long long p = (long long)sp * 256 + threadIdx.x;
+    for (; p + step < a.npg; p += 2 * step) {
+        long long oy0, od0, ou0, oy1, od1, ou1;
+        offs(p, oy0, od0, ou0);
+        offs(p + step, oy1, od1, ou1);
+        Raw8 ry0 = ldraw(a.y, oy0), ry1 = ldraw(a.y, oy1), rd0{}, rd1{}, ru0{}, ru1{};
+        if (MODE >= 1) { rd0 = ldraw(a.dz, od0); rd1 = ldraw(a.dz, od1); }
+        if (MODE == 2) { ru0 = ldraw(a.u, ou0); ru1 = ldraw(a.u, ou1); }
+        add(ry0, rd0, ru0);
+        add(ry1, rd1, ru1);
     }
-    __shared__ float red[K * 8][256];
+    if (p < a.npg) {
+        long long oy0, od0, ou0;
+        offs(p, oy0, od0, ou0);
+        Raw8 ry0 = ldraw(a.y, oy0), rd0{}, ru0{};
+        if (MODE >= 1) rd0 = ldraw(a.dz, od0);
+        if (MODE == 2) ru0 = ldraw(a.u, ou0);
+        add(ry0, rd0, ru0);
+    }
+    constexpr int RS = 256 + 16;                     // row pitch: the four rows a wave folds at once fall into disjoint bank windows
+    __shared__ float red[K * 8][RS];
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[k * 8 + e][threadIdx.x] = acc[k][e];
     __syncthreads();
-    if (threadIdx.x < K * 8) {
+#pragma unroll
+    for (int v0 = 0; v0 < K * 8; v0 += 16) {
+        const int vi = v0 + (threadIdx.x >> 4), j = threadIdx.x & 15;
         double s = 0.0;
-        for (int i = 0; i < 256; ++i) s += (double)red[threadIdx.x][i];
-        const int k = threadIdx.x / 8, e = threadIdx.x % 8, c = cg * 8 + e;
-        if (c < a.C) atomicAdd(a.sums + ((long long)g * a.C + c) * K + k, s);
+        if (vi < K * 8)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += (double)red[vi][i * 16 + j];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (j == 0 && vi < K * 8) {
+            const int k = vi / 8, e = vi % 8, c = cg * 8 + e;
+            if (c < a.C) atomicAdd(a.sums + ((long long)g * a.C + c) * K + k, s);
+        }
     }
 }
 
 // MODE 0: z = lrelu(scale*y + shift)                                   -> out0 (S2D layout when S2D)
 // MODE 1: dy (see header)                                              -> out0;  dz read with S2D indexing when S2D
 // MODE 2: g_dz -> out0 (S2D layout when S2D), g_y -> out1
-template <int MODE, bool S2D>
+// Block = (image, channel group, chunk of U x 256 pixels): the 8 channels' per-channel constants (affine, statistics, the backward sums and their
+// double -> float conversions: ~60 loads and a dozen fp64 operations) are formed ONCE per thread and serve its U pixels, whose loads are all
+// issued before the first result is computed.  (One pixel per thread re-derived them for every 16-byte vector: the kernels ran at 3 TB/s.)
+template <int MODE, bool S2D, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)a.B * a.ncg * a.H * a.W;
-    if (idx >= total) return;
-    const int xx = (int)(idx % a.W);
-    long long t = idx / a.W;
-    const int yy = (int)(t % a.H);
-    t /= a.H;
-    const int cg = (int)(t % a.ncg), b = (int)(t / a.ncg);
+    int t = blockIdx.x;
+    const int chunk = t % a.chunks;
+    t /= a.chunks;
+    const int cg = t % a.ncg, b = t / a.ncg;
     const int g = b / (a.B / a.groups);
-    float fy[8], o0[8], o1[8];
-    ld8(a.y, voff<false>(a.y, b, cg, yy, xx), fy);
-    float fd[8], fu[8];
-    if (MODE >= 1) ld8(a.dz, voff<S2D>(a.dz, b, cg, yy, xx), fd);
-    if (MODE == 2) ld8(a.u, voff<false>(a.u, b, cg, yy, xx), fu);
+    const int hw = a.H * a.W;
+    float sc[8], sh[8], mu[8], rs[8], k1[8], s1[8], s2[8], t1[8], t2[8], q[8];
+    bool okc[8];
     const double inv_n = 1.0 / (double)a.npg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = cg * 8 + e;
         const bool ok = c < a.C;
+        okc[e] = ok;
         const long long gc = (long long)g * a.C + (ok ? c : 0);
-        const float sc = (ok && a.scale) ? a.scale[gc] : 1.f, sh = (ok && a.shift) ? a.shift[gc] : 0.f;
-        const float pre = sc * fy[e] + sh;
-        if (MODE == 0) { o0[e] = ok ? (pre > 0.f ? pre : a.slope * pre) : 0.f; continue; }
-        const float m = pre > 0.f ? 1.f : a.slope;
-        const float dyb = fd[e] * m;
-        if (a.const_stats) {                          // y -> z is a fixed affine map + activation
-            if (MODE == 1) o0[e] = ok ? sc * dyb : 0.f;
-            else { o0[e] = ok ? m * sc * fu[e] : 0.f; o1[e] = 0.f; }
-            continue;
+        sc[e] = (ok && a.scale) ? a.scale[gc] : 1.f;
+        sh[e] = (ok && a.shift) ? a.shift[gc] : 0.f;
+        mu[e] = rs[e] = k1[e] = s1[e] = s2[e] = t1[e] = t2[e] = q[e] = 0.f;
+        if (MODE >= 1 && !a.const_stats) {
+            mu[e] = a.mean[gc];
+            rs[e] = a.rstd[gc];
+            k1[e] = (a.gamma ? a.gamma[ok ? c : 0] : 1.f) * rs[e];
+            s1[e] = (float)(a.s2[gc * 2] * inv_n);                      // E[dyb], E[dyb*xh]
+            s2[e] = (float)(a.s2[gc * 2 + 1] * inv_n);
+            if (MODE == 2) {
+                t1[e] = (float)(a.s3[gc * 3] * inv_n);
+                t2[e] = (float)(a.s3[gc * 3 + 1] * inv_n);
+                q[e] = (float)(a.s3[gc * 3 + 2] * inv_n) - t1[e] * s1[e] - t2[e] * s2[e];
+            }
         }
-        const float mu = a.mean[gc], rs = a.rstd[gc], gm = a.gamma ? a.gamma[ok ? c : 0] : 1.f;
-        const float xh = (fy[e] - mu) * rs;
-        const float s1 = (float)(a.s2[gc * 2] * inv_n), s2 = (float)(a.s2[gc * 2 + 1] * inv_n);       // E[dyb], E[dyb*xh]
-        const float dterm = dyb - s1 - xh * s2;
-        if (MODE == 1) { o0[e] = ok ? gm * rs * dterm : 0.f; continue; }
-        const float t1 = (float)(a.s3[gc * 3] * inv_n), t2 = (float)(a.s3[gc * 3 + 1] * inv_n), t3 = (float)(a.s3[gc * 3 + 2] * inv_n);
-        const float uterm = fu[e] - t1 - xh * t2;
-        const float q = t3 - t1 * s1 - t2 * s2;
-        o0[e] = ok ? m * gm * rs * uterm : 0.f;
-        o1[e] = ok ? -gm * rs * rs * (xh * q + s2 * uterm + t2 * dterm) : 0.f;
     }
-    // every result is the input of a conv (or weight-gradient) launch: write its zero border too
-    const long long os = voff<S2D>(a.out0, b, cg, yy, xx), op = voff<false>(MODE == 2 ? a.out1 : a.out0, b, cg, yy, xx);
-    if (MODE == 0 || MODE == 2) {
-        st8(a.out0, os, o0);
-        if (S2D) zero_border(a.out0, os, yy >> 1, xx >> 1, a.H / 2, a.W / 2);
-        else zero_border(a.out0, os, yy, xx, a.H, a.W);
+    Raw8 ry[U], rd[U], ru[U];
+    int ys[U], xs[U];
+    bool live[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int p = (chunk * U + i) * 256 + threadIdx.x;
+        live[i] = p < hw;
+        const int pc = live[i] ? p : 0;
+        ys[i] = pc / a.W;
+        xs[i] = pc - ys[i] * a.W;
+        ry[i] = ldraw(a.y, voff<false>(a.y, b, cg, ys[i], xs[i]));
+        if (MODE >= 1) rd[i] = ldraw(a.dz, voff<S2D>(a.dz, b, cg, ys[i], xs[i]));
+        if (MODE == 2) ru[i] = ldraw(a.u, voff<false>(a.u, b, cg, ys[i], xs[i]));
     }
-    if (MODE == 1) { st8(a.out0, op, o0); zero_border(a.out0, op, yy, xx, a.H, a.W); }
-    if (MODE == 2) { st8(a.out1, op, o1); zero_border(a.out1, op, yy, xx, a.H, a.W); }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        if (!live[i]) continue;
+        const int yy = ys[i], xx = xs[i];
+        float fy[8], fd[8], fu[8], o0[8], o1[8];
+        dec8(a.y, ry[i], fy);
+        if (MODE >= 1) dec8(a.dz, rd[i], fd);
+        if (MODE == 2) dec8(a.u, ru[i], fu);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = okc[e];
+            const float pre = sc[e] * fy[e] + sh[e];
+            if (MODE == 0) { o0[e] = ok ? (pre > 0.f ? pre : a.slope * pre) : 0.f; continue; }
+            const float m = pre > 0.f ? 1.f : a.slope;
+            const float dyb = fd[e] * m;
+            if (a.const_stats) {                          // y -> z is a fixed affine map + activation
+                if (MODE == 1) o0[e] = ok ? sc[e] * dyb : 0.f;
+                else { o0[e] = ok ? m * sc[e] * fu[e] : 0.f; o1[e] = 0.f; }
+                continue;
+            }
+            const float xh = (fy[e] - mu[e]) * rs[e];
+            const float dterm = dyb - s1[e] - xh * s2[e];
+            if (MODE == 1) { o0[e] = ok ? k1[e] * dterm : 0.f; continue; }
+            const float uterm = fu[e] - t1[e] - xh * t2[e];
+            o0[e] = ok ? m * k1[e] * uterm : 0.f;
+            o1[e] = ok ? -k1[e] * rs[e] * (xh * q[e] + s2[e] * uterm + t2[e] * dterm) : 0.f;
+        }
+        // every result is the input of a conv (or weight-gradient) launch: write its zero border too
+        const long long os = voff<S2D>(a.out0, b, cg, yy, xx), op = voff<false>(MODE == 2 ? a.out1 : a.out0, b, cg, yy, xx);
+        if (MODE == 0 || MODE == 2) {
+            st8(a.out0, os, o0);
+            if (S2D) zero_border(a.out0, os, yy >> 1, xx >> 1, a.H / 2, a.W / 2);
+            else zero_border(a.out0, os, yy, xx, a.H, a.W);
+        }
+        if (MODE == 1) { st8(a.out0, op, o0); zero_border(a.out0, op, yy, xx, a.H, a.W); }
+        if (MODE == 2) { st8(a.out1, op, o1); zero_border(a.out1, op, yy, xx, a.H, a.W); }
+    }
 }
 
 // One thread per channel; the groups are processed in order (the running statistics see the calls in the order the reference makes them).
@@ -280,6 +370,14 @@ bool s2d_view_ok(const CView& v, const BnArgs& a, bool s2d) { return v.hi && (s2
         ESR_CHECK_LAUNCH();                                                                                                     \
     } while (0)
 
+#define ESR_LAUNCH3(KERNEL, MODE, S2D, U, GRID, ARGS)                                                                          \
+    do {                                                                                                                        \
+        ESR_CLEAR_ERR();                                                                                                        \
+        if (S2D) hipLaunchKernelGGL((KERNEL<MODE, true, U>), dim3((unsigned)(GRID)), dim3(256), 0, (hipStream_t)stream, ARGS);  \
+        else hipLaunchKernelGGL((KERNEL<MODE, false, U>), dim3((unsigned)(GRID)), dim3(256), 0, (hipStream_t)stream, ARGS);     \
+        ESR_CHECK_LAUNCH();                                                                                                     \
+    } while (0)
+
 extern "C" int esr_bn_reduce(const esr_bn_desc* d, int mode, double* sums, esr_stream_t stream) {
     BnArgs a{};
     const int rc = fill_common(a, d);
@@ -306,11 +404,15 @@ extern "C" int esr_bn_apply(const esr_bn_desc* d, int mode, esr_stream_t stream)
     if (mode == 1 && !s2d_view_ok(a.out0, a, false)) return ESR_E_ARG;
     if (mode == 2 && (!s2d_view_ok(a.u, a, false) || !s2d_view_ok(a.out0, a, s2d) || !s2d_view_ok(a.out1, a, false))) return ESR_E_ARG;
     if (mode >= 1 && !a.const_stats && (!a.mean || !a.rstd || !a.s2 || (mode == 2 && !a.s3))) return ESR_E_ARG;
-    const long long total = (long long)a.B * a.ncg * a.H * a.W;
-    const long long grid = (total + 255) / 256;
-    if (mode == 0) ESR_LAUNCH2(bn_apply_kernel, 0, s2d, grid, a);
-    else if (mode == 1) ESR_LAUNCH2(bn_apply_kernel, 1, s2d, grid, a);
-    else ESR_LAUNCH2(bn_apply_kernel, 2, s2d, grid, a);
+    // pixels per thread: 4 (2 for the three-operand double backward: registers) on planes that fill such blocks, else 1
+    const long long hw = (long long)a.H * a.W;
+    const int u = hw >= 1024 ? (mode == 2 ? 2 : 4) : 1;
+    a.chunks = (int)((hw + 256 * u - 1) / (256 * u));
+    const long long grid = (long long)a.B * a.ncg * a.chunks;
+    if (grid > 0x7FFFFFFFll) return ESR_E_UNSUPPORTED;
+    if (mode == 0) { if (u == 4) ESR_LAUNCH3(bn_apply_kernel, 0, s2d, 4, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 0, s2d, 1, grid, a); }
+    else if (mode == 1) { if (u == 4) ESR_LAUNCH3(bn_apply_kernel, 1, s2d, 4, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 1, s2d, 1, grid, a); }
+    else { if (u == 2) ESR_LAUNCH3(bn_apply_kernel, 2, s2d, 2, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 2, s2d, 1, grid, a); }
     return ESR_OK;
 }
 

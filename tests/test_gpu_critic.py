@@ -110,6 +110,45 @@ def test_backward_and_double_backward_kernels_match_float64_autograd():
     assert rel(K._UnpackOut.apply(gya, 128), gy) < tol and rel(gga, gg) < tol and rel(K._UnpackOut.apply(gdza, 128), gdz) < tol
 
 
+@pytest.mark.parametrize('precision,tol', [('split', 2e-5), ('bf16', 1e-4)])
+def test_first_layer_weight_gradient_runs_the_gathered_tile_form(precision, tol):
+    """The critic's first conv has a 3-channel MAIN input: its weight gradient runs the 27 (tap, channel) columns as one MFMA tile (csrc/esr_bwd.hip,
+    main_as_latk) and the same workgroups own the bias gradient.  Against float64 autograd, as a single launch (partial sums + fold) and inside
+    the batched launch of all layers' gradients (which takes the space-to-depth kernel flavour)."""
+    import torch.nn.functional as F
+    from esr_hip import critic as K
+    netD = make_D()
+    eng = K.CriticEngine(netD, precision)
+    eng.refresh()
+    L0 = eng.layers[0]
+    B, H, W = 5, 40, 72                       # ragged 8 x 32 pixel tiles
+    x, dy = seeded_uniform((B, 3, H, W), 11).cuda() - 0.5, seeded_uniform((B, 64, H, W), 12).cuda() - 0.5
+    xa, dya = K._PackIn.apply(x, eng.planes), K._PackIn.apply(dy, eng.planes)
+    xs, dys = K._UnpackOut.apply(xa, 3).double(), K._UnpackOut.apply(dya, 64).double()          # the operands as stored
+    w = L0.conv.weight.double().detach().requires_grad_(True)
+    F.conv2d(xs, w, None, padding=1).backward(dys)
+    with torch.no_grad():
+        dw, db = eng.conv_wgrad(L0, dya, xa)
+        assert dw.shape == (64, 3, 3, 3) and rel(dw, w.grad) < tol and rel(db, dys.sum((0, 2, 3))) < tol
+    # the batched launch: this layer next to a space-to-depth one (sizes the critic's five stride-2 convs accept)
+    B, H, W = 2, 64, 96
+    x, dy = seeded_uniform((B, 3, H, W), 15).cuda() - 0.5, seeded_uniform((B, 64, H, W), 16).cuda() - 0.5
+    xa, dya = K._PackIn.apply(x, eng.planes), K._PackIn.apply(dy, eng.planes)
+    xs, dys = K._UnpackOut.apply(xa, 3).double(), K._UnpackOut.apply(dya, 64).double()
+    w = L0.conv.weight.double().detach().requires_grad_(True)
+    F.conv2d(xs, w, None, padding=1).backward(dys)
+    bs = K._BufSet(eng, B, 3, H, W, x.device)
+    bs.t0.copy_(xa); bs.dy[0].copy_(dya)
+    z0 = seeded_uniform((B, 256, H // 2, W // 2), 13).cuda() - 0.5
+    dy1 = seeded_uniform((B, 64, H // 2, W // 2), 14).cuda() - 0.5
+    bs.z[0].copy_(K._PackIn.apply(z0, eng.planes)); bs.dy[1].copy_(K._PackIn.apply(dy1, eng.planes))
+    with torch.no_grad():
+        out = K._WgradSet(eng, bs, [(eng.layers[0], bs.dy[0], bs.t0), (eng.layers[1], bs.dy[1], bs.z[0])]).run()
+        assert rel(out[0][0], w.grad) < tol and rel(out[0][1], dys.sum((0, 2, 3))) < tol
+        dw1, _ = eng.conv_wgrad(eng.layers[1], bs.dy[1], bs.z[0])
+        assert rel(out[1][0], dw1) < 1e-6
+
+
 def stock_losses(netD, real, fake, pt, gp_w=10.0):
     pr, pf = netD(real), netD(fake)
     interp = (pt * fake + (1 - pt) * real).requires_grad_(True)

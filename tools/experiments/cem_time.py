@@ -33,5 +33,10 @@ for name, sf, kernel, B, lr_size in (('configs[1] x4 bicubic', 4, None, 32, 128)
             name, td.shape[0], ti.shape[0], m, t(lambda: cem_ops.downscale_raw(g, td, sf, pre, lr=lr, lr_pad=m)), t(lambda: cem_ops.lr_filter_raw(lrp, ti)),
             t(lambda: cem_ops.upscale_raw(lrp, tu, sf, pre, g=g, crop=sf * m, mode=1)),
             t(lambda: cem_ops.project(lr, g, td, ti, tu, sf, pre, lr_pad=m, crop=sf * m))))
+        keep = cem_ops.PROJECT_CHUNK_IMAGES
+        for nb in (0, 16, 8, 4, 2):                       # the projection per chunk of nb images (0: the whole batch at once)
+            cem_ops.PROJECT_CHUNK_IMAGES = nb
+            print('    project(), chunks of %2d images: %.3f ms' % (nb, t(lambda: cem_ops.project(lr, g, td, ti, tu, sf, pre, lr_pad=m, crop=sf * m))))
+        cem_ops.PROJECT_CHUNK_IMAGES = keep
     del g, lr, lrp
     torch.cuda.empty_cache()
