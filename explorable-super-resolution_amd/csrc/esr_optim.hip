@@ -46,6 +46,25 @@ extern "C" int64_t esr_adam_workspace_bytes(const esr_adam_tensor* tensors, int 
     return (int64_t)n * sizeof(esr_adam_tensor) + c * (int64_t)sizeof(AdamChunk);
 }
 
+// the table as it lies in the workspace: [tensors | chunks]
+static int64_t adam_fill(const esr_adam_tensor* tensors, int n, char* host) {
+    memcpy(host, tensors, (size_t)n * sizeof(esr_adam_tensor));
+    AdamChunk* ch = (AdamChunk*)(host + (size_t)n * sizeof(esr_adam_tensor));
+    int64_t k = 0;
+    for (int i = 0; i < n; ++i)
+        for (int64_t j = 0; j * ADAM_CHUNK < tensors[i].n; ++j) ch[k++] = AdamChunk{i, (int32_t)j};
+    return k;
+}
+
+extern "C" int64_t esr_adam_table(const esr_adam_tensor* tensors, int n, void* host_table, int64_t host_bytes) {
+    const int64_t need = esr_adam_workspace_bytes(tensors, n);
+    if (need < 0) return need;
+    if (!host_table || host_bytes < need) return ESR_E_ARG;
+    const int64_t c = adam_nchunks(tensors, n);
+    if (c > 0x7fffffff) return ESR_E_UNSUPPORTED;
+    return c == 0 ? 0 : adam_fill(tensors, n, (char*)host_table);
+}
+
 extern "C" int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream) {
     const int64_t need = esr_adam_workspace_bytes(tensors, n);
     if (need < 0) return need;
@@ -53,14 +72,9 @@ extern "C" int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* 
     const int64_t c = adam_nchunks(tensors, n);
     if (c == 0) return 0;
     if (c > 0x7fffffff) return ESR_E_UNSUPPORTED;
-    // one host staging block: [tensors | chunks]
-    char* host = (char*)malloc((size_t)need);
+    char* host = (char*)malloc((size_t)need);          // one host staging block
     if (!host) return ESR_E_ARG;
-    memcpy(host, tensors, (size_t)n * sizeof(esr_adam_tensor));
-    AdamChunk* ch = (AdamChunk*)(host + (size_t)n * sizeof(esr_adam_tensor));
-    int64_t k = 0;
-    for (int i = 0; i < n; ++i)
-        for (int64_t j = 0; j * ADAM_CHUNK < tensors[i].n; ++j) ch[k++] = AdamChunk{i, (int32_t)j};
+    adam_fill(tensors, n, host);
     hipError_t e = hipMemcpyAsync(workspace, host, (size_t)need, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);      // the staging block is freed on return
     free(host);

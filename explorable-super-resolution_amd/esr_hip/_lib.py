@@ -149,6 +149,7 @@ _SIGS = {
     'esr_bn_param_grads': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'esr_adam_workspace_bytes': (C.c_int64, [C.POINTER(AdamTensor), C.c_int]),
     'esr_adam_upload': (C.c_int64, [C.POINTER(AdamTensor), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'esr_adam_table': (C.c_int64, [C.POINTER(AdamTensor), C.c_int, C.c_void_p, C.c_int64]),
     'esr_adam_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'esr_run': (C.c_int, [C.POINTER(Cmd), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     'esr_cmd_bytes': (C.c_int64, []),

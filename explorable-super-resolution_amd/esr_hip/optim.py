@@ -15,7 +15,8 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError('invalid Adam hyper-parameters')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._tables = {}           # group index -> (pointer fingerprint, workspace tensor, n tensors, n chunks)
+        self._tables = {}           # group index -> {pointer fingerprint: (fingerprint, workspace tensor, n tensors, n chunks, pinned staging block)}
+        self.table_uploads = 0      # (diagnostic: how often a table had to be built and copied)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -52,18 +53,31 @@ class Adam(torch.optim.Optimizer):
             t = float(first) + 1
             # everything the uploaded table points at: parameters, gradients AND both moment tensors (load_state_dict replaces the latter)
             fp = tuple((p.data_ptr(), g.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p, g in zip(ps, grads))
-            tab = self._tables.get(gi)
-            if tab is None or tab[0] != fp:
+            # a few tables per group, keyed by the pointer fingerprint: gradient storages typically alternate between two or three addresses
+            # (the allocator hands back the blocks of the step before last), and a table that is still on the device costs nothing
+            cache = self._tables.setdefault(gi, {})
+            tab = cache.get(fp)
+            if tab is None:
                 arr = (_lib.AdamTensor * len(ps))()
                 for a, p, g in zip(arr, ps, grads):
                     st = self.state[p]
                     a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
                 need = _lib.lib.esr_adam_workspace_bytes(arr, len(ps))
                 _lib.check(min(need, 0), 'esr_adam_workspace_bytes')
-                ws = tab[1] if (tab is not None and tab[1].numel() >= need) else torch.empty(int(need), dtype=torch.uint8, device=ps[0].device)
-                nchunks = _lib.lib.esr_adam_upload(arr, len(ps), ws.data_ptr(), ws.numel(), stream_ptr())
-                _lib.check(min(nchunks, 0), 'esr_adam_upload')
-                tab = self._tables[gi] = (fp, ws, len(ps), int(nchunks))
+                if len(cache) >= 4:
+                    cache.pop(next(iter(cache)))          # (oldest entry; its workspace is freed stream-ordered by the caching allocator)
+                ws = torch.empty(int(need), dtype=torch.uint8, device=ps[0].device)
+                # the table goes through PINNED host memory and an asynchronous copy on the step's stream: gradient tensors are new storages
+                # every step more often than not (autograd hands over the buffers the backward pass produced), and a blocking upload here
+                # stalled the host until the whole backward pass had run — the next step's launches then started from an idle GPU
+                # (configs[2] step: ~1.5 ms of gaps behind the two Adam launches).  The pinned block stays referenced by the table entry;
+                # torch's pinned-memory allocator does not recycle it before the copy has executed.
+                pin = torch.empty(int(need), dtype=torch.uint8, pin_memory=True)
+                nchunks = _lib.lib.esr_adam_table(arr, len(ps), pin.data_ptr(), pin.numel())
+                _lib.check(min(nchunks, 0), 'esr_adam_table')
+                ws[:int(need)].copy_(pin, non_blocking=True)
+                tab = cache[fp] = (fp, ws, len(ps), int(nchunks), pin)
+                self.table_uploads += 1
             b1, b2 = group['betas']
             _lib.check(_lib.lib.esr_adam_run(tab[1].data_ptr(), tab[2], tab[3], float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
                                              1 - b1 ** t, math.sqrt(1 - b2 ** t), stream_ptr()), 'esr_adam_run')

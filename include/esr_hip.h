@@ -314,10 +314,14 @@ int esr_soft_hist_bwd(const float* v, int64_t n, int K, float lo, float hi, floa
  *     p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps)
  * with bias_correction1 = 1 - beta1^t and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller for step t.
  * `tensors` is a HOST array; _upload writes it (plus a work table) into caller-owned device `workspace` (>= _workspace_bytes), blocks until
- * the copy is done and returns the chunk count to pass to _run (>= 0) or ESR_E_*; it is repeated only when a pointer changes. */
+ * the copy is done and returns the chunk count to pass to _run (>= 0) or ESR_E_*; it is repeated only when a pointer changes.
+ * esr_adam_table writes the same table into caller-owned HOST memory instead (>= _workspace_bytes; e.g. a pinned buffer) and returns the
+ * chunk count: a caller whose gradient tensors move from step to step copies it to the device workspace itself, asynchronously on its
+ * stream — no host synchronisation (the training loop of codes/train.py:90-192 has none between optimizer steps either). */
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } esr_adam_tensor;
 int64_t esr_adam_workspace_bytes(const esr_adam_tensor* tensors, int n);
 int64_t esr_adam_upload(const esr_adam_tensor* tensors, int n, void* workspace, int64_t workspace_bytes, esr_stream_t stream);
+int64_t esr_adam_table(const esr_adam_tensor* tensors, int n, void* host_table, int64_t host_bytes);
 int esr_adam_run(const void* workspace, int n, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float bias_correction1, float bias_correction2_sqrt, esr_stream_t stream);
 

@@ -167,3 +167,29 @@ def test_mask_stash_gives_the_same_input_gradient_with_a_third_of_the_memory(pre
     # a parameter that wants a gradient switches the forward back to keeping everything
     next(net.parameters()).requires_grad_(True)
     assert eng.keep_mode() is True
+
+
+@pytest.mark.parametrize('precision', ['split', 'bf16', 'mixed'])
+def test_small_launch_output_slices_are_bit_identical_to_the_64_channel_form(precision):
+    """A 64-channel conv of a small launch (no more tiles than CUs) runs as two 32-channel output slices of the 32-channel kernel out of the same
+    weight pack (esr_conv3x3, csrc/esr_conv.hip: two workgroups per CU instead of one): same products, same order per output channel, so the
+    forward, the input gradient and every weight gradient must not change by a bit against the unsliced form (esr_conv3x3_desc.lds_stages = 2
+    keeps every launch in its 64-channel two-stage form).  Covers the RDB's closing conv (residual from the staged tile), the RRDB's (second
+    residual), the trunk / HR convs and the mirrored data gradients (LeakyReLU masks)."""
+    from esr_hip import act as A
+
+    def run(stages):
+        keep = A.LDS_STAGES
+        A.LDS_STAGES = stages
+        try:
+            net = make_net(nb=2, precision=precision)
+            x = inputs(3, 3, 4, 24, 20, 77).requires_grad_(True)
+            y = net(x)
+            (y * seeded_uniform(tuple(y.shape), 78).cuda()).sum().backward()
+            return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]
+        finally:
+            A.LDS_STAGES = keep
+    y0, dx0, dw0 = run(2)
+    y1, dx1, dw1 = run(0)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))

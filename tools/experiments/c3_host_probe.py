@@ -20,7 +20,7 @@ data = {'LR': torch.rand(32, 3, 52, 52, generator=g).cuda(), 'HR': torch.rand(32
         'Z': (torch.rand(32, 3, 208, 208, generator=g) * 2 - 1).cuda()}
 uploads = {'adam': 0, 'wgrad': 0, 'pack': 0}
 lib = _lib.lib
-for name, key in (('esr_adam_upload', 'adam'), ('esr_conv3x3_wgrad_batch_upload', 'wgrad'), ('esr_pack_batch_upload', 'pack')):
+for name, key in (('esr_adam_table', 'adam'), ('esr_conv3x3_wgrad_batch_upload', 'wgrad'), ('esr_pack_batch_upload', 'pack')):
     f = getattr(lib, name)
     def wrap(*a, _f=f, _k=key):
         uploads[_k] += 1

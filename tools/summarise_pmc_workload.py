@@ -21,7 +21,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    return re.sub(r'\(.*$', '', name).strip()
+    """kernel name without its namespace and argument list (template arguments kept)"""
+    n = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            return n[:i].strip()
+    return n.strip()
 
 
 def main():
