@@ -17,8 +17,12 @@ def _prep(x, what):
 
 
 USE_SEPARABLE = True          # module attribute: the tests compare the separable kernels with the 2-D ones by clearing it
-# project(): batches whose generator output exceeds PROJECT_CHUNK_BYTES run the three kernels per chunk of this many images (0: never)
-PROJECT_CHUNK_IMAGES = 8
+# project(): batches whose generator output exceeds PROJECT_CHUNK_BYTES run the three kernels per chunk of this many images (0: never).
+# OFF by default — measured on MI355X at configs[1] (tools/experiments/cem_time.py, profiles/r04_cem_chunk{0,8}_pmc.json): the whole batch
+# 0.225 ms, chunks of 16 / 8 / 4 images 0.267 / 0.283 / 0.370 ms, and the counters see the same 0.64 GB per projection either way (FETCH_SIZE
+# counts L2 misses; what the Infinity Cache absorbs is invisible to it) — four times the launches of kernels that are 30-100 us each cost more
+# than the second reading of `g` from HBM.  Kept as a switch (results are bit-identical, tests/test_gpu_parity.py).
+PROJECT_CHUNK_IMAGES = 0
 PROJECT_CHUNK_BYTES = 64 << 20
 
 

@@ -83,9 +83,11 @@ class SRRaGANModel(BaseModel):
             if self.latent_input is not None and train_opt['optimalZ_loss_type'] is not None and train_opt['optimalZ_loss_weight'] is not None:
                 self.optimalZ_loss_type = train_opt['optimalZ_loss_type']
             self.D_verification = train_opt['D_verification']
-            if self.D_verification not in ['current', 'past', None]:
-                raise NotImplementedError("train.D_verification = %r: 'current', 'past' or null" % (self.D_verification,))
+            if self.D_verification not in ['current', 'convergence', 'past', None]:
+                raise ValueError("train.D_verification = %r: 'current', 'convergence', 'past' or null" % (self.D_verification,))
             self.D_verified = self.verified_D_saved = self.D_verification is None
+            if self.D_verification == 'convergence':
+                self.D_converged = False
             net_D = opt['network_D'] or {}
             self.relativistic_D = net_D.get('relativistic') is None or bool(net_D.get('relativistic'))
             self.add_quantization_noise = bool(net_D.get('add_quantization_noise'))
@@ -431,6 +433,27 @@ class SRRaGANModel(BaseModel):
                     self.generator_step = len(log['D_logits_diff']) >= n and \
                         all(v[1] > np.log(train_opt['min_D_prob_ratio_4_G']) for v in log['D_logits_diff'][-n:]) and \
                         all(v[1] > train_opt['min_mean_D_correct'] for v in log['Correctly_distinguished'][-n:])
+                if first_acc_D and first_dual and self.generator_step and self.D_verification == 'convergence':
+                    # G waits until the critic's losses have levelled out (reference :383-393): a line is fitted to the logged l_d_real / l_d_fake of the
+                    # last steps_4_loss_std steps; converged once lr_change_ratio * |slope| (at least 1e-5) is below the residual's standard
+                    # deviation.  A host read of the log, as in the reference; under data parallelism the ranks' logs hold their own shards'
+                    # losses, so the decision is made global (all ranks converged) before anybody acts on it.
+                    if not self.D_converged and self.gradient_step_num >= train_opt['steps_4_D_convergence']:
+                        log = self.log_dict
+                        std = slope = 0.0
+                        fit_ok = True
+                        for key in ('l_d_real', 'l_d_fake'):
+                            vals = [v[1] for v in log[key] if v[0] >= self.gradient_step_num - train_opt['steps_4_loss_std']]
+                            if len(vals) < 4:                   # numpy needs more points than parameters + 2 for the covariance
+                                fit_ok = False
+                                break
+                            (cur_slope, _), ((cur_var, _), _) = np.polyfit(np.arange(len(vals)), vals, 1, cov=True)
+                            std += 0.5 * np.sqrt(cur_var)
+                            slope += 0.5 * cur_slope
+                        conv = bool(fit_ok and -train_opt['lr_change_ratio'] * np.minimum(-1e-5, slope) < std)
+                        flags = esr_dist.gather_scalars(torch.tensor([1.0 if conv else 0.0], device=self.device))
+                        self.D_converged = bool(flags.min().item() > 0.5)
+                    self.generator_step = bool(self.D_converged)
                 if self.D_verification == 'current' and self.generator_step:
                     # a host read, as in the reference: this mode gates G on the current batch — the GLOBAL batch under data parallelism (all
                     # ranks must take the same decision: the generator's all-reduce is only entered by ranks that do a G step)
