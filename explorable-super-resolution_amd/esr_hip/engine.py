@@ -39,7 +39,6 @@ class RRDBEngine:
         self._packed_t = None
         self._packed_rdb_t = None
         self._bufs = {}
-        self._lane_streams = {}
         self._gpool, self._gpool_key = {}, None
         self._pack_batch = A.PackBatch()
         self._packs_fp = None
@@ -241,11 +240,11 @@ class RRDBEngine:
         return self._packed_rdb_t
 
     # ------------------------------------------------------------------ buffers
-    def _buffers(self, B, h, w, dev, keep, lane=0):
+    def _buffers(self, B, h, w, dev, keep):
         """Activation buffers, cached per shape (their zero borders are written once).  A differentiable forward (keep=True) LEASES
         its set until the autograd node that saved it is gone: a second differentiable forward in the meantime (two generator
         calls before one backward) gets a fresh, uncached set instead of overwriting saved activations."""
-        key = (B, h, w, str(dev), lane, keep)
+        key = (B, h, w, str(dev), keep)
         cached = self._bufs.get(key)
         if cached is not None:
             busy = cached.get('_busy')
@@ -254,7 +253,7 @@ class RRDBEngine:
             fresh = self._new_buffers(B, h, w, dev, keep)
             fresh['_ephemeral'] = True        # lives for one pass: not worth recording a launch list for
             return self._lease(fresh)
-        if len(self._bufs) > 3:
+        if len(self._bufs) > 2:
             self._bufs.clear()
         d = self._new_buffers(B, h, w, dev, keep)
         self._bufs[key] = d
@@ -324,63 +323,9 @@ class RRDBEngine:
         packs = self._pack_gen[0] if kind == 'fwd' else tuple(self._pack_gen)
         return (kind,) + what + (self.split, self._ptr_epoch, packs)
 
-    # Inference batches are run as SUB-BATCHES alternating over TWO streams (images are independent; each lane has its own activation buffers
-    # and launch list): a conv launch of N tiles over 512 workgroup slots ends in a partly empty last round (configs[1]: 1920 tiles = 3.75
-    # rounds, 6 % of every launch), and two lanes fill each other's ramps and tails.  Measured on the configs[1] forward (DESIGN 5.10,
-    # tools/experiments/substream_ab.py): whole batch 68.6-68.8 ms, 2 x 16 images 67.1-67.8, 4 x 8 images round-robin 66.6-67.3 (-2.3 %), three
-    # or four lanes 69.5-69.8, sub-batches of 4 (launches of < 320 tiles: the one-workgroup-per-CU form) worse.  Same kernels per image: results are
-    # bit-identical to the whole-batch pass.  (images per sub-batch, lanes); None: never.  Sub-batches must keep their launches in the
-    # two-workgroups-per-CU regime: LANE_MIN_PIXELS LR pixels per sub-batch (8 x 148^2 = 175 k at configs[1]).
-    LANES = (8, 2)
-    LANE_MIN_PIXELS = 160000
-
-    def _lane_plan(self, x, pad, keep):
-        if keep or self.LANES is None or not self.use_plans or A._rec() is not None or torch.cuda.is_current_stream_capturing():
-            return None
-        sub, n = self.LANES
-        B, h, w = x.shape[0], x.shape[2] + 2 * pad, x.shape[3] + 2 * pad
-        if B < 2 * sub or B % sub or sub * h * w < self.LANE_MIN_PIXELS:
-            return None
-        return sub, n
-
-    def run_forward(self, x, pad=0, keep=False):
-        """Returns (g, bufs).  keep=True keeps one buffer per RDB so that `bufs` holds every activation the backward needs (bufs is None for an
-        inference pass that ran as sub-batches on two streams)."""
-        lanes = self._lane_plan(x, pad, keep)
-        if lanes is None:
-            return self._run_forward_one(x, pad, keep)
-        sub, n = lanes
-        net = self.net
-        x = x.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
-        sf = self._check(x)[0]
-        B, Ct, h0, w0 = x.shape
-        self.packed()                         # weight packs refreshed on the caller's stream, before the lanes fork from it
-        g = torch.empty(B, net.out_nc, sf * (h0 + 2 * pad), sf * (w0 + 2 * pad), dtype=torch.float32, device=x.device)
-        cur = torch.cuda.current_stream(x.device)
-        streams = self._lane_streams.get(str(x.device))
-        if streams is None or len(streams) < n:
-            streams = self._lane_streams[str(x.device)] = [torch.cuda.Stream(device=x.device) for _ in range(n)]
-        ev, self._ev = self._ev, None          # (bench.py's bracket of the generator: around the fork and the join instead of inside a lane)
-        try:
-            if ev:
-                ev[0].record(cur)
-            for s in streams[:n]:
-                s.wait_stream(cur)
-            for j, i in enumerate(range(0, B, sub)):
-                with torch.cuda.stream(streams[j % n]):
-                    self._run_forward_one(x[i:i + sub], pad, False, lane=1 + j % n, out=g[i:i + sub])
-            for s in streams[:n]:
-                cur.wait_stream(s)                # x, g and the packs were allocated on `cur`: nothing of them is released before this join
-            if ev:
-                ev[1].record(cur)
-        finally:
-            self._ev = ev
-        return g, None
-
     @A.one_stream
-    def _run_forward_one(self, x, pad=0, keep=False, lane=0, out=None):
+    def run_forward(self, x, pad=0, keep=False):
+        """Returns (g, bufs).  keep=True keeps one buffer per RDB so that `bufs` holds every activation the backward needs."""
         net = self.net
         x = x.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -388,8 +333,8 @@ class RRDBEngine:
         sf, has_lat, lat1 = self._check(x)
         B, Ct, h0, w0 = x.shape
         self.packed()                         # weight packs refreshed here, outside any recording: replays assume current packs
-        bufs = self._buffers(B, h0 + 2 * pad, w0 + 2 * pad, x.device, keep, lane)
-        g = out if out is not None else torch.empty(B, net.out_nc, sf * (h0 + 2 * pad), sf * (w0 + 2 * pad), dtype=torch.float32, device=x.device)
+        bufs = self._buffers(B, h0 + 2 * pad, w0 + 2 * pad, x.device, keep)
+        g = torch.empty(B, net.out_nc, sf * (h0 + 2 * pad), sf * (w0 + 2 * pad), dtype=torch.float32, device=x.device)
         if not self.use_plans or bufs.get('_ephemeral') or A._rec() is not None:
             self._forward_launches(x, pad, keep, bufs, g)
             return g, bufs
