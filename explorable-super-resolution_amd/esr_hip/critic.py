@@ -24,7 +24,7 @@ from . import act as A
 from ._lib import ActView, BnDesc, EsrError, check
 
 SLOPE = 0.2
-_state = {'input_grad_only': 0, 'group': None}
+_state = {'input_grad_only': 0, 'group': None, 'only': None}
 
 
 class input_grad_only:
@@ -32,18 +32,27 @@ class input_grad_only:
     tell the conv nodes that the weight gradients it would also hand back are not wanted by torch.autograd.grad(inputs=[interp])).
     group = g: the cotangent that enters a critic_forward_group() graph inside is non-zero for the g-th input only (the penalty
     differentiates the interpolated batch's logits alone) — the backward pass, and later the backward of that backward pass, then run on
-    that input's images only.  A promise the caller makes: rows of the other inputs are not looked at."""
+    that input's images only.  A promise the caller makes: rows of the other inputs are not looked at.
+    of = a logits tensor returned by critic_forward / critic_forward_group: the hints then apply to THAT call's graph only — any other critic
+    graph differentiated inside the context (another model's critic, a second call) computes everything it is asked for."""
 
-    def __init__(self, group=None):
-        self.group = group
+    def __init__(self, group=None, of=None):
+        self.group, self.only = group, getattr(of, '_esr_critic_state', None)
 
     def __enter__(self):
         _state['input_grad_only'] += 1
-        self.prev, _state['group'] = _state['group'], self.group
+        self.prev, _state['group'], _state['only'] = (_state['group'], _state['only']), self.group, self.only
 
     def __exit__(self, *exc):
         _state['input_grad_only'] -= 1
-        _state['group'] = self.prev
+        _state['group'], _state['only'] = self.prev
+
+
+def _hints_for(S):
+    """(input gradients only?, group) as they apply to the forward call whose state is S"""
+    if not _state['input_grad_only'] or (_state['only'] is not None and _state['only'] is not S):
+        return False, None
+    return True, _state['group']
 
 
 
@@ -973,8 +982,9 @@ class _CriticFwd(torch.autograd.Function):
         params = [next(it) if m else None for m in ctx.pmask]
         ys = saved[nreal:]
         want_dx = ctx.needs_input_grad[3]
-        want_params = any(ctx.needs_input_grad[4:]) and not _state['input_grad_only']
-        group = _state['group'] if ctx.S.bs.groups > 1 else None
+        igo, hint_group = _hints_for(ctx.S)
+        want_params = any(ctx.needs_input_grad[4:]) and not igo
+        group = hint_group if ctx.S.bs.groups > 1 else None
         outs = _CriticBwd.apply(ctx.eng, ctx.S, want_dx, want_params, group, d_feat, len(ys), *g_ys, *ys, *params)
         dx, pgrads = outs[0], outs[1:]
         return (None, None, None, dx if want_dx else None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + k]) else None for k, g in enumerate(pgrads))
@@ -1008,7 +1018,7 @@ class _CriticBwd(torch.autograd.Function):
         n, nf = ctx.n, _CriticBwd.NFIXED
         if u is None:
             return (None,) * (nf + 2 * n + ctx.nparams)
-        want_params = any(ctx.needs_input_grad[nf + 2 * n:]) and not _state['input_grad_only']
+        want_params = any(ctx.needs_input_grad[nf + 2 * n:]) and not _hints_for(ctx.S)[0]
         g_dfeat, g_ys, conv2, g_gammas = _bwd2_pass(ctx.eng, ctx.S, u, want_params, ctx.group)
         pg = []
         for i, L in enumerate(ctx.eng.layers):
@@ -1050,4 +1060,8 @@ def critic_forward_group(eng, xs):
     outs = _CriticFwd.apply(eng, net.training, len(xs), x, *_param_list(eng))
     feat = outs[0]
     logits = net.classifier(feat.reshape(feat.size(0), -1))
-    return [logits] if len(xs) == 1 else list(logits.chunk(len(xs)))
+    res = [logits] if len(xs) == 1 else list(logits.chunk(len(xs)))
+    S = getattr(feat.grad_fn, 'S', None)              # the call's state (ctx of _CriticFwd): lets input_grad_only(of=logits) address this graph alone
+    for t in res:
+        t._esr_critic_state = S
+    return res

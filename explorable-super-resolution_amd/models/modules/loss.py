@@ -74,7 +74,7 @@ class GradientPenaltyLoss(nn.Module):
         """critic_group: `interp_crit` is the critic_group-th output of a grouped critic call (esr_hip.critic.critic_forward_group): the
         penalty's first backward then runs on that batch's images only."""
         from esr_hip.critic import input_grad_only
-        with input_grad_only(group=critic_group):       # (hints to the HIP critic's nodes; stock modules ignore them)
+        with input_grad_only(group=critic_group, of=interp_crit):       # (hints to the HIP critic's nodes of THIS call; stock modules ignore them)
             grad_interp = torch.autograd.grad(outputs=interp_crit, inputs=interp, grad_outputs=torch.ones_like(interp_crit),
                                               create_graph=True, retain_graph=True, only_inputs=True)[0]
         norms = grad_interp.reshape(grad_interp.size(0), -1).norm(2, dim=1)
