@@ -351,6 +351,11 @@ __device__ __forceinline__ void glds16w(const uint4* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
 }
 
+// the same copy, source = wave-uniform base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit per-lane address arithmetic
+__device__ __forceinline__ void glds16ws(const uint4* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // LDS planes are sized so that consecutive channel groups start 64 bytes apart modulo 256: the four 64-byte runs a half-wave
 // touches in one ds_read_b64_tr_b16 (2 groups x 4 pixels, for two 16-lane groups) then fall into four different 16-bank windows
 constexpr int XP = (WG_TH + 2) * (WG_TW + 2);        // 340 haloed x pixels per plane; 340 % 16 == 4
@@ -470,6 +475,74 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
         }                                                                                                                        \
     } while (0)
 
+    // The same copies for the common case (no upsampled source): a slot's offsets inside the tile are tile-independent — computed ONCE per
+    // workgroup (relative offset + row / column inside the haloed tile) — so that a tile costs per slot two compares against the tile's distance
+    // to the image edge, one add and one select, and the copy takes a uniform base + a 32-bit lane offset.  (The general macro above spends
+    // ~12 VALU per slot and a 64-bit add per plane: 4.8 VALU per MFMA in this kernel's counters, profiles/r04_wgrad_pmc.json.)
+    const bool fast_issue = NPL == 1 && a.ups == 1;      // (one-plane operands: the hi+lo kernels sit at the 256-register limit and would spill)
+    // only the LAST tile column / row of an image can be partial: per slot two precomputed bits — "inside the image when the tile is in the last
+    // column" / "... last row" — packed into one register (slot j: bits 2j, 2j + 1; X slots first, then the dY slots)
+    int xrel[XSLOTS], yrel[YSLOTS];
+    unsigned vbits = 0;
+    {
+        const int x_last = (a.tiles_x - 1) * TW, y_last = (a.tiles_y - 1) * TH;
+#pragma unroll
+        for (int sl = 0; sl < XSLOTS; ++sl) {
+            const int p = sl * 64 + lane;
+            const int rr = p / (TW + 2), cc = p - rr * (TW + 2);
+            xrel[sl] = rr * a.Wx_p + cc;
+            if (x_last + cc < a.W + 2) vbits |= 1u << (2 * sl);
+            if (y_last + rr < a.H + 2) vbits |= 2u << (2 * sl);
+        }
+#pragma unroll
+        for (int sl = 0; sl < YSLOTS; ++sl) {
+            const int p = sl * 64 + lane;
+            const int rr = p >> LGW, cc = p & (TW - 1);
+            yrel[sl] = rr * (a.W + 2) + cc;
+            if (x_last + cc < a.W) vbits |= 1u << (2 * (XSLOTS + sl));
+            if (y_last + rr < a.H) vbits |= 2u << (2 * (XSLOTS + sl));
+        }
+    }
+    static_assert(2 * (XSLOTS + YSLOTS) <= 32, "validity bits of all slots in one register");
+    auto issue_fast = [&](const int tile_, const unsigned st_) {
+        const int tx_ = tile_ % a.tiles_x;
+        const int r1_ = tile_ / a.tiles_x;
+        const int ty_ = r1_ % a.tiles_y;
+        const int b_ = r1_ / a.tiles_y;
+        const int x0_ = tx_ * TW, y0_ = ty_ * TH;
+        // (uniform) a tile that is not in the last column / row is whole: its bits are forced on; an operand group that does not exist reads
+        // the zero border vector for every slot
+        unsigned um = (tx_ == a.tiles_x - 1 ? 0u : 0x55555555u) | (ty_ == a.tiles_y - 1 ? 0u : 0xAAAAAAAAu);
+        unsigned keep = 0xFFFFFFFFu;
+        if (!xhave) keep &= ~((1u << (2 * XSLOTS)) - 1u);
+        if (!yhave) keep &= (1u << (2 * XSLOTS)) - 1u;
+        const unsigned m = (vbits | um) & keep;
+        const uint4* const xh_ = xv.hi + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs;
+        const uint4* const xl_ = NPL == 2 ? xv.lo + b_ * xv.bs + (xhave ? xcg : 0) * xv.cs : nullptr;
+        const unsigned xd_ = st_ + wave * XP * 16;
+        const int xb_ = y0_ * a.Wx_p + x0_;
+#pragma unroll
+        for (int sl = 0; sl < XSLOTS; ++sl) {
+            if (LATK && NST == 1 && wave > 0) break;
+            const unsigned vo = ((m >> (2 * sl)) & 3u) == 3u ? (unsigned)(xrel[sl] + xb_) * 16u : 0u;
+            if (sl * 64 + lane < XPS) {
+                glds16ws(xh_, vo, xd_ + sl * 1024);
+                if (NPL == 2) glds16ws(xl_, vo, xd_ + WG_X_BYTES + sl * 1024);
+            }
+        }
+        const uint4* const yh_ = a.dy.hi + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs;
+        const uint4* const yl_ = NPL == 2 ? a.dy.lo + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs : nullptr;
+        const unsigned yd_ = st_ + NPL * WG_X_BYTES + wave * YPP * 16;
+        const int yb_ = (y0_ + 1) * (a.W + 2) + x0_ + 1;
+#pragma unroll
+        for (int sl = 0; sl < YSLOTS; ++sl) {
+            const unsigned vo = ((m >> (2 * (XSLOTS + sl))) & 3u) == 3u ? (unsigned)(yrel[sl] + yb_) * 16u : 0u;
+            glds16ws(yh_, vo, yd_ + sl * 1024);
+            if (NPL == 2) glds16ws(yl_, vo, yd_ + WG_Y_BYTES + sl * 1024);
+        }
+    };
+#define ESR_WG_ISSUE2(TILE, ST) do { if (fast_issue) issue_fast((TILE), (ST)); else ESR_WG_ISSUE((TILE), (ST)); } while (0)
+
     // NST == 2: two LDS stages, the next tile's copies in flight under the MFMAs, one workgroup per CU.
     // NST == 1: one stage, two workgroups per CU cover each other's DMA waits (same trade as the conv kernel; selected by the host).
     int tile = slice;
@@ -482,17 +555,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #else
 #define ESR_WTR() do { } while (0)
 #endif
-    if (NST == 2 && tile < ntiles) ESR_WG_ISSUE(tile, lds0);
+    if (NST == 2 && tile < ntiles) ESR_WG_ISSUE2(tile, lds0);
     for (; tile < ntiles; tile += a.nslices) {
         const int nxt = tile + a.nslices;
         ESR_WTR();
         if (NST == 1) {
-            ESR_WG_ISSUE(tile, lds0);
+            ESR_WG_ISSUE2(tile, lds0);
             ESR_WTR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ESR_WTR();
         } else if (nxt < ntiles) {
-            ESR_WG_ISSUE(nxt, lds0 + (cur ^ 1) * STAGE);
+            ESR_WG_ISSUE2(nxt, lds0 + (cur ^ 1) * STAGE);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NY) : "memory");     // everything but the copies just issued
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -645,6 +718,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 }
 
 #undef ESR_WG_ISSUE
+#undef ESR_WG_ISSUE2
 #undef ESR_WTR
 
 // s2d (WgradArgs.tapmode == 1): the layer is a stride-2 conv run as a 3x3 conv over the space-to-depth input (esr_hip/critic.py): main input
