@@ -231,6 +231,8 @@ def parse_args(argv=None):
                     help="c2 default 'split' (headline): bf16 hi+lo operands in every product; 'mixed': fp16 one-MFMA dense blocks, reported in the "
                          "alt_precision block.  c3 default 'bf16' (configs[2] names bf16)")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
+    ap.add_argument('--no-extra-workloads', action='store_true',
+                    help="skip the short configs[2] / configs[4] runs appended (after the headline's timed region) as `extra_workloads`")
     return ap.parse_args(argv)
 
 
@@ -319,6 +321,8 @@ def main(argv=None):
         out = run_c5(args, dev, rank, world, dist, sync, max_over_ranks)
     else:
         out = run_c2(args, dev, rank, world, dist, sync, max_over_ranks)
+        if world == 1 and args.batch == BATCH and not args.no_extra_workloads:
+            out['extra_workloads'] = extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks)
     infos = rank_info()
     if rank == 0:
         out['ranks'] = infos
@@ -449,6 +453,33 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
         out['alt_precision'] = alt
         net.set_precision(precision)
     return out
+
+
+def extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks):
+    """Single-GPU default run only, AFTER the headline's timed region and its alt-precision / CPU-baseline legs: a short run (3 warm-up + 5
+    steps) of configs[2] (`--workload c3`: G+D training step at the per-GPU shape, bf16) and of configs[4] (`--workload c5`: x8 inference, f16,
+    blurry_cubic_2.0 CEM kernel), each through the same function its own `--workload` run uses — so the line the driver records carries
+    driver-observed numbers for the configs the headline does not time.  Nothing here touches a headline key; a failure is recorded as
+    {'error': ...} for that block instead of costing the line."""
+    import copy
+    import gc
+    import torch
+    res = {}
+    for name, fn in (('c3', run_c3), ('c5', run_c5)):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.precision = name, 5, 3, None
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            r = fn(a, dev, rank, world, dist, sync, max_over_ranks)
+            r = {k: r[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'phases_ms', 'roofline',
+                                   'cem_consistency_rmse_interior', 'peak_memory_GB') if k in r} | {'workload': r['config']['workload']}
+        except Exception as e:                      # noqa: BLE001 — the headline line must survive whatever an appended block does
+            r = {'error': '%s: %s' % (type(e).__name__, e)}
+        r['wall_s'] = time.perf_counter() - t0
+        res[name] = r
+    return res
 
 
 def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
