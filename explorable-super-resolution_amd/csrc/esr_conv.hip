@@ -64,31 +64,41 @@ constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 =
 // residual 1 is a channel-group slice of the conv's own input (RDB conv5: out = 0.2*conv + x, block.py:235): it is added to the
 // accumulators from the LDS copy the K loop stages anyway, so the epilogue has no residual loads at all
 constexpr int EPI_RESIN = 32;
+// pixel-shuffle store (esr_conv3x3_desc.pixel_shuffle): its own instantiations, so that the plain store carries none of its index arithmetic
+constexpr int EPI_PS = 64;
 
 struct ConvArgs {
+    // ---- what the prologue decodes before it can issue the first copy (one kernarg batch): the tile space, the tile geometry and the
+    // divisions by launch constants turned into multiplications on the host (esr_conv3x3: magic numbers, the waves' copy shares)
+    int tiles_x, tiles_y, ntiles, per_xcd;      // per_xcd = ceil(ntiles / 8): tiles swept by one XCD
+    unsigned m_tx, m_ty;            // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)   (unused when the divisor is 1)
+    int TH, TW, P, NPIX_T, NPIX_L, nslots;      // NPIX_L is a multiple of 64: whole 1-KiB copy slots, nslots of them per plane
+    unsigned m_P, m_ups;            // ceil(2^20 / P), ceil(2^16 / ups)
+    int H, W, Win_p, ups;           // output interior; padded input row pitch (W_in + 2); input upsample factor
+    unsigned share[NW];             // per wave: activation slots | first weight fragment << 8 | weight fragments << 16 (dma_share)
+    int ncp, lo_chunks, reverse, B; // chunks [0, lo_chunks) carry a lo activation plane, later ones are hi-only (PARTLO kernels); reverse: walk the tile space backwards (cache-reuse hint)
     DView in0, in1;
-    int ups, Win_p;                 // input upsample factor; padded input row pitch (W_in + 2)
     const uint4* wpack;
-    const float* bias;
-    int cout, B, H, W;              // output channels, batch, output interior
-    int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y, ncp;
+    // where chunk cp's / tap t's fragments sit in the pack: normally 9 * MT * NPW and MT * NPW fragments apart.  A 64-channel layer of a SMALL
+    // launch is run as two 32-channel slices by the MT = 1 kernel out of the same [chunk][tap][M tile][plane] pack: slice s starts s * NPW
+    // fragments in and its taps are 2 * NPW fragments apart
+    long long wchunk;               // 16-byte vectors between the fragments of consecutive chunks
+    long long wslice;               // 16-byte vectors between the weight fragments of consecutive output slices (0: no slices)
+    int wtap;                       // fragments between consecutive taps
+    int nslices;                    // output slices of this launch (blockIdx.y): cout / 64 when cout > 64; 2 for a 64-channel layer run as two 32-channel halves
+    // ---- epilogue
+    const float* zero_bias;
+    int bias_stride;                // 1, or 0 when `bias` is the zero block (output slices step through a real bias only)
+    const float* bias;              // never NULL in the kernel: a launch without a bias points at the library's zero block (zero_bias())
+    int cout, ncg_out;              // output channels of one slice, and their groups
     float act_slope, alpha, beta1, beta2;
     DView res1, res2, out, out2, mask;
     float* out_nchw;
     int mask_cg0, mask_cg1;
     float mask_slope;
-    int reverse;                    // walk the tile space backwards (cache-reuse hint)
-    int lo_chunks;                  // chunks [0, lo_chunks) carry a lo activation plane, later ones are hi-only (PARTLO kernels)
     int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
     float resin_scale;              // beta1 / alpha
     int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
-    int nslices;                    // output slices of this launch (blockIdx.y): cout / 64 when cout > 64; 2 for a 64-channel layer run as two 32-channel halves
-    long long wslice;               // 16-byte vectors between the weight fragments of consecutive output slices (0: no slices)
-    // where chunk cp's / tap t's fragments sit in the pack: normally 9 * MT * NPW and MT * NPW fragments apart.  A 64-channel layer of a SMALL
-    // launch is run as two 32-channel slices by the MT = 1 kernel out of the same [chunk][tap][M tile][plane] pack: slice s starts s * NPW
-    // fragments in and its taps are 2 * NPW fragments apart
-    long long wchunk;               // 16-byte vectors between the fragments of consecutive chunks
-    int wtap;                       // fragments between consecutive taps
     // split K (esr_conv3x3_desc.k_split_ws): blockIdx.z = which run of `ncp` chunks (kz_groups channel groups) of the input this workgroup
     // contracts; its fp32 partial sums go to slab z of the workspace ([B][nchw_ctot][H][W] each, EPI_NCHW store), bias in slab 0 only
     int ksplit, kz_groups;
@@ -101,6 +111,7 @@ struct ConvArgs {
 };
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <int FMT>
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
     if (FMT) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -119,20 +130,20 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 template <> __device__ __forceinline__ uint32_t cvt_pk<0>(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 template <> __device__ __forceinline__ uint32_t cvt_pk<1>(float lo, float hi) { return f2h(lo) | (f2h(hi) << 16); }
 
-// Asynchronous global -> LDS copy, 16 bytes per lane: LDS destination = (wave-uniform) lds_dst + lane*16.
+// Asynchronous global -> LDS copy, 16 bytes per lane: LDS destination = (wave-uniform) lds_dst + lane*16; the source is a uniform base
+// (SGPR pair) + a per-lane 32-bit byte offset: no 64-bit per-lane address arithmetic per copy (the offsets of a tile's slots are computed once
+// per tile, the bases once per chunk).
 // Issued through inline asm on purpose: hipcc treats the builtin form as a pending LDS write and drains vmcnt(0) in front of
 // every later ds_read, which would serialise the copy of step s+1 with the MFMAs of step s.  Hidden from the compiler, the
 // copy is ordered by hand: wait_vm_upto() + barrier before the first read of a stage (see the step loop).
 // M0 (the DMA's LDS base) is not preserved by hipcc across statements and no other instruction of this kernel reads it.
-__device__ __forceinline__ void glds16(const uint4* src, unsigned lds_dst) {
-    // (readfirstlane: the destination is wave-uniform by construction, but the compiler cannot always prove it and M0 takes a scalar)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
-}
-// the same copy with the source given as a uniform base (SGPR pair) + a per-lane 32-bit byte offset: no 64-bit per-lane address arithmetic per
-// copy (the offsets of a tile's slots are computed once per tile, the bases once per chunk)
 __device__ __forceinline__ void glds16s(const uint4* sbase, unsigned voff, unsigned lds_dst) {
+    // (readfirstlane: the destination is wave-uniform by construction, but the compiler cannot always prove it and M0 takes a scalar)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
+
+// n / d for a launch constant d, m = ceil(2^32 / d) from the host: exact while n * d < 2^32 (tile indices: n < 2^22, d < 2^10)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, int d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
 // (their packed weights are zero, the data only has to be finite)
@@ -143,38 +154,31 @@ __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b
     return (lo ? a.in1.lo : a.in1.hi) + b * a.in1.bs + g1 * a.in1.cs;
 }
 
+// The activation copies of a tile: up to MAXS slots (64 pixel vectors = 1 KiB each) per wave and plane.  soff = the lane's source BYTE offset
+// inside a plane; slot = the LDS slot it fills (uniform).  Pixels of the flattened tile that lie outside the padded image (and the pad of the
+// last slot) read the plane's (0,0) border vector, which is zero: every lane of every slot copies something, no per-lane predication.
+template <int MAXS>
 struct FetchState {
-    int soff[4];               // up to 4 activation slots: source vector offset inside a plane, or -1 (lane past the tile)
-    int slot[4];               // LDS slot (64 pixel vectors) each of them fills; slot[0] is `wave`
-    int b;                     // image index
+    unsigned soff[MAXS];
+    int slot[MAXS];
 };
 
-__device__ __forceinline__ int slot_offset(const ConvArgs& a, int x0, int y0, int p) {
-    const int rr = p / a.P, cc = p - rr * a.P;
-    const int Yp = y0 + rr, Xp = x0 + cc;
-    const bool inb = (p < a.NPIX_T) && (Yp < a.H + 2) && (Xp < a.W + 2);
-    int sy = Yp, sx = Xp;
-    if (a.ups == 2) { sy = (Yp + 1) >> 1; sx = (Xp + 1) >> 1; }
-    else if (a.ups > 2) { sy = (Yp - 1 + a.ups) / a.ups; sx = (Xp - 1 + a.ups) / a.ups; }
-    // out-of-image pixels read the plane's (0,0) border vector, which is zero
-    return (p < a.NPIX_L) ? (inb ? sy * a.Win_p + sx : 0) : -1;
-}
-
+// Flattened-tile pixel p -> (row, column) with the pitch division as a multiplication (m_P = ceil(2^20 / P): exact for p * P < 2^20, and
+// p < 1024, P <= 386), nearest-upsample source coordinate (c - 1 + ups) / ups the same way (m_ups = ceil(2^16 / ups): exact for
+// coordinates < 2^15, checked by the host; ups = 1: the identity).
 template <int MAXS>
-__device__ __forceinline__ FetchState setup_tile(const ConvArgs& a, int t, int wave, int lane) {
-    const int tx = t % a.tiles_x;
-    const int r1 = t / a.tiles_x;
-    const int ty = r1 % a.tiles_y;
-    FetchState f;
-    f.b = r1 / a.tiles_y;
-    const int x0 = tx * a.TW, y0 = ty * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
-    // every wave issues exactly MAXS activation slots per plane (a constant instruction count keeps the s_waitcnt
-    // bookkeeping static): a slot index past the tile re-fetches this wave's first slot (same data, same destination)
-    const int nslots = (a.NPIX_L + 63) >> 6;
+__device__ __forceinline__ FetchState<MAXS> setup_tile(const ConvArgs& a, int x0, int y0, int wave, int lane) {
+    FetchState<MAXS> f;
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-        f.slot[s] = (wave + s * NW) < nslots ? wave + s * NW : wave;
-        f.soff[s] = slot_offset(a, x0, y0, f.slot[s] * 64 + lane);
+        // (a slot index past the tile re-fetches this wave's first slot; dma_chunk never issues it: the wave's share says how many it owns)
+        f.slot[s] = (wave + s * NW) < a.nslots ? wave + s * NW : wave;
+        const unsigned p = (unsigned)f.slot[s] * 64 + lane;
+        const unsigned rr = __umul24(p, a.m_P) >> 20, cc = p - rr * a.P;
+        const unsigned Yp = y0 + rr, Xp = x0 + cc;
+        const bool inb = (p < (unsigned)a.NPIX_T) && (Yp < (unsigned)a.H + 2) && (Xp < (unsigned)a.W + 2);
+        const unsigned sy = __umul24(Yp + a.ups - 1, a.m_ups) >> 16, sx = __umul24(Xp + a.ups - 1, a.m_ups) >> 16;
+        f.soff[s] = inb ? (sy * a.Win_p + sx) * 16 : 0;
     }
     return f;
 }
@@ -187,7 +191,7 @@ struct Bases {
     int wtap;
 };
 template <int NPL, int MT, int NPW>
-__device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b, int lane) {
+__device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b) {
     Bases<NPL> r;
 #pragma unroll
     for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
@@ -199,28 +203,13 @@ __device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int 
 // Which copies of a chunk this wave issues.  A chunk is 2*NPL activation planes x `nslots` 1-KiB slots plus NWI 1-KiB weight fragments; wave w
 // owns the slots w, w + NW, ... (setup_tile) and a contiguous range of weight fragments sized so that every wave issues the same number of
 // copies (+-1): a 1-KiB global_load_lds occupies its in-order wave for 90-150 cycles (profiles/microbench/ingest_paths.hip), the barrier
-// behind the copies waits for the slowest wave, and nothing is fetched twice.
+// behind the copies waits for the slowest wave, and nothing is fetched twice.  Computed on the HOST per launch (dma_share_host; the kernel
+// reads its wave's packed word from the kernel arguments).
 struct DmaShare {
     int nsl;                   // activation slots of this wave
     int w0, wc;                // its weight fragments [w0, w0 + wc)
 };
-template <int NPL, int NWI>
-__device__ __forceinline__ DmaShare dma_share(int npix_l, int wave) {
-    const int nslots = (npix_l + 63) >> 6;
-    const int target = (2 * NPL * nslots + NWI + NW - 1) / NW;
-    DmaShare d{0, 0, 0};
-    int start = 0;
-#pragma unroll
-    for (int v = 0; v < NW; ++v) {
-        const int nv = (nslots - v + NW - 1) / NW;
-        int c = target - 2 * NPL * nv;
-        c = c < 0 ? 0 : c;
-        if (c > NWI - start || v == NW - 1) c = NWI - start;
-        if (v == wave) { d.nsl = nv; d.w0 = start; d.wc = c; }
-        start += c;
-    }
-    return d;
-}
+__device__ __forceinline__ DmaShare unpack_share(unsigned w) { return DmaShare{(int)(w & 0xFF), (int)((w >> 8) & 0xFF), (int)(w >> 16)}; }
 // number of copies dma_chunk() issues (for the counted waits of the two-stage kernels)
 // TMODE != 0 (tap-masked kernels): only the 4 * MT * NPW fragments of the chunk's live taps are copied, wave k those of the k-th live tap
 // (per M tile: its own k-th live tap) — MT * NPW copies per wave whatever the chunk's tap set is
@@ -231,19 +220,17 @@ __device__ __forceinline__ int dma_count(const DmaShare& d, bool xlo) { return (
 // the 2x2 block of taps at (r0, c0): S2D_FWD[q] -> (1 - (q >> 1), 1 - (q & 1)), S2D_FLIP[q] -> (q >> 1, q & 1) with q = 2 * parity + m.  The dead
 // taps' fragments (5 of 9: zeros in the pack) are neither copied nor read — on the 512-channel layers the weight copies ARE the launch.
 template <int NPL, int MT, int NPW, int TMODE = 0>
-__device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo,
+__device__ __forceinline__ void dma_chunk(const FetchState<maxs_of(MT)>& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo,
                                           int tsel = 0, int wave = 0) {
     constexpr int MAXS = maxs_of(MT);
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
         if (s >= d.nsl) break;                          // wave-uniform
-        const int so = f.soff[s];
-        const unsigned vo = (unsigned)so * 16;
         const unsigned dst = stage + (unsigned)f.slot[s] * 1024;
 #pragma unroll
         for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
             if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
-            if (so >= 0) glds16s(bs.p[cgpl], vo, dst + cgpl * plane_bytes);
+            glds16s(bs.p[cgpl], f.soff[s], dst + cgpl * plane_bytes);
         }
     }
     const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
@@ -267,9 +254,11 @@ __device__ __forceinline__ void dma_chunk(const FetchState& f, const Bases<NPL>&
     }
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  MAXN = the largest count the calling kernel can ask
+// for (its waves' copy shares are bounded by the tile format): the cases above it are not compiled.
+template <int MAXN>
 __device__ __forceinline__ void wait_vm_upto(int n) {
-#define ESR_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define ESR_VMC(k) case k: if constexpr (k <= MAXN) { asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break; }
     switch (n) {
         ESR_VMC(1) ESR_VMC(2) ESR_VMC(3) ESR_VMC(4) ESR_VMC(5) ESR_VMC(6) ESR_VMC(7) ESR_VMC(8) ESR_VMC(9) ESR_VMC(10) ESR_VMC(11) ESR_VMC(12)
         ESR_VMC(13) ESR_VMC(14) ESR_VMC(15) ESR_VMC(16) ESR_VMC(17) ESR_VMC(18) ESR_VMC(19) ESR_VMC(20) ESR_VMC(21) ESR_VMC(22) ESR_VMC(23)
@@ -281,41 +270,28 @@ __device__ __forceinline__ void wait_vm_upto(int n) {
 
 // Residual / mask operand of one PAIR of channel groups (cg0, cg0+1) at this lane's pixel, read the way the output is stored:
 // lanes 0-31 load the full 16-byte pixel vector of group cg0, lanes 32-63 that of group cg0+1 (one coalesced b128 load per
-// plane); res_unpack() then exchanges halves (v_permlane32_swap) into the accumulator arrangement: this lane's 4 channels
-// (4*half .. 4*half+3) of both groups.
+// plane, uniform per-image base + 32-bit lane offset); res_unpack() then exchanges halves (v_permlane32_swap) into the accumulator
+// arrangement: this lane's 4 channels (4*half .. 4*half+3) of both groups.
 struct ResRaw { uint4 h, l; };
-__device__ __forceinline__ ResRaw res_issue(const DView& v, int b, int cgs, int pix, bool want_lo) {
-    ResRaw r;
-    r.h = make_uint4(0, 0, 0, 0);
-    r.l = make_uint4(0, 0, 0, 0);
-    if (cgs >= 0 && cgs < v.ncg) {
-        const long long o = b * v.bs + cgs * v.cs + pix;
-        r.h = v.hi[o];
-        if (want_lo && v.lo) r.l = v.lo[o];
-    }
-    return r;
-}
 __device__ __forceinline__ void swap_halves(const uint4& x, uint32_t (&d)[2][2]) {
     const auto s0 = __builtin_amdgcn_permlane32_swap(x.x, x.z, false, false);
     const auto s1 = __builtin_amdgcn_permlane32_swap(x.y, x.w, false, false);
     d[0][0] = s0[0]; d[0][1] = s1[0]; d[1][0] = s0[1]; d[1][1] = s1[1];
 }
 template <int FMT>
-__device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, float (&rv)[2][4]) {
+__device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, f32x2 (&rv)[2][2]) {
     uint32_t d[2][2];
     swap_halves(q.h, d);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        rv[k][0] = e2f<FMT>(d[k][0] & 0xFFFF); rv[k][1] = e2f<FMT>(d[k][0] >> 16);
-        rv[k][2] = e2f<FMT>(d[k][1] & 0xFFFF); rv[k][3] = e2f<FMT>(d[k][1] >> 16);
-    }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rv[k][j] = f32x2{e2f<FMT>(d[k][j] & 0xFFFF), e2f<FMT>(d[k][j] >> 16)};
     if (has_lo) {
         swap_halves(q.l, d);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            rv[k][0] += e2f<FMT>(d[k][0] & 0xFFFF); rv[k][1] += e2f<FMT>(d[k][0] >> 16);
-            rv[k][2] += e2f<FMT>(d[k][1] & 0xFFFF); rv[k][3] += e2f<FMT>(d[k][1] >> 16);
-        }
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rv[k][j] += f32x2{e2f<FMT>(d[k][j] & 0xFFFF), e2f<FMT>(d[k][j] >> 16)};
     }
 }
 
@@ -328,23 +304,37 @@ __device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const Con
     for (int sgrp = 0; sgrp < 2; ++sgrp) {
         const int og = 2 * cp + sgrp - a.resin_g0;              // output group fed by this input group (uniform)
         if (og < 0 || og * 8 >= a.cout) continue;
+        float x[R][4];
 #pragma unroll
-        for (int mg = 0; mg < MT * 4; ++mg) {
-            if (og != mg) continue;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const unsigned char* const pr = stage + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
-                const uint2 h = *(const uint2*)pr;
-                float x0 = e2f<FMT>(h.x & 0xFFFF), x1 = e2f<FMT>(h.x >> 16), x2 = e2f<FMT>(h.y & 0xFFFF), x3 = e2f<FMT>(h.y >> 16);
-                if (NPL == 2 && xlo) {
-                    const uint2 l = *(const uint2*)(pr + plane_bytes);
-                    x0 += e2f<FMT>(l.x & 0xFFFF); x1 += e2f<FMT>(l.x >> 16); x2 += e2f<FMT>(l.y & 0xFFFF); x3 += e2f<FMT>(l.y >> 16);
-                }
-                acc[mg / 4][r][(mg % 4) * 4 + 0] = fmaf(a.resin_scale, x0, acc[mg / 4][r][(mg % 4) * 4 + 0]);
-                acc[mg / 4][r][(mg % 4) * 4 + 1] = fmaf(a.resin_scale, x1, acc[mg / 4][r][(mg % 4) * 4 + 1]);
-                acc[mg / 4][r][(mg % 4) * 4 + 2] = fmaf(a.resin_scale, x2, acc[mg / 4][r][(mg % 4) * 4 + 2]);
-                acc[mg / 4][r][(mg % 4) * 4 + 3] = fmaf(a.resin_scale, x3, acc[mg / 4][r][(mg % 4) * 4 + 3]);
+        for (int r = 0; r < R; ++r) {
+            const unsigned char* const pr = stage + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
+            const uint2 h = *(const uint2*)pr;
+            x[r][0] = e2f<FMT>(h.x & 0xFFFF); x[r][1] = e2f<FMT>(h.x >> 16); x[r][2] = e2f<FMT>(h.y & 0xFFFF); x[r][3] = e2f<FMT>(h.y >> 16);
+            if (NPL == 2 && xlo) {
+                const uint2 l = *(const uint2*)(pr + plane_bytes);
+                x[r][0] += e2f<FMT>(l.x & 0xFFFF); x[r][1] += e2f<FMT>(l.x >> 16); x[r][2] += e2f<FMT>(l.y & 0xFFFF); x[r][3] += e2f<FMT>(l.y >> 16);
             }
+        }
+        // (uniform switch with the row group as a compile-time constant per case: accumulator rows are register indices — an if-chain over an
+        // unrolled index gets re-rolled into a run-time index, which sends the whole accumulator array to scratch)
+        auto add = [&](auto MG) {
+            constexpr int mg = decltype(MG)::value;
+            if constexpr (mg < MT * 4) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mg / 4][r][(mg % 4) * 4 + i] = fmaf(a.resin_scale, x[r][i], acc[mg / 4][r][(mg % 4) * 4 + i]);
+            }
+        };
+        switch (og) {
+            case 0: add(std::integral_constant<int, 0>{}); break;
+            case 1: add(std::integral_constant<int, 1>{}); break;
+            case 2: add(std::integral_constant<int, 2>{}); break;
+            case 3: add(std::integral_constant<int, 3>{}); break;
+            case 4: add(std::integral_constant<int, 4>{}); break;
+            case 5: add(std::integral_constant<int, 5>{}); break;
+            case 6: add(std::integral_constant<int, 6>{}); break;
+            default: add(std::integral_constant<int, 7>{}); break;
         }
     }
 }
@@ -414,6 +404,238 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned 
 // 32-channel tile, the non-zero taps of the embedded weight (bit 3 ty + tx) — and of its flipped / transposed form (data gradient)
 constexpr int S2D_FWD[4] = {432, 216, 54, 27}, S2D_FLIP[4] = {27, 54, 216, 432};
 
+// ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i, output row (i&3) + 8*(i>>2) + 4*(lane>>5):
+// i>>2 selects the 8-channel group inside the 32-row tile, (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes
+// of bf16.  Two groups are paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector: lanes 0-31 group cg0's,
+// lanes 32-63 group cg0+1's (same pixel).
+//
+// What depends only on (tile, lane) is computed ONCE, in front of the K loop where a lone workgroup waits for its first copies anyway
+// (epi_coords): per column tile the lane's byte offset inside an activation plane and `lim` = how many output groups the lane may store
+// (0: its pixel is pitch padding or outside the image; ncg_out - half otherwise, so that one compare `cg0 < lim` covers both the pixel and
+// the existence of group cg0 + half).  KIND 1 (fp32 NCHW destination): poff = byte offset inside a channel plane, lim without the half
+// term (every lane stores its own 4 channels of both groups); KIND 2 (pixel-shuffle store): poff = Y << 16 | X.
+template <int R>
+struct EpiCoord {
+    int lim[R];
+    unsigned poff[R];
+};
+template <int R, int KIND>
+__device__ __forceinline__ EpiCoord<R> epi_coords(const ConvArgs& a, int x0, int y0, int wave, int lane) {
+    EpiCoord<R> e;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned q = (wave + r * NW) * 32 + (lane & 31);
+        const unsigned rr = __umul24(q, a.m_P) >> 20, cc = q - rr * a.P;
+        const unsigned Y = y0 + rr, X = x0 + cc;
+        const bool valid = (rr < (unsigned)a.TH) && (cc < (unsigned)a.TW) && (Y < (unsigned)a.H) && (X < (unsigned)a.W);
+        e.lim[r] = valid ? (KIND == 1 ? a.ncg_out : a.ncg_out - half) : 0;
+        if (KIND == 1) e.poff[r] = (__umul24(Y, a.W) + X) * 4;
+        else if (KIND == 2) e.poff[r] = (Y << 16) | X;
+        else e.poff[r] = valid ? (__umul24(Y + 1, a.W + 2) + X + 1) * 16 : 0;
+    }
+    return e;
+}
+
+template <int NPL, int MT, int R, int EPI, int FMT, bool PARTLO>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][R], const int b, const EpiCoord<R>& ec, const int lane) {
+    constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
+    constexpr bool NCHW = (EPI & EPI_NCHW) != 0, OUT2 = (EPI & EPI_OUT2) != 0, PS = (EPI & EPI_PS) != 0;
+    const int half = lane >> 5;
+    const long long bl = b;
+    const f32x2 slope2 = {a.act_slope, a.act_slope}, alpha2 = {a.alpha, a.alpha};
+    // per-image plane bases (uniform: SGPR pairs) and the half-wave's group stride (one VGPR per view): every access below is
+    // base + 32-bit lane offset (the host checked that a view's image fits 2^32 bytes)
+    const char *r1h = nullptr, *r1l = nullptr, *r2h = nullptr, *r2l = nullptr, *mkh = nullptr;
+    unsigned h1 = 0, h2 = 0, ho = 0, ho2 = 0;
+    if constexpr (HAS_R1) {
+        r1h = (const char*)(a.res1.hi + bl * a.res1.bs);
+        r1l = a.res1.lo ? (const char*)(a.res1.lo + bl * a.res1.bs) : nullptr;
+        h1 = half ? (unsigned)a.res1.cs * 16 : 0;
+    }
+    if constexpr (HAS_R2) {
+        r2h = (const char*)(a.res2.hi + bl * a.res2.bs);
+        r2l = a.res2.lo ? (const char*)(a.res2.lo + bl * a.res2.bs) : nullptr;
+        h2 = half ? (unsigned)a.res2.cs * 16 : 0;
+    }
+    if constexpr (HAS_MK) {
+        mkh = (const char*)(a.mask.hi + bl * a.mask.bs);
+    }
+    char *oh = nullptr, *ol = nullptr, *o2h = nullptr, *o2l = nullptr;
+    if constexpr (!NCHW) {
+        oh = (char*)(a.out.hi + bl * a.out.bs);
+        ol = (NPL == 2 && a.out.lo) ? (char*)(a.out.lo + bl * a.out.bs) : nullptr;
+        ho = half ? (unsigned)a.out.cs * 16 : 0;
+        if constexpr (OUT2) {
+            o2h = (char*)(a.out2.hi + bl * a.out2.bs);
+            o2l = (NPL == 2 && a.out2.lo) ? (char*)(a.out2.lo + bl * a.out2.bs) : nullptr;       // (a hi-only second destination: the mask stash)
+            ho2 = half ? (unsigned)a.out2.cs * 16 : 0;
+        }
+    }
+    // Residual / mask operands: 16-byte loads, all of a column tile's (or, where the registers allow, of the whole tile's) issued in one go
+    // before the math that uses them.  A lane without an output reads its view's first vector (always mapped) and drops it.
+    constexpr int OPREGS_R = MT * 2 * (((HAS_R1 ? 1 : 0) + (HAS_R2 ? 1 : 0)) * NPL + (HAS_MK ? 1 : 0)) * 4;
+    constexpr bool ALL_FIRST = OPREGS_R * R <= 96;
+    constexpr int RQ = ALL_FIRST ? R : 1;
+    ResRaw q1[HAS_R1 ? RQ : 1][MT * 2], q2[HAS_R2 ? RQ : 1][MT * 2];
+    uint4 qm[HAS_MK ? RQ : 1][MT * 2];
+    auto issue = [&](const int r) {
+        const int rq = ALL_FIRST ? r : 0;
+#pragma unroll
+        for (int mp = 0; mp < MT * 2; ++mp) {
+            const int cg0 = mp * 2;
+            const bool ok = cg0 < ec.lim[r];
+            if constexpr (HAS_R1) {
+                const unsigned off = ok ? ec.poff[r] + h1 + cg0 * ((unsigned)a.res1.cs * 16) : 0;
+                q1[rq][mp].h = *(const uint4*)(r1h + off);
+                if (NPL == 2 && r1l) q1[rq][mp].l = *(const uint4*)(r1l + off);
+            }
+            if constexpr (HAS_R2) {
+                const unsigned off = ok ? ec.poff[r] + h2 + cg0 * ((unsigned)a.res2.cs * 16) : 0;
+                q2[rq][mp].h = *(const uint4*)(r2h + off);
+                if (NPL == 2 && r2l) q2[rq][mp].l = *(const uint4*)(r2l + off);
+            }
+            if constexpr (HAS_MK) {
+                const int cgm = cg0 + half - a.mask_cg0;                  // the lane's group inside the mask view
+                const bool okm = ok && cgm >= 0 && cg0 + half < a.mask_cg1;
+                const unsigned off = okm ? ec.poff[r] + (unsigned)cgm * ((unsigned)a.mask.cs * 16) : 0;
+                qm[rq][mp] = *(const uint4*)(mkh + off);
+            }
+        }
+    };
+    if constexpr (ALL_FIRST && (HAS_R1 || HAS_R2 || HAS_MK)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) issue(r);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if constexpr (!ALL_FIRST && (HAS_R1 || HAS_R2 || HAS_MK)) issue(r);
+        const int rq = ALL_FIRST ? r : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
+                if (!(cg0 < ec.lim[r])) continue;                // per lane: pixel inside the image and group cg0 + half exists
+                f32x2 v[2][2];                                   // [group k][channel pair]: this lane's 4 channels of both groups
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // alpha * LeakyReLU(y) = max(alpha * y, alpha * slope * y) for alpha >= 0, 0 < slope <= 1 (checked by the host); the bias is
+                        // the accumulators' seed.  (Scaling first makes both operands of the max products: no canonicalising v_max x, x.)
+                        v[k][j] = f32x2{acc[m][r][(gp * 2 + k) * 4 + 2 * j], acc[m][r][(gp * 2 + k) * 4 + 2 * j + 1]} * alpha2;
+                        v[k][j] = __builtin_elementwise_max(v[k][j], v[k][j] * slope2);
+                    }
+                if constexpr (HAS_R1) {
+                    f32x2 rv[2][2];
+                    res_unpack<FMT>(q1[rq][m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
+                    const f32x2 bb = {a.beta1, a.beta1};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) v[k][j] = __builtin_elementwise_fma(bb, rv[k][j], v[k][j]);
+                }
+                if constexpr (HAS_R2) {
+                    f32x2 rv[2][2];
+                    res_unpack<FMT>(q2[rq][m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
+                    const f32x2 bb = {a.beta2, a.beta2};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) v[k][j] = __builtin_elementwise_fma(bb, rv[k][j], v[k][j]);
+                }
+                if constexpr (HAS_MK) {
+                    // LeakyReLU' from the stored post-activation value: its sign is the pre-activation's (slope > 0);
+                    // x <= 0 -> slope (torch: leaky_relu'(0) = slope).  16-bit elements, two per dword: the low one is positive iff
+                    // (int)(d << 16) > 0, the high one iff (int)d > 0xFFFF (sign clear, magnitude bits not all zero) — bf16 and f16 alike
+                    uint32_t d[2][2];
+                    swap_halves(qm[rq][m * 2 + gp], d);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int cg = cg0 + k;
+                        const float ms = (cg < a.mask_cg0 || cg >= a.mask_cg1) ? 1.f : a.mask_slope;      // uniform: groups outside the masked range keep their value
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x2 s = v[k][j] * f32x2{ms, ms};
+                            v[k][j].x = (int)(d[k][j] << 16) > 0 ? v[k][j].x : s.x;
+                            v[k][j].y = (int)d[k][j] > 0xFFFF ? v[k][j].y : s.y;
+                        }
+                    }
+                }
+                if constexpr (NCHW) {
+                    // fp32 [B][nchw_ctot][H][W]: this lane's 4 channels of both groups (no exchange)
+                    char* const ob = (char*)(a.out_nchw + bl * a.nchw_ctot * a.H * a.W);
+                    const unsigned hw4 = (unsigned)(a.H * a.W) * 4;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int ch0 = (cg0 + k) * 8 + half * 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ch0 + i < a.cout) *(float*)(ob + (ec.poff[r] + (unsigned)(ch0 + i) * hw4)) = v[k][i >> 1][i & 1];
+                    }
+                    continue;                                    // the fp32 NCHW destination replaces the act-layout one
+                }
+                // to 16-bit hi (+ lo = the rounding residue) elements (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword.  Rows past
+                // cout need no masking: their weights and their bias seed are zero, so is whatever the residual buffers hold there.
+                uint32_t hi[2][2], lo[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t h = cvt_pk<FMT>(v[k][j].x, v[k][j].y);
+                        hi[k][j] = h;
+                        lo[k][j] = 0;
+                        if (NPL == 2) lo[k][j] = cvt_pk<FMT>(v[k][j].x - e2f<FMT>(h & 0xFFFF), v[k][j].y - e2f<FMT>(h >> 16));
+                    }
+                // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
+                const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                uint4 lv = hv;
+                if (NPL == 2) {
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
+                    lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                unsigned off;
+                if constexpr (PS) {
+                    // row group -> (output group, sub-position) of the r x r block at (Y, X)
+                    const int cgs = cg0 + half, rg = a.ps_rg0 + cgs, r2 = a.ps * a.ps, sp = rg % r2;
+                    const int Y = ec.poff[r] >> 16, X = ec.poff[r] & 0xFFFF;
+                    off = ((unsigned)(rg / r2) * (unsigned)a.out.cs + (unsigned)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1)) * 16;
+                } else off = ec.poff[r] + ho + cg0 * ((unsigned)a.out.cs * 16);
+                *(uint4*)(oh + off) = hv;
+                if (NPL == 2 && (!PARTLO || ol)) *(uint4*)(ol + off) = lv;
+                if constexpr (OUT2) {
+                    const unsigned off2 = ec.poff[r] + ho2 + cg0 * ((unsigned)a.out2.cs * 16);
+                    *(uint4*)(o2h + off2) = hv;
+                    if (NPL == 2 && o2l) *(uint4*)(o2l + off2) = lv;
+                }
+            }
+        }
+    }
+}
+
+// The accumulators' seed: the bias of this lane's 16 rows per M tile (esr_conv3x3_desc.bias: MT * 32 floats, zero beyond cout; the library's
+// zero block without a bias).  Scalar loads (the constant address space: s_load_dwordx8 per 8-channel block, on their own counter — the hand-counted vmcnt of the
+// copies is not involved), then one select per value on the half-wave.
+template <int MT>
+__device__ __forceinline__ void bias_seed(const float* bias, int half, float (&bz)[MT][16]) {
+    typedef const __attribute__((address_space(4))) float* cptr;
+    const cptr cb = (cptr)(uintptr_t)bias;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c0 = (m * 4 + j) * 8;
+                const float lo = cb[c0 + k], hi = cb[c0 + 4 + k];
+                bz[m][j * 4 + k] = half ? hi : lo;
+            }
+}
+
 // One output tile per workgroup.
 //   NST == 1: single LDS stage, 2 workgroups resident per CU: latency hiding comes from the co-resident workgroup instead of an
 //             in-workgroup pipeline (the persistent multi-stage variant measured slower).  Large launches.
@@ -423,6 +645,10 @@ constexpr int S2D_FWD[4] = {432, 216, 54, 27}, S2D_FLIP[4] = {27, 54, 216, 432};
 //   NST == 4: a ring of four stages, three chunks of copies in flight: few, small tiles with a long K axis (the critic's deep layers).
 // TMODE: 0 all taps; 1 the K chunks' tap sets follow S2D_FWD by the parity (cp >> 1) & 3 of their channel quad (forward of an embedded stride-2
 // conv); 2 the M tiles' tap sets follow S2D_FLIP by the parity of output tile 2 * slice + m (its data gradient)
+//
+// Order of the prologue (round 5: a lone workgroup per CU pays every instruction in front of its first copy in full): tile decode and the
+// slots' source offsets (multiplications by host-made magic numbers, no division), the first chunk's copies — and only then, while those
+// are in flight, the bias seed of the accumulators and the epilogue's per-lane coordinates.
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
     // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
@@ -432,7 +658,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     {
         const long long sl = blockIdx.y;                            // a slice is this kernel's MT * 32 output channels
         a.wpack += sl * a.wslice;
-        if (a.bias) a.bias += sl * (MT * 32);
+        a.bias += sl * (MT * 32) * a.bias_stride;
         auto shift = [&](DView& v) { if (v.hi) { v.hi += sl * (MT * 4) * v.cs; if (v.lo) v.lo += sl * (MT * 4) * v.cs; } };
         shift(a.out); shift(a.out2); shift(a.res1); shift(a.res2); shift(a.mask);
         if constexpr ((EPI & EPI_RESIN) != 0) a.resin_g0 += (int)sl * (MT * 4);      // the slice's residual groups: further along the input
@@ -444,7 +670,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
                 if (a.in1.lo) a.in1.lo += kz * a.kz_groups * a.in1.cs;
                 a.wpack += kz * a.ncp * (9 * MT * NPW * 64);
                 a.out_nchw += kz * a.kz_slab;
-                if (kz) a.bias = nullptr;
+                if (kz) a.bias = a.zero_bias;
             }
         }
     }
@@ -457,58 +683,74 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr int NSTAGES = NST == 1 ? 1 : (NST == 4 ? 4 : 2);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     const int plane_bytes = a.NPIX_L * 16;
     constexpr int NWI = 9 * MT * NPW;                              // weight fragments staged in LDS per chunk
+    constexpr int MAXCNT = 2 * NPL * MAXS + (NWI + NW - 1) / NW;      // most copies one wave issues per chunk (dma_share_host balances them)
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    constexpr int nstg = NSTAGES;
-    float* const s_bias = (float*)(smem + nstg * stage_bytes);
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    const int nxcd = 8, per_xcd = (ntiles + nxcd - 1) / nxcd;
-    const int tile_f = (blockIdx.x % nxcd) * per_xcd + blockIdx.x / nxcd;
-    if (blockIdx.x / nxcd >= per_xcd || tile_f >= ntiles) return;
-    const int tile = a.reverse ? ntiles - 1 - tile_f : tile_f;
-    if (tid < MT * 32) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
-    const DmaShare share = dma_share<NPL, NWI>(a.NPIX_L, wave);
+    const unsigned in_xcd = blockIdx.x >> 3;
+    const unsigned tile_f = (blockIdx.x & 7) * a.per_xcd + in_xcd;
+    if (in_xcd >= (unsigned)a.per_xcd || tile_f >= (unsigned)a.ntiles) return;
+    const unsigned tile = a.reverse ? a.ntiles - 1 - tile_f : tile_f;
+    const unsigned trow = udiv_magic(tile, a.tiles_x, a.m_tx);      // = image * tiles_y + tile row
+    const int b = udiv_magic(trow, a.tiles_y, a.m_ty);
+    const int x0 = (tile - trow * a.tiles_x) * a.TW, y0 = (trow - b * a.tiles_y) * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
+    const DmaShare share = unpack_share(a_in.share[wave]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 #ifdef ESR_TRACE
     unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
     int tslot = 2;
     if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); tr[126] = wall_clock64(); }
 #define ESR_TR() do { if (tr && tid == 0 && tslot < 126) tr[tslot++] = __builtin_readcyclecounter(); } while (0)
+    ESR_TR();                                    // entry stamp (slot 2): everything up to the first step stamp is the prologue
 #else
 #define ESR_TR() do { } while (0)
 #endif
-    const FetchState fs = setup_tile<MAXS>(a, tile, wave, lane);
-    f32x16 acc[MT][R];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.f;
+    const FetchState<MAXS> fs = setup_tile<MAXS>(a, x0, y0, wave, lane);
     static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
     constexpr int NTERM_CAP = 3;
     // which 2x2 block of taps chunk c's weights live in (dma_chunk)
     auto tsel_of = [&](const int c) { return TMODE == 1 ? ((c >> 1) & 3) : (TMODE == 2 ? (int)(blockIdx.y & 1) : 0); };
-    if (NST == 2) {                           // prologue: chunk 0 -> stage 0
-        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, 0, fs.b, lane);
-        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0, plane_bytes, !PARTLO || 0 < a.lo_chunks, tsel_of(0), wave);
-    }
+    auto issue = [&](const int c, const unsigned stage, const bool xlo) {
+        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, b);
+        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, stage, plane_bytes, xlo, tsel_of(c), wave);
+    };
     if (NST == 4) {                           // ring of four stages: chunks 0, 1, 2 in flight before the first multiply
         static_assert(NST != 4 || !PARTLO, "the four-stage ring counts its copies per chunk: one count for all chunks");
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (c < a.ncp) {
-                const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, fs.b, lane);
-                dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + c * stage_bytes, plane_bytes, true, tsel_of(c), wave);
-            }
+            if (c < a.ncp) issue(c, lds0 + c * stage_bytes, true);
     }
+    // What waits for nothing: done behind the first copies.  The accumulators start from the bias (their rows' seed); the epilogue's
+    // coordinates are formed here when the registers allow (the lone-workgroup forms and the one-plane 32-channel kernels), otherwise after
+    // the K loop (the 64-channel kernels of the large launches sit at their 256-register limit and a co-resident workgroup covers it).
+    constexpr int EKIND = (EPI & EPI_NCHW) ? 1 : ((EPI & EPI_PS) ? 2 : 0);
+    constexpr bool EARLY_COORDS = NST >= 2 || (MT == 1 && NPL == 1);
+    f32x16 acc[MT][R];
+    EpiCoord<R> ec;
+    auto seed = [&]() {
+        // (an opaque copy of the lane index: everything per-lane below is loop-invariant and would otherwise be hoisted in front of the copies)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        float bz[MT][16];
+        bias_seed<MT>(a.bias, lane_o >> 5, bz);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][r][i] = bz[m][i];
+        if constexpr (EARLY_COORDS) ec = epi_coords<R, EKIND>(a, x0, y0, wave, lane_o);
+    };
+    // The first chunk's copies go out in front of the K loop, the seed right behind them.  (Seeding inside the loop's first pass instead —
+    // one copy of the issue code — made the accumulators' loop-carried registers VGPRs: 96 v_accvgpr moves per chunk, +0.35 us per chunk.)
+    if (NST != 4) issue(0, lds0, !PARTLO || 0 < a.lo_chunks);
+    __builtin_amdgcn_sched_barrier(0);
+    seed();
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
     // plane.  The chunks with a lo plane come first, so the K loop is two loops over the same step with XLO = true / false: a run-time
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
@@ -519,33 +761,25 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         const unsigned char* const sa = sa0 + st * stage_bytes;
         ESR_TR();
         if (NST == 1) {
-            const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp, fs.b, lane);
-            DmaShare sh = share;
-            dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, sh, lds0, plane_bytes, xlo, tsel_of(cp), wave);
+            if (cp > 0) issue(cp, lds0, xlo);
             ESR_TR();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (NST == 4) {
             // NST == 4 (launches of few, small tiles with a long K axis — the critic's 512-channel layers on 8x8 / 4x4 maps): each chunk is a
             // handful of MFMAs behind a copy round trip, so the round trips of THREE chunks are kept in flight.  The stage refilled now
             // (chunk cp + 3) was last read in iteration cp - 1, closed by its trailing barrier.
-            if (cp + 3 < a.ncp) {
-                const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 3, fs.b, lane);
-                dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + ((cp + 3) & 3) * stage_bytes, plane_bytes, true, tsel_of(cp + 3), wave);
-            }
+            if (cp + 3 < a.ncp) issue(cp + 3, lds0 + ((cp + 3) & 3) * stage_bytes, true);
             const int ahead = a.ncp - 1 - cp < 3 ? a.ncp - 1 - cp : 3;         // chunks behind cp that stay in flight
             ESR_TR();
-            wait_vm_upto(ahead * dma_count<NPL, MT, NPW, TMODE>(share, true));
-        } else if (cp + 1 < a.ncp) {
+            wait_vm_upto<3 * MAXCNT < 32 ? 3 * MAXCNT : 32>(ahead * dma_count<NPL, MT, NPW, TMODE>(share, true));
+        } else {
             // the other stage was last read in iteration cp-1 (closed by its trailing barrier): refill it now, then wait for
             // everything EXCEPT the copies just issued
-            const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, cp + 1, fs.b, lane);
+            const bool more = cp + 1 < a.ncp;
             const bool xlo_next = !PARTLO || cp + 1 < a.lo_chunks;
-            dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, lds0 + (st ^ 1) * stage_bytes, plane_bytes, xlo_next, tsel_of(cp + 1), wave);
+            if (more) issue(cp + 1, lds0 + ((cp + 1) & 1) * stage_bytes, xlo_next);
             ESR_TR();
-            wait_vm_upto(dma_count<NPL, MT, NPW, TMODE>(share, xlo_next));
-        } else {
-            ESR_TR();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vm_upto<MAXCNT>(more ? dma_count<NPL, MT, NPW, TMODE>(share, xlo_next) : 0);
         }
         ESR_TR();
         __syncthreads();
@@ -572,159 +806,8 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     if constexpr (PARTLO)
         for (int cp = lo_end; cp < a.ncp; ++cp) step(std::false_type{}, cp);
     ESR_TR();
-    {
-        // ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i,
-        // output row (i&3) + 8*(i>>2) + 4*(lane>>5): i>>2 selects the 8-channel group inside the 32-row tile,
-        // (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes of bf16.  Two groups are
-        // paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector.
-        const int tx = tile % a.tiles_x;
-        const int r1 = tile / a.tiles_x;
-        const int ty = r1 % a.tiles_y;
-        const int b = r1 / a.tiles_y;
-        const int x0 = tx * a.TW, y0 = ty * a.TH;
-        const int half = lane >> 5;
-        const int Wp = a.W + 2;
-        const int ncg_out = (a.cout + 7) >> 3;
-        // Residual / mask operands are 16-byte loads straight from global memory, issued ESR_EPI_AHEAD column tiles ahead of the math that
-        // uses them.  Measured: 0 (load, use, next tile) and R-1 (all loads first) run the C2 forward in the same time — the co-resident
-        // workgroup already covers the latency — and 0 keeps every instantiation free of register spills, so 0 it is.
-        constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
-        constexpr int AHEAD = ESR_EPI_AHEAD < R ? ESR_EPI_AHEAD : R - 1;
-        ResRaw q1[HAS_R1 ? R : 1][MT * 2], q2[HAS_R2 ? R : 1][MT * 2], qm[HAS_MK ? R : 1][MT * 2];
-        int Ys[R], Xs[R], pixs[R];
-        bool valids[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int q = (wave + r * NW) * 32 + (lane & 31);
-            const int rr = q / P, cc = q - rr * P;
-            Ys[r] = y0 + rr; Xs[r] = x0 + cc;
-            valids[r] = (rr < a.TH) && (cc < a.TW) && (Ys[r] < a.H) && (Xs[r] < a.W);
-            pixs[r] = (Ys[r] + 1) * Wp + (Xs[r] + 1);
-        }
-#pragma unroll
-        for (int st = 0; st < R + AHEAD; ++st) {                     // software pipeline: loads of column tile st, math of tile st - AHEAD
-            if (st < R && (HAS_R1 || HAS_R2 || HAS_MK)) {
-#pragma unroll
-                for (int mp = 0; mp < MT * 2; ++mp) {
-                    const int cgs = (valids[st] && (mp * 2 + half) < ncg_out) ? mp * 2 + half : -1;     // -1: no such output, operand = 0
-                    if constexpr (HAS_R1) q1[st][mp] = res_issue(a.res1, b, cgs, pixs[st], NPL == 2);
-                    if constexpr (HAS_R2) q2[st][mp] = res_issue(a.res2, b, cgs, pixs[st], NPL == 2);
-                    if constexpr (HAS_MK) qm[st][mp] = res_issue(a.mask, b, (cgs >= a.mask_cg0 && cgs < a.mask_cg1) ? cgs - a.mask_cg0 : -1, pixs[st], false);
-                }
-            }
-            if (st < AHEAD) continue;
-            const int r = st - AHEAD;
-            const bool valid = valids[r];
-            const int Y = Ys[r], X = Xs[r], pix = pixs[r];
-            const bool any_valid = __builtin_amdgcn_ballot_w64(valid) != 0;      // wave-uniform
-            if (any_valid && valid) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
-                        if (cg0 >= ncg_out) continue;                    // uniform
-                        float v[2][4];
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int ch0 = (cg0 + k) * 8 + half * 4;
-                            const float4 bz = *(const float4*)(s_bias + ch0);
-                            v[k][0] = acc[m][r][(gp * 2 + k) * 4 + 0] + bz.x; v[k][1] = acc[m][r][(gp * 2 + k) * 4 + 1] + bz.y;
-                            v[k][2] = acc[m][r][(gp * 2 + k) * 4 + 2] + bz.z; v[k][3] = acc[m][r][(gp * 2 + k) * 4 + 3] + bz.w;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[k][i] = a.alpha * fmaxf(v[k][i], v[k][i] * a.act_slope);   // 0 < slope <= 1
-                        }
-                        if constexpr (HAS_R1) {
-                            float rv[2][4];
-                            res_unpack<FMT>(q1[r][m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta1, rv[k][i], v[k][i]);
-                        }
-                        if constexpr (HAS_R2) {
-                            float rv[2][4];
-                            res_unpack<FMT>(q2[r][m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[k][i] = fmaf(a.beta2, rv[k][i], v[k][i]);
-                        }
-                        if constexpr (HAS_MK) {
-                            // LeakyReLU' from the stored post-activation value: its sign is the pre-activation's (slope > 0);
-                            // x <= 0 -> slope (torch: leaky_relu'(0) = slope)
-                            uint32_t d[2][2];
-                            swap_halves(qm[r][m * 2 + gp].h, d);
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int cg = cg0 + k;
-                                if (cg < a.mask_cg0 || cg >= a.mask_cg1) continue;
-                                const uint32_t sg[4] = {d[k][0] & 0x8000u, d[k][0] & 0x80000000u, d[k][1] & 0x8000u, d[k][1] & 0x80000000u};
-                                const uint32_t nz[4] = {d[k][0] & 0x7FFFu, d[k][0] & 0x7FFF0000u, d[k][1] & 0x7FFFu, d[k][1] & 0x7FFF0000u};
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (sg[i] || !nz[i]) v[k][i] *= a.mask_slope;
-                            }
-                        }
-                        if constexpr ((EPI & EPI_NCHW) != 0) {
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int ch0 = (cg0 + k) * 8 + half * 4;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (ch0 + i < a.cout)
-                                        a.out_nchw[((long long)(b * a.nchw_ctot + ch0 + i) * a.H + Y) * a.W + X] = v[k][i];
-                            }
-                            continue;                                    // the fp32 NCHW destination replaces the act-layout one
-                        }
-                        // split to hi + lo bf16 (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword
-                        uint32_t hi[2][2], lo[2][2];
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int ch0 = (cg0 + k) * 8 + half * 4;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (ch0 + i >= a.cout) v[k][i] = 0.f;     // channels past cout stay zero in the buffer
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const uint32_t h = cvt_pk<FMT>(v[k][2 * j], v[k][2 * j + 1]);
-                                hi[k][j] = h;
-                                lo[k][j] = 0;
-                                if (NPL == 2)
-                                    lo[k][j] = cvt_pk<FMT>(v[k][2 * j] - e2f<FMT>(h & 0xFFFF), v[k][2 * j + 1] - e2f<FMT>(h >> 16));
-                            }
-                        }
-                        // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
-                        const int cgs = cg0 + half;
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
-                        const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        uint4 lv = hv;
-                        if (NPL == 2) {
-                            const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
-                            const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
-                            lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
-                        }
-                        if (cgs < ncg_out) {
-                            long long o = b * a.out.bs + cgs * a.out.cs + pix;
-                            if (a.ps) {            // row group -> (output group, sub-position) of the r x r block at (Y, X)
-                                const int rg = a.ps_rg0 + cgs, r2 = a.ps * a.ps;
-                                const int sp = rg % r2;
-                                o = b * a.out.bs + (rg / r2) * a.out.cs + (long long)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1);
-                            }
-                            ((uint4*)a.out.hi)[o] = hv;
-                            if (NPL == 2 && (!PARTLO || a.out.lo)) ((uint4*)a.out.lo)[o] = lv;
-                            if (EPI & EPI_OUT2) {
-                                const long long o2 = b * a.out2.bs + cgs * a.out2.cs + pix;
-                                ((uint4*)a.out2.hi)[o2] = hv;
-                                if (NPL == 2 && a.out2.lo) ((uint4*)a.out2.lo)[o2] = lv;       // (a hi-only second destination: the mask stash)
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
+    if constexpr (!EARLY_COORDS) ec = epi_coords<R, EKIND>(a, x0, y0, wave, lane);
+    conv_epilogue<NPL, MT, R, EPI, FMT, PARTLO>(a, acc, b, ec, lane);
     ESR_TR();
 #ifdef ESR_TRACE
     if (tr && tid == 0) tr[127] = wall_clock64();
@@ -822,8 +905,9 @@ TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
             const int npix_t = (TH + 2) * P;
             int npix_l = max_px + 2 * P + 2;
             if (npix_l < npix_t) npix_l = npix_t;
+            npix_l = (npix_l + 63) / 64 * 64;          // whole 1-KiB copy slots: every lane of every slot copies (setup_tile)
             if (npix_l > MAXS * NW * 64) continue;
-            const size_t lds = nwg * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024) + (size_t)mt * 32 * 4;
+            const size_t lds = nwg * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024);
             if (lds > budget) continue;
             const int nty = (H + TH - 1) / TH;
             const double halo = (double)(TH + 2) * P / ((double)TH * TW);
@@ -841,16 +925,46 @@ TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
 unsigned long long* g_trace = nullptr;
 #endif
 
+// 64 zero floats per device: what ConvArgs.bias points at when the launch has no bias (the kernel seeds its accumulators without a branch)
+__device__ float g_zero_bias[64];
+const float* zero_bias() {
+    static const float* ptr[64] = {};      // per device (benign race: every thread resolves the same address)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const float*& p = ptr[dev & 63];
+    if (!p) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_bias)) != hipSuccess) return nullptr;
+        p = (const float*)q;
+    }
+    return p;
+}
+
+// Which copies of a chunk each wave issues (DmaShare): a chunk is 2 * npl activation planes x `nslots` 1-KiB slots plus `nwi` 1-KiB weight
+// fragments; wave w owns the slots w, w + NW, ... and a contiguous range of weight fragments sized so that every wave issues the same
+// number of copies (+-1).  Packed per wave: slots | first fragment << 8 | fragments << 16.
+void dma_share_host(int npl, int nwi, int nslots, unsigned (&out)[NW]) {
+    const int target = (2 * npl * nslots + nwi + NW - 1) / NW;
+    int start = 0;
+    for (int v = 0; v < NW; ++v) {
+        const int nv = nslots > v ? (nslots - v + NW - 1) / NW : 0;
+        int c = target - 2 * npl * nv;
+        c = c < 0 ? 0 : c;
+        if (c > nwi - start || v == NW - 1) c = nwi - start;
+        out[v] = (unsigned)nv | ((unsigned)start << 8) | ((unsigned)c << 16);
+        start += c;
+    }
+}
+
 template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
     void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMODE>;
     ESR_ALLOW_160K_LDS(k);
     const int nslices = a.wslice ? a.nslices : 1;
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
-    const size_t lds = (NST == 1 ? 1 : (NST == 4 ? 4 : 2)) * stage + (size_t)MT * 32 * 4;
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const size_t lds = (NST == 1 ? 1 : (NST == 4 ? 4 : 2)) * stage;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(((ntiles + 7) / 8) * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(a.per_xcd * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -865,7 +979,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     // few small tiles, long K: the four-stage ring where it fits (plain bf16 kernels — what the critic's deep layers launch)
     if constexpr ((EPI == 0 || EPI == EPI_NCHW) && !PARTLO && FMT == 0 && MT == 2) {
         const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
-        if (!force && small && a.ncp >= (EPI == EPI_NCHW ? 8 : 16) && 4 * stage + MT * 32 * 4 <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
+        if (!force && small && a.ncp >= (EPI == EPI_NCHW ? 8 : 16) && 4 * stage <= 160 * 1024) return launch_nst<NPL, MT, EPI, 4, FMT, NPW, PARTLO, TMODE>(a, s);
     }
     // the tap-masked kernels with hi+lo operands (four / two copies of the chunk body with their own tap sets) do not fit the 256 registers of
     // the two-workgroups-per-CU form — they spilled 34-168 VGPRs to scratch: always the two-stage form (one workgroup per CU, 512 registers)
@@ -889,6 +1003,7 @@ int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
             case EPI_RESIN | EPI_RES2: return launch<NPL, MT, EPI_RESIN | EPI_RES2, FMT, NPW, PARTLO>(a, s);
             case EPI_NCHW: return launch<NPL, MT, EPI_NCHW, FMT, NPW, PARTLO>(a, s);
             case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW, PARTLO>(a, s);
+            case EPI_PS: return launch<NPL, MT, EPI_PS, FMT, NPW, PARTLO>(a, s);
             default: return ESR_E_UNSUPPORTED;
         }
     }
@@ -902,6 +1017,7 @@ int launch_epi(const ConvArgs& a, int epi, hipStream_t s) {
         case EPI_OUT2: return launch<NPL, MT, EPI_OUT2, FMT, NPW, PARTLO>(a, s);
         case EPI_RES1 | EPI_MASK: return launch<NPL, MT, EPI_RES1 | EPI_MASK, FMT, NPW, PARTLO>(a, s);
         case EPI_MASK: return launch<NPL, MT, EPI_MASK, FMT, NPW, PARTLO>(a, s);
+        case EPI_PS: return launch<NPL, MT, EPI_PS, FMT, NPW, PARTLO>(a, s);
         default: return ESR_E_UNSUPPORTED;
     }
 }
@@ -1035,7 +1151,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     // a missing lo OUTPUT plane with hi+lo inputs is the single-plane-intermediate case (fp16 formats only, checked below)
     if (d->out.hi && d->out.lo && !split) return ESR_E_ARG;
     if (d->out2.hi && (!d->out.hi || (d->out2.lo && !d->out.lo))) return ESR_E_ARG;      // out2 may drop the lo plane, not add one
-    if (d->act_slope <= 0.f || d->act_slope > 1.f) return ESR_E_ARG;
+    if (d->act_slope <= 0.f || d->act_slope > 1.f || !(d->alpha >= 0.f)) return ESR_E_ARG;      // (the epilogue evaluates alpha * LeakyReLU as a max of two products)
 
     ConvArgs a{};
     a.in0 = to_dview(d->in0);
@@ -1043,7 +1159,10 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.ups = ups;
     a.Win_p = d->in1.W + 2;
     a.wpack = (const uint4*)d->wpack;
-    a.bias = d->bias;
+    a.zero_bias = zero_bias();
+    if (!a.zero_bias) return ESR_E_LAUNCH;
+    a.bias = d->bias ? d->bias : a.zero_bias;
+    a.bias_stride = d->bias ? 1 : 0;
     a.cout = nslices > 1 ? 64 : d->cout;
     a.nslices = nslices;
     a.B = d->B;
@@ -1068,6 +1187,26 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (mslice) { a.cout = 32; a.nslices = 2; }
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    // the kernel's divisions by launch constants, as multiplications (ConvArgs; conv3x3_tile_kernel's prologue)
+    a.ntiles = a.tiles_x * a.tiles_y * a.B;
+    a.per_xcd = (a.ntiles + 7) / 8;
+    a.m_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);          // (divisor 1: 2^32 does not fit — udiv_magic skips the multiply)
+    a.m_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    a.m_P = ((1u << 20) + a.P - 1) / a.P;
+    a.m_ups = ((1u << 16) + ups - 1) / ups;
+    a.nslots = a.NPIX_L / 64;
+    a.ncg_out = (a.cout + 7) >> 3;
+    if (d->H + 2 >= 32768 || d->W + 2 >= 32768 || ups > 8 || (long long)a.ntiles * a.tiles_x >= 0x100000000ll) return ESR_E_UNSUPPORTED;
+    {
+        // every per-lane address of the kernel is a uniform per-image base + a 32-bit byte offset
+        auto fits = [](const esr_act_view& v) { return !v.hi || (long long)v.ncg * v.cg_stride * 16 < 0x100000000ll; };
+        if (!fits(d->in0) || !fits(d->in1) || !fits(d->out) || !fits(d->out2) || !fits(d->res1) || !fits(d->res2) || !fits(d->mask_src)) return ESR_E_UNSUPPORTED;
+        if (d->out_nchw && (long long)d->cout * d->H * d->W * 4 >= 0x100000000ll) return ESR_E_UNSUPPORTED;
+        // residuals cover every output group (the epilogue reads them for all of them)
+        const int ncg_all = (d->cout + 7) >> 3;
+        if ((d->res1.hi && d->res1.ncg < ncg_all) || (d->res2.hi && d->res2.ncg < ncg_all)) return ESR_E_ARG;
+        if (d->mask_src.hi && d->mask_src.ncg < (d->mask_cg1 < ncg_all ? d->mask_cg1 : ncg_all) - d->mask_cg0) return ESR_E_ARG;
+    }
     a.ncp = (a.in0.ncg + a.in1.ncg + 1) / 2;
     a.act_slope = d->act_slope;
     a.alpha = d->alpha;
@@ -1109,6 +1248,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (d->mask_src.hi) epi |= EPI_MASK;
     if (d->out_nchw) epi |= EPI_NCHW;
     if (d->out2.hi) epi |= EPI_OUT2;
+    if (ps) epi |= EPI_PS;
     if ((epi & EPI_NCHW) && d->out.hi) return ESR_E_UNSUPPORTED;     // one destination kind per launch
     hipStream_t s = (hipStream_t)stream;
     int wpl = d->weight_planes;
@@ -1118,6 +1258,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.wchunk = (long long)9 * mt * wpl * 64;
     a.wtap = mt * wpl;
     if (mslice) a.wslice = (long long)wpl * 64;                   // slice s = M tile s of every (chunk, tap) block of the 64-row pack
+    dma_share_host(npl, 9 * mt_k * wpl, a.nslots, a.share);
     // which leading chunks of the concatenated input carry a lo plane
     a.lo_chunks = a.ncp;
     bool partlo = false;
