@@ -70,9 +70,11 @@ constexpr int EPI_PS = 64;
 struct ConvArgs {
     // ---- what the prologue decodes before it can issue the first copy (one kernarg batch): the tile space, the tile geometry and the
     // divisions by launch constants turned into multiplications on the host (esr_conv3x3: magic numbers, the waves' copy shares)
-    int tiles_x, tiles_y, ntiles, per_xcd;      // per_xcd = ceil(ntiles / 8): tiles swept by one XCD
-    unsigned m_tx, m_ty;            // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)   (unused when the divisor is 1)
-    int TH, TW, P, NPIX_T, NPIX_L, nslots;      // NPIX_L is a multiple of 64: whole 1-KiB copy slots, nslots of them per plane
+    int tiles_x, tiles_y, ntiles;
+    int xcd_q, xcd_r;               // ntiles = 8 * xcd_q + xcd_r: XCD x sweeps xcd_q (+1 if x < xcd_r) consecutive tiles
+    unsigned m_tx, m_ty;            // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y); 0 when the divisor is 1 ...
+    unsigned i_tx, i_ty;            // ... and then these are 1: n / d = umulhi(n, m) + n * i, no branch
+    int TH, TW, P, NPIX_T, NPIX_L, nslots;      // nslots = 1-KiB copy slots (64 pixel vectors) per plane, the last one partial
     unsigned m_P, m_ups;            // ceil(2^20 / P), ceil(2^16 / ups)
     int H, W, Win_p, ups;           // output interior; padded input row pitch (W_in + 2); input upsample factor
     unsigned share[NW];             // per wave: activation slots | first weight fragment << 8 | weight fragments << 16 (dma_share)
@@ -142,8 +144,9 @@ __device__ __forceinline__ void glds16s(const uint4* sbase, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
-// n / d for a launch constant d, m = ceil(2^32 / d) from the host: exact while n * d < 2^32 (tile indices: n < 2^22, d < 2^10)
-__device__ __forceinline__ unsigned udiv_magic(unsigned n, int d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
+// n / d for a launch constant d: m = ceil(2^32 / d) from the host, exact while n * d < 2^32 (tile indices: n < 2^22, d < 2^10); d = 1 comes
+// as m = 0, i = 1 (2^32 does not fit): branch-free, so that nothing in the prologue keeps the kernel-argument loads from being batched
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned i) { return __umulhi(n, m) + n * i; }
 
 // base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
 // (their packed weights are zero, the data only has to be finite)
@@ -155,8 +158,8 @@ __device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b
 }
 
 // The activation copies of a tile: up to MAXS slots (64 pixel vectors = 1 KiB each) per wave and plane.  soff = the lane's source BYTE offset
-// inside a plane; slot = the LDS slot it fills (uniform).  Pixels of the flattened tile that lie outside the padded image (and the pad of the
-// last slot) read the plane's (0,0) border vector, which is zero: every lane of every slot copies something, no per-lane predication.
+// inside a plane (~0: a lane past the tile's last pixel vector, copies nothing); slot = the LDS slot it fills (uniform).  Pixels of the
+// flattened tile that lie outside the padded image read the plane's (0,0) border vector, which is zero.
 template <int MAXS>
 struct FetchState {
     unsigned soff[MAXS];
@@ -178,7 +181,9 @@ __device__ __forceinline__ FetchState<MAXS> setup_tile(const ConvArgs& a, int x0
         const unsigned Yp = y0 + rr, Xp = x0 + cc;
         const bool inb = (p < (unsigned)a.NPIX_T) && (Yp < (unsigned)a.H + 2) && (Xp < (unsigned)a.W + 2);
         const unsigned sy = __umul24(Yp + a.ups - 1, a.m_ups) >> 16, sx = __umul24(Xp + a.ups - 1, a.m_ups) >> 16;
-        f.soff[s] = inb ? (sy * a.Win_p + sx) * 16 : 0;
+        // (the pad of the last slot is not copied: it would land in the next plane.  Rounding the planes up to whole slots instead — no
+        // per-lane predicate at all — measured +2.6 % on the configs[1] forward: 7 % more bytes into LDS under the power cap)
+        f.soff[s] = p >= (unsigned)a.NPIX_L ? ~0u : (inb ? (sy * a.Win_p + sx) * 16 : 0);
     }
     return f;
 }
@@ -227,10 +232,12 @@ __device__ __forceinline__ void dma_chunk(const FetchState<maxs_of(MT)>& f, cons
     for (int s = 0; s < MAXS; ++s) {
         if (s >= d.nsl) break;                          // wave-uniform
         const unsigned dst = stage + (unsigned)f.slot[s] * 1024;
+        if (f.soff[s] != ~0u) {                         // per lane; one predicate per slot, not per copy
 #pragma unroll
-        for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
-            if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
-            glds16s(bs.p[cgpl], f.soff[s], dst + cgpl * plane_bytes);
+            for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
+                if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
+                glds16s(bs.p[cgpl], f.soff[s], dst + cgpl * plane_bytes);
+            }
         }
     }
     const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
@@ -689,13 +696,13 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     constexpr int NWI = 9 * MT * NPW;                              // weight fragments staged in LDS per chunk
     constexpr int MAXCNT = 2 * NPL * MAXS + (NWI + NW - 1) / NW;      // most copies one wave issues per chunk (dma_share_host balances them)
     const int stage_bytes = 2 * NPL * plane_bytes + NWI * 1024;
-    // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space
-    const unsigned in_xcd = blockIdx.x >> 3;
-    const unsigned tile_f = (blockIdx.x & 7) * a.per_xcd + in_xcd;
-    if (in_xcd >= (unsigned)a.per_xcd || tile_f >= (unsigned)a.ntiles) return;
+    // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space.  The grid is exactly ntiles
+    // workgroups (XCD x owns xcd_q tiles, one more if x < xcd_r): no idle workgroup, no early exit — the prologue is branch-free
+    const unsigned xcd = blockIdx.x & 7;
+    const unsigned tile_f = xcd * a.xcd_q + (xcd < (unsigned)a.xcd_r ? xcd : (unsigned)a.xcd_r) + (blockIdx.x >> 3);
     const unsigned tile = a.reverse ? a.ntiles - 1 - tile_f : tile_f;
-    const unsigned trow = udiv_magic(tile, a.tiles_x, a.m_tx);      // = image * tiles_y + tile row
-    const int b = udiv_magic(trow, a.tiles_y, a.m_ty);
+    const unsigned trow = udiv_magic(tile, a.m_tx, a.i_tx);         // = image * tiles_y + tile row
+    const int b = udiv_magic(trow, a.m_ty, a.i_ty);
     const int x0 = (tile - trow * a.tiles_x) * a.TW, y0 = (trow - b * a.tiles_y) * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
     const DmaShare share = unpack_share(a_in.share[wave]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -709,6 +716,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #define ESR_TR() do { } while (0)
 #endif
     const FetchState<MAXS> fs = setup_tile<MAXS>(a, x0, y0, wave, lane);
+    ESR_TR();                                    // (slot 3) tile decoded, slot offsets formed
     static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
     const unsigned char* const sa0 = smem + 2 * NPL * plane_bytes + lane * 16;
@@ -750,7 +758,9 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // one copy of the issue code — made the accumulators' loop-carried registers VGPRs: 96 v_accvgpr moves per chunk, +0.35 us per chunk.)
     if (NST != 4) issue(0, lds0, !PARTLO || 0 < a.lo_chunks);
     __builtin_amdgcn_sched_barrier(0);
+    ESR_TR();                                    // (slot 4) first chunk's copies issued
     seed();
+    ESR_TR();                                    // (slot 5) accumulators seeded, epilogue coordinates formed
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
     // plane.  The chunks with a lo plane come first, so the K loop is two loops over the same step with XLO = true / false: a run-time
     // branch between the two MFMA bodies inside ONE loop made the register allocator spill (vgpr_spill 200-500 in the 64-channel kernels).
@@ -905,7 +915,6 @@ TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
             const int npix_t = (TH + 2) * P;
             int npix_l = max_px + 2 * P + 2;
             if (npix_l < npix_t) npix_l = npix_t;
-            npix_l = (npix_l + 63) / 64 * 64;          // whole 1-KiB copy slots: every lane of every slot copies (setup_tile)
             if (npix_l > MAXS * NW * 64) continue;
             const size_t lds = nwg * ((size_t)2 * npl * npix_l * 16 + (size_t)9 * mt * npl * 1024);
             if (lds > budget) continue;
@@ -964,7 +973,7 @@ int launch_nst(const ConvArgs& a, hipStream_t s) {
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
     const size_t lds = (NST == 1 ? 1 : (NST == 4 ? 4 : 2)) * stage;
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(a.per_xcd * 8, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(a.ntiles, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -1189,12 +1198,15 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     // the kernel's divisions by launch constants, as multiplications (ConvArgs; conv3x3_tile_kernel's prologue)
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
-    a.per_xcd = (a.ntiles + 7) / 8;
-    a.m_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);          // (divisor 1: 2^32 does not fit — udiv_magic skips the multiply)
-    a.m_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    a.xcd_q = a.ntiles / 8;
+    a.xcd_r = a.ntiles % 8;
+    a.m_tx = a.tiles_x == 1 ? 0 : (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);     // (divisor 1: 2^32 does not fit — udiv_magic adds n * i instead)
+    a.m_ty = a.tiles_y == 1 ? 0 : (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    a.i_tx = a.tiles_x == 1;
+    a.i_ty = a.tiles_y == 1;
     a.m_P = ((1u << 20) + a.P - 1) / a.P;
     a.m_ups = ((1u << 16) + ups - 1) / ups;
-    a.nslots = a.NPIX_L / 64;
+    a.nslots = (a.NPIX_L + 63) / 64;
     a.ncg_out = (a.cout + 7) >> 3;
     if (d->H + 2 >= 32768 || d->W + 2 >= 32768 || ups > 8 || (long long)a.ntiles * a.tiles_x >= 0x100000000ll) return ESR_E_UNSUPPORTED;
     {

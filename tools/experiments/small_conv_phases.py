@@ -3,8 +3,8 @@ written by tools/experiments/trace_conv.py / trace_conv_mixed.py into gpurun_out
 
     python tools/experiments/small_conv_phases.py 128_32:8[:lead] [64_32:4 ...]          # name:chunks[:lead]
 
-lead = stamps between the entry stamp and chunk 0's first stamp (0: the round-4 kernels and the single-stage form; 1: the two-stage form since
-round 5, whose K loop starts with a pass that only issues chunk 0 and seeds the accumulators).
+lead = stamps between the entry stamp and chunk 0's first stamp (0: the round-4 kernels; 3: the round-5 kernels, which stamp the end of the tile
+decode, of the first chunk's copy issue and of the accumulator seed).
 
 Per workgroup (wave 0's stamps, shader-clock cycles): entry -> first step stamp (tile set-up, and the prologue copies of the two-stage
 form), per chunk [copy issue, landing wait, barrier, MFMAs, barrier], the epilogue; plus the 100 MHz wall stamps at entry / exit."""
@@ -28,6 +28,10 @@ for arg in sys.argv[1:]:
     c = np.median(clk) * 1e3              # cycles per us
     pro = T[:, 1 + lead] - T[:, 0]
     print('  set-up (entry -> first step stamp)   %6.0f cycles  %.2f us' % (pro.mean(), pro.mean() / c))
+    if lead == 3:                         # round-5 kernels: entry | tile decode + slot offsets | first copies issued | seed + epilogue coordinates
+        for i, nm in enumerate(['tile decode, slot offsets', "first chunk's copies issued", 'seed + epilogue coordinates']):
+            d = T[:, i + 1] - T[:, i]
+            print('    %-30s %6.0f cycles' % (nm, d.mean()))
     names = ['issue', 'wait', 'bar1', 'mfma', 'bar2']
     tot_k = 0
     for i, nm in enumerate(names):
