@@ -18,6 +18,24 @@ namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Workgroup -> (tile column, tile row, image plane) for the tiled kernels.  Workgroups are dispatched in linear order (x fastest), round-robin
+// over the 8 XCDs, each with its own L2: XCD x sweeps a CONTIGUOUS run of the row-major (plane, tile row, tile column) order, so that the
+// window overlap of neighbouring tiles (1.45x of g for the x4 downscale) is served by the L2 that fetched it (round 4 counters: 0.299 GB
+// fetched for 0.135 GB of g, L2 hit rate 4 % with the linear order).
+struct TileId { int bx, by; long long bz; };
+__device__ __forceinline__ TileId xcd_tile() {
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned xcd = lin & 7, q = total >> 3, r = total & 7;
+    const unsigned t = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+    const unsigned row = t / nx;
+    TileId id;
+    id.bx = (int)(t - row * nx);
+    id.bz = row / ny;
+    id.by = (int)(row - (unsigned)id.bz * ny);
+    return id;
+}
+
 __global__ void cem_downscale_kernel(const float* __restrict__ y, int h, int w, int sf, int pre, const float* __restrict__ taps, int k,
                                      const float* __restrict__ lr, int lr_pad, float* __restrict__ d, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,6 +310,23 @@ __global__ __launch_bounds__(256) void cem_upscale_tiled_kernel(const float* __r
 }
 
 
+// sum_{c < k} t[c] * at(c) with four accumulators: four scalar tap loads and four LDS reads in flight per step.  (Round 5 also tried the taps
+// held across the lanes of a register and read with v_readlane — no memory access per tap: the lrfilter ran 2.3x SLOWER, 38 -> 86 us at
+// configs[1]; the scalar cache serves these 17..45 words without a miss and its loads pipeline.)
+template <typename At>
+__device__ __forceinline__ float tap_sum(const float* __restrict__ t, const int k, At at) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= k; c += 4) {
+        a0 = fmaf(t[c], at(c), a0);
+        a1 = fmaf(t[c + 1], at(c + 1), a1);
+        a2 = fmaf(t[c + 2], at(c + 2), a2);
+        a3 = fmaf(t[c + 3], at(c + 3), a3);
+    }
+    for (; c < k; ++c) a0 = fmaf(t[c], at(c), a0);
+    return (a0 + a1) + (a2 + a3);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Separable fast path.  The bicubic ds_kernel and its inv_hTh are rank one (sigma_2 / sigma_1 ~ 1e-16), taps[a][b] = tv[a]*th[b]:
 // every filter is a horizontal pass followed by a vertical one (or the reverse) on the tile a workgroup holds in LDS — 2k instead of k^2 MACs
@@ -350,12 +385,13 @@ __global__ __launch_bounds__(256) void cem_lrfilter_sep_kernel(const float* __re
 template <int SFT>
 __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __restrict__ y, int h, int w, int sf_rt, int pre, const float* __restrict__ tv,
                                                               const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
-                                                              float* __restrict__ d, int qpitch, int rows) {
-    extern __shared__ float tile[];          // [sf][rows][qpitch] de-interleaved window (as cem_downscale_tiled_kernel) | horizontal pass [rows][DT + 1]
+                                                              float* __restrict__ d, int qpitch, int rows, int hpp) {
+    extern __shared__ float tile[];          // [sf][rows][qpitch] de-interleaved window (as cem_downscale_tiled_kernel) | horizontal pass [rows][hpp]
     const int sf = SFT ? SFT : sf_rt;
     const int p = k / 2, Hh = h * sf, Wh = w * sf;
-    const int j0 = blockIdx.x * DT, i0 = blockIdx.y * DT;
-    const long long bc = blockIdx.z;
+    const TileId id = xcd_tile();
+    const int j0 = id.bx * DT, i0 = id.by * DT;
+    const long long bc = id.bz;
     const float* src = y + bc * Hh * (long long)Wh;
     const int Yb = sf * i0 + pre - p, Xb = sf * j0 + pre - p;
     const int cols = (DT - 1) * sf + k;
@@ -365,7 +401,7 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
         // the window [rows][cols] as 16-byte vectors of 4 columns starting at a multiple of 4 (rows of a contiguous fp32 image whose width is a
         // multiple of 4 are 16-byte aligned); vectors that stick out of the image row, or an unaligned image, take four clamped scalar loads.
         // SB vectors per thread are in flight together; each lands as four LDS words in the de-interleaved planes.
-        constexpr int SB = 4;
+        constexpr int SB = 8;                                 // (x4, k = 17: the 77-row window is 6.3 vectors per thread — one round trip, not two)
         const int Xa = (Xb >> 2) << 2;                       // floor to a multiple of 4 (arithmetic shift: also for negative Xb)
         const int nvec = (Xb + cols - Xa + 3) >> 2;
         const bool vec_ok = (Wh & 3) == 0 && (((size_t)src) & 15) == 0;
@@ -400,28 +436,26 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
     }
     __syncthreads();
     const int tx = threadIdx.x & 15;
-    for (int r = threadIdx.x >> 4; r < rows; r += 16) {       // horizontal (strided) pass: 16 kept columns of every window row
-        float a0 = 0.f, a1 = 0.f;
-        for (int ph = 0; ph < sf; ++ph) {
-            const float* pl = tile + (ph * rows + r) * qpitch + tx;
-            int c = ph, q = 0;
-#pragma unroll 4
-            for (; c + sf < k; c += 2 * sf, q += 2) { a0 = fmaf(th[c], pl[q], a0); a1 = fmaf(th[c + sf], pl[q + 1], a1); }
-            if (c < k) a0 = fmaf(th[c], pl[q], a0);
-        }
-        hp[r * (DT + 1) + tx] = a0 + a1;
+    // horizontal (strided) pass: 16 kept columns of every window row.  The two 16-lane halves of a 32-lane LDS group take rows r and r + sf:
+    // with sf * qpitch = sf * hpp = 16 (mod 32) (chosen by the host) their reads of the window planes and their writes of the pass's output fall on
+    // disjoint banks — consecutive rows collided on 12 of 32 banks (round-4 counters: 49 % of the LDS cycles were conflict cycles)
+    const int half16 = (threadIdx.x >> 4) & 1, pi0 = threadIdx.x >> 5;         // pair index inside a step of 8 pairs
+    const int npairs = (rows + 2 * sf - 1) / (2 * sf) * sf;
+    for (int pi = pi0; pi < npairs; pi += 8) {
+        const int blk = SFT ? pi / SFT : pi / sf;
+        const int r = blk * 2 * sf + (pi - blk * sf) + half16 * sf;
+        if (r >= rows) continue;
+        // window column c of row r sits in plane c % sf at column c / sf
+        const float* base = tile + r * qpitch + tx;
+        const int pstride = rows * qpitch;
+        hp[r * hpp + tx] = tap_sum(th, k, [&](const int c) { const int q = SFT ? c / SFT : c / sf; return base[(c - q * sf) * pstride + q]; });
     }
     __syncthreads();
     const int ty = threadIdx.x >> 4;
     const int i = i0 + ty, j = j0 + tx;
     if (i < h && j < w) {
-        const float* col = hp + ty * sf * (DT + 1) + tx;
-        float a0 = 0.f, a1 = 0.f;
-        int a = 0;
-#pragma unroll 4
-        for (; a + 1 < k; a += 2) { a0 = fmaf(tv[a], col[a * (DT + 1)], a0); a1 = fmaf(tv[a + 1], col[(a + 1) * (DT + 1)], a1); }
-        if (a < k) a0 = fmaf(tv[a], col[a * (DT + 1)], a0);
-        float acc = a0 + a1;
+        const float* col = hp + ty * sf * hpp + tx;
+        float acc = tap_sum(tv, k, [&](const int a) { return col[a * hpp]; });
         if (lr) {
             const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
             acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
@@ -577,16 +611,39 @@ __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* 
 template <bool TWO, int SFT>
 __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf_rt, int pre,
                                                             const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
-                                                            int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc) {
-    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [UT_Y][wc] | vertical pass 2
+                                                            int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc, int vp) {
+    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [UT_Y][vp] | vertical pass 2 | tv[k] | th[k]   (vp = 16 mod 32: two rows of a 32-lane group on disjoint banks)
     float* const w1 = sm;
     float* const w2 = w1 + wr * wc;
     float* const v1 = w2 + (TWO ? wr * wc : 0);
-    float* const v2 = v1 + UT_Y * wc;
+    float* const v2 = v1 + UT_Y * vp;
     const int sf = SFT ? SFT : sf_rt;
     const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
-    const long long bc = blockIdx.z;
-    const int xo0 = blockIdx.x * UT_X, yo0 = blockIdx.y * UT_Y;
+    const TileId id = xcd_tile();
+    const long long bc = id.bz;
+    const int xo0 = id.bx * UT_X, yo0 = id.by * UT_Y;
+    // the taps in LDS: both passes index them per lane (the polyphase offset depends on the output row / column) — through global memory that
+    // was one vector load per tap and output
+    float* const tvs = v2 + (TWO ? UT_Y * vp : 0);
+    float* const ths = tvs + k;
+    for (int e = threadIdx.x; e < 2 * k; e += 256) tvs[e] = e < k ? tv[e] : th[e - k];
+    // (what the horizontal pass's thread needs of g — 4 consecutive output columns of one row — is requested NOW: its memory round trip runs under
+    // the window staging and both passes instead of after them)
+    static_assert(UT_Y * (UT_X / 4) == 256, "one quad of output columns per thread");
+    const int ry = threadIdx.x / (UT_X / 4), xo = xo0 + 4 * (threadIdx.x % (UT_X / 4));
+    const int yq = yo0 + ry;
+    const bool live = xo < Wo && yq < Ho;
+    const int Y = yq + crop;
+    const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
+    const float* gp = (mode >= 1 && live) ? g + (bc * Hh + Y) * (long long)Wh + xo + crop : nullptr;
+    const bool full = xo + 3 < Wo;
+    const bool vec_g = live && full && mode >= 1 && ((((size_t)gp) & 15) == 0);
+    float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec_g) { const float4 t = *(const float4*)gp; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
+    else if (mode >= 1 && live) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[t] = gp[t];
+    }
     const int fy = yo0 + crop - p - pre, fx = xo0 + crop - p - pre;
     const int ib = (fy >= 0 ? fy / sf : -((-fy + sf - 1) / sf)), jb = (fx >= 0 ? fx / sf : -((-fx + sf - 1) / sf));
     const float* s1 = f + bc * h * (long long)w;
@@ -600,48 +657,35 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
     }
     __syncthreads();
     for (int e = threadIdx.x; e < UT_Y * wc; e += 256) {      // vertical pass
-        const int ry = e / wc, c = e - ry * wc;
-        const int Y = yo0 + ry + crop;
+        const int ry1 = e / wc, c = e - ry1 * wc;
+        const int Y1 = yo0 + ry1 + crop;
         float u1 = 0.f, u2 = 0.f;
-        if (Y < Hh) {
-            int a0 = (pre + p - Y) % sf; if (a0 < 0) a0 += sf;
-            int il = (Y + a0 - p - pre) / sf - ib;
+        if (Y1 < Hh) {
+            int a0 = (pre + p - Y1) % sf; if (a0 < 0) a0 += sf;
+            int il = (Y1 + a0 - p - pre) / sf - ib;
             for (int a = a0; a < k; a += sf, ++il) {
-                const int yy = Y + a - p;
+                const int yy = Y1 + a - p;
                 if (yy < 0 || yy >= Hh) continue;
-                u1 = fmaf(tv[a], w1[il * wc + c], u1);
-                if (TWO) u2 = fmaf(tv[a], w2[il * wc + c], u2);
+                const float ta = tvs[a];
+                u1 = fmaf(ta, w1[il * wc + c], u1);
+                if (TWO) u2 = fmaf(ta, w2[il * wc + c], u2);
             }
             if (pre == 0)
-                for (int a = 0; Y + a - p < 0 && a < k; ++a) {
-                    u1 = fmaf(tv[a], w1[-ib * wc + c], u1);
-                    if (TWO) u2 = fmaf(tv[a], w2[-ib * wc + c], u2);
+                for (int a = 0; Y1 + a - p < 0 && a < k; ++a) {
+                    u1 = fmaf(tvs[a], w1[-ib * wc + c], u1);
+                    if (TWO) u2 = fmaf(tvs[a], w2[-ib * wc + c], u2);
                 }
         }
-        v1[e] = u1;
-        if (TWO) v2[e] = u2;
+        v1[ry1 * vp + c] = u1;
+        if (TWO) v2[ry1 * vp + c] = u2;
     }
     __syncthreads();
     // horizontal pass: a thread owns 4 consecutive output columns of one row (16 rows x 16 quads = the 256 threads): g comes in and the
     // result goes out as 16-byte vectors when the rows are 16-byte aligned (else element by element)
-    static_assert(UT_Y * (UT_X / 4) == 256, "one quad of output columns per thread");
-    const int ry = threadIdx.x / (UT_X / 4), xo = xo0 + 4 * (threadIdx.x % (UT_X / 4));
-    const int yq = yo0 + ry;
-    if (xo >= Wo || yq >= Ho) return;
-    const int Y = yq + crop;
-    const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
-    const float* gp = mode >= 1 ? g + (bc * Hh + Y) * (long long)Wh + xo + crop : nullptr;
-    const bool full = xo + 3 < Wo;
-    const bool vec_g = full && mode >= 1 && ((((size_t)gp) & 15) == 0);
+    if (!live) return;
     const bool vec_o = full && (((size_t)(out + idx)) & 15) == 0 && (mode != 3 || (((size_t)(out2 + idx)) & 15) == 0);
-    float gv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec_g) { const float4 t = *(const float4*)gp; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
-    else if (mode >= 1) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[t] = gp[t];
-    }
-    const float* r1 = v1 + ry * wc;
-    const float* r2 = v2 + ry * wc;
+    const float* r1 = v1 + ry * vp;
+    const float* r2 = v2 + ry * vp;
     float res[4], res2[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -652,13 +696,14 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
         for (int b = b0; b < k; b += sf, ++jl) {
             const int xx = X + b - p;
             if (xx < 0 || xx >= Wh) continue;
-            u1 = fmaf(th[b], r1[jl], u1);
-            if (TWO) u2 = fmaf(th[b], r2[jl], u2);
+            const float tb = ths[b];
+            u1 = fmaf(tb, r1[jl], u1);
+            if (TWO) u2 = fmaf(tb, r2[jl], u2);
         }
         if (pre == 0)
             for (int b = 0; X + b - p < 0 && b < k; ++b) {
-                u1 = fmaf(th[b], r1[-jb], u1);
-                if (TWO) u2 = fmaf(th[b], r2[-jb], u2);
+                u1 = fmaf(ths[b], r1[-jb], u1);
+                if (TWO) u2 = fmaf(ths[b], r2[-jb], u2);
             }
         res2[t] = 0.f;
         if (mode == 0) res[t] = u1;
@@ -800,18 +845,22 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
         }
     }
     const int rows = (DT - 1) * sf + k, qcols = (rows + sf - 1) / sf + 1;
-    int qpitch = qcols;
+    // pitches of the window planes and of the horizontal pass's output: rows sf apart on disjoint halves of the 32 banks (possible for sf = 2^n
+    // and 3; see the kernel's horizontal pass)
+    int qpitch = qcols, hpp = DT;
     while ((sf * qpitch) % 32 != 16 && qpitch < qcols + 32) ++qpitch;
     if ((sf * qpitch) % 32 != 16) qpitch = qcols | 1;
-    const size_t lds = ((size_t)sf * rows * qpitch + (size_t)rows * (DT + 1)) * 4;
+    while ((sf * hpp) % 32 != 16 && hpp < DT + 32) ++hpp;
+    if ((sf * hpp) % 32 != 16) hpp = DT + 1;
+    const size_t lds = ((size_t)sf * rows * qpitch + (size_t)rows * hpp) * 4;
     if (lds > 150 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     ESR_CLEAR_ERR();
-    void (*kern)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int) =
+    void (*kern)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int, int) =
         sf == 2 ? cem_downscale_sep_kernel<2> : sf == 3 ? cem_downscale_sep_kernel<3> : sf == 4 ? cem_downscale_sep_kernel<4> : sf == 8 ? cem_downscale_sep_kernel<8>
                                                                                                                               : cem_downscale_sep_kernel<0>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((w + DT - 1) / DT, (h + DT - 1) / DT, B * C), dim3(256), lds, (hipStream_t)stream, y, h, w, sf, pre, tv, th, k, lr, lr_pad, d,
-                       qpitch, rows);
+                       qpitch, rows, hpp);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
@@ -837,12 +886,13 @@ extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C
     if ((mode >= 1 && !g) || (mode >= 2 && !f2) || (mode == 3 && !out2)) return ESR_E_ARG;
     const int wr = (UT_Y + 2 * (k / 2)) / sf + 3, wc = (UT_X + 2 * (k / 2)) / sf + 3;
     const int two = mode >= 2 ? 2 : 1;
-    const size_t lds = ((size_t)two * wr * wc + (size_t)two * UT_Y * wc) * 4;
+    const int vp = wc + (16 - wc % 32 + 32) % 32;                       // pass-1 row pitch = 16 (mod 32)
+    const size_t lds = ((size_t)two * wr * wc + (size_t)two * UT_Y * vp + 2 * (size_t)k) * 4;
     if (lds > 60 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
     const dim3 tg((Wo + UT_X - 1) / UT_X, (Ho + UT_Y - 1) / UT_Y, B * C);
     ESR_CLEAR_ERR();
-    typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int);
+    typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int);
     up_t kern;
     if (mode >= 2)
         kern = sf == 2 ? cem_upscale_sep_kernel<true, 2> : sf == 3 ? cem_upscale_sep_kernel<true, 3> : sf == 4 ? cem_upscale_sep_kernel<true, 4>
@@ -850,7 +900,7 @@ extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C
     else
         kern = sf == 2 ? cem_upscale_sep_kernel<false, 2> : sf == 3 ? cem_upscale_sep_kernel<false, 3> : sf == 4 ? cem_upscale_sep_kernel<false, 4>
                : sf == 8 ? cem_upscale_sep_kernel<false, 8> : cem_upscale_sep_kernel<false, 0>;
-    hipLaunchKernelGGL(kern, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2, wr, wc);
+    hipLaunchKernelGGL(kern, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2, wr, wc, vp);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
