@@ -275,6 +275,8 @@ def main(argv=None):
     if world > 1 or 'WORLD_SIZE' in os.environ:        # under a launcher the collectives run whatever the world size is (one rank: RCCL all the same)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        from esr_hip import dist as D
+        D.SINGLE_RANK_COLLECTIVES = True                # under a launcher this file runs the collectives whatever N is (N = 1: RCCL all the same)
         if select_backend(os.environ) == 'gloo':
             dist.init_process_group(backend='gloo')
         else:

@@ -107,6 +107,8 @@ struct ConvArgs {
     long long kz_slab;              // floats between two slabs
     int nchw_ctot;                  // channels of the fp32 NCHW destination (== cout unless the launch covers output slices)
     int stages_hint;                // esr_conv3x3_desc.lds_stages
+    unsigned* range_flag;           // esr_conv3x3_desc.range_flag / range_tag (fp16 formats)
+    unsigned range_tag;
 #ifdef ESR_TRACE
     unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
 #endif
@@ -486,6 +488,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     constexpr int RQ = ALL_FIRST ? R : 1;
     ResRaw q1[HAS_R1 ? RQ : 1][MT * 2], q2[HAS_R2 ? RQ : 1][MT * 2];
     uint4 qm[HAS_MK ? RQ : 1][MT * 2];
+    unsigned big = 0;              // fp16 range watch: bit 15 / 31 set once a stored half had magnitude >= 2^15 (exponent field >= 30, inf and NaN included)
     auto issue = [&](const int r) {
         const int rq = ALL_FIRST ? r : 0;
 #pragma unroll
@@ -592,6 +595,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t h = cvt_pk<FMT>(v[k][j].x, v[k][j].y);
                         hi[k][j] = h;
+                        if constexpr (FMT == 1) big |= (h & 0x7FFF7FFFu) + 0x08000800u;      // 15-bit magnitude >= 0x7800 carries into the half's top bit
                         lo[k][j] = 0;
                         if (NPL == 2) lo[k][j] = cvt_pk<FMT>(v[k][j].x - e2f<FMT>(h & 0xFFFF), v[k][j].y - e2f<FMT>(h >> 16));
                     }
@@ -621,6 +625,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 }
             }
         }
+    }
+    if constexpr (FMT == 1 && !NCHW) {
+        if (a.range_flag && (big & 0x80008000u)) atomicMin(a.range_flag, a.range_tag);      // (no lane gets here in a pass that stays in range)
     }
 }
 
@@ -1236,6 +1243,8 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     a.mask_slope = d->mask_slope;
     a.reverse = d->reverse_order;
     a.stages_hint = (d->lds_stages == 1 || d->lds_stages == 2) ? d->lds_stages : 0;
+    a.range_flag = f16 ? d->range_flag : nullptr;
+    a.range_tag = d->range_tag;
     a.ps = ps;
     a.ps_rg0 = d->ps_rowgroup0;
 #ifdef ESR_TRACE

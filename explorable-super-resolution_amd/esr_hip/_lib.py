@@ -26,7 +26,8 @@ class Conv3x3Desc(C.Structure):
                 ('mask_src', ActView), ('mask_cg0', C.c_int32), ('mask_cg1', C.c_int32), ('mask_slope', C.c_float),
                 ('reverse_order', C.c_int32), ('weight_planes', C.c_int32), ('in1_lo_groups', C.c_int32),
                 ('pixel_shuffle', C.c_int32), ('ps_rowgroup0', C.c_int32), ('tap_mask_k', C.c_int32 * 4), ('tap_mask_k_shift', C.c_int32),
-                ('tap_mask_m', C.c_int32 * 4), ('k_split_ws', C.c_void_p), ('k_split_ws_floats', C.c_int64), ('lds_stages', C.c_int32)]
+                ('tap_mask_m', C.c_int32 * 4), ('k_split_ws', C.c_void_p), ('k_split_ws_floats', C.c_int64), ('lds_stages', C.c_int32),
+                ('range_flag', C.c_void_p), ('range_tag', C.c_uint32)]
 
 
 class WgradDesc(C.Structure):

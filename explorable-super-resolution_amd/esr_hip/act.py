@@ -464,10 +464,41 @@ def reset_launch_parity():
     _launch_parity = 0
 
 
+class RangeWatch:
+    """fp16 range watch of one pass (esr_conv3x3_desc.range_flag / range_tag): one device word, initialised to -1 (0xFFFFFFFF), that every
+    launch of the pass whose stored values reach 2^15 (or are not finite) lowers to its own tag = its index in `names`."""
+
+    def __init__(self, device):
+        self.flag = torch.full((1,), -1, dtype=torch.int32, device=device)
+        self.names = []
+
+
+_range_watch = None
+
+
+class watching:
+    """with watching(w): every conv3x3() launch issued (or recorded) inside carries w's flag word and the next tag."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def __enter__(self):
+        global _range_watch
+        self.prev, _range_watch = _range_watch, self.w
+        return self.w
+
+    def __exit__(self, *exc):
+        global _range_watch
+        _range_watch = self.prev
+
+
 def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0,
             out=None, out2=None, out_nchw=None, use_bias=True, mask_src=None, mask_cg=(0, 0), mask_slope=0.2, reverse=None, in1_lo_groups=0,
-            pixel_shuffle=0, ps_rowgroup0=0, tap_mask_k=None, tap_mask_k_shift=0, tap_mask_m=None, k_split_ws=None):
+            pixel_shuffle=0, ps_rowgroup0=0, tap_mask_k=None, tap_mask_k_shift=0, tap_mask_m=None, k_split_ws=None, name=None):
     d = _lib.Conv3x3Desc()
+    if _range_watch is not None:
+        d.range_flag, d.range_tag = _range_watch.flag.data_ptr(), len(_range_watch.names)
+        _range_watch.names.append(name or 'conv %d' % len(_range_watch.names))
     d.in0 = in0 if in0 is not None else NO_VIEW
     d.in1 = in1
     d.upsample = upsample

@@ -385,7 +385,8 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx = _ConvT.apply(ctx.eng, ctx.L, dy, w) if ctx.needs_input_grad[2] else None
         dw = db = None
-        if (ctx.needs_input_grad[3] or (ctx.has_b and ctx.needs_input_grad[4])) and not _state['input_grad_only']:
+        # (the per-layer graph carries no state object: a hint scoped to another graph — input_grad_only(of=...) — must not reach it)
+        if (ctx.needs_input_grad[3] or (ctx.has_b and ctx.needs_input_grad[4])) and not (_state['input_grad_only'] and _state['only'] is None):
             dw, db = _WGrad.apply(ctx.eng, ctx.L, dy, x)
         return None, None, dx, dw, (db if ctx.has_b else None)
 

@@ -13,12 +13,18 @@ import torch
 import torch.distributed as dist
 
 
+# A one-rank group runs no collectives unless this is set (init_from_env(single_rank=True) sets it; bench.py and the RCCL tests do, so that the
+# one-GPU box the tests have executes the RCCL code path itself — with one rank every collective is the identity, results are bit-identical to
+# the plain single process).  A single-GPU job that merely inherits launcher variables (torchrun --nproc-per-node 1, SLURM) pays nothing.
+SINGLE_RANK_COLLECTIVES = False
+
+
 def is_distributed():
-    """True once a process group exists — ALSO at world size 1: a job started by a launcher (torchrun / bench.py --gpus N) runs the same
-    collectives whatever N is, so that the one-GPU box the tests have executes the RCCL code path itself (with one rank every collective
-    is the identity: results are bit-identical to the plain single process, tests/test_gpu_dist.py).  A plain process without a launcher has
-    no group and skips them."""
-    return dist.is_available() and dist.is_initialized()
+    """True when this process takes part in collectives: a process group exists and has more than one rank — or has one and
+    SINGLE_RANK_COLLECTIVES is set."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES
 
 
 def rank():
@@ -29,10 +35,16 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun-style env vars (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+def init_from_env(backend=None, single_rank=False):
+    """Initialise the default process group from torchrun-style env vars (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  WORLD_SIZE <= 1 creates
+    no group (nothing to exchange) unless single_rank=True, which also switches the one-rank collectives on (SINGLE_RANK_COLLECTIVES)."""
+    global SINGLE_RANK_COLLECTIVES
     if 'WORLD_SIZE' not in os.environ or 'RANK' not in os.environ or (dist.is_available() and dist.is_initialized()):
         return                    # not under a launcher (plain single process), or already initialised
+    if int(os.environ['WORLD_SIZE']) <= 1:
+        if not single_rank:
+            return
+        SINGLE_RANK_COLLECTIVES = True
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:

@@ -62,6 +62,11 @@ class RRDBEngine:
         self._ptr_fp, self._ptr_epoch = None, 0   # parameter storages the recorded descriptors point into; epoch moves when any changes
         self.generation = 0  # bumped by invalidate(): consumers that cache derived state (GraphedForward) compare it
         self._ev = None      # optional (start, end) torch.cuda.Event pair bracketing the conv launches of one forward (bench.py)
+        # fp16 range watch (precisions 'f16', 'f16x2', 'mixed'): the forward's conv launches report the first layer whose stored activations
+        # reach 2^15 or are not finite into one device word (A.RangeWatch); it is copied to pinned host memory behind every forward and looked at
+        # without synchronising at the start of the next one — or, synchronising, by check_range().  The reference's fp32 path has no such cliff
+        # (codes/models/modules/architecture.py:278-302): leaving the range raises EsrError naming the layer instead of returning inf / NaN images.
+        self._watch, self._watch_host, self._watch_ev = None, None, None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
@@ -70,12 +75,57 @@ class RRDBEngine:
         split = {'split': True, 'bf16': False, 'f16': 'f16', 'f16x2': 'f16x2', 'mixed': 'mixed'}[precision]
         if split != self.split:
             self.split = split
+            if self._watch is not None:        # a pending range verdict belongs to the precision that is being left
+                self._watch.flag.fill_(-1)
+                self._watch_host.fill_(-1)
+                self._watch_ev = None
             self._packed = None
             self._packed_t = None
             self._packed_rdb_t = None
             self._bufs = {}
             self._packs_fp = None
             self._pack_sets += 1
+
+    # ------------------------------------------------------------------ fp16 range watch
+    def _watching(self, device):
+        if self.split not in ('f16', 'f16x2', 'mixed'):
+            return None
+        if self._watch is None or self._watch.flag.device != device:
+            self._watch = A.RangeWatch(device)
+            self._watch_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+            self._watch_ev = None
+        return self._watch
+
+    def _post_range(self):
+        """Behind a forward's launches: the flag word on its way to the host (asynchronous; nothing waits for it here)."""
+        if self._watch is None or A._rec() is not None or torch.cuda.is_current_stream_capturing():
+            return
+        self._watch_host.copy_(self._watch.flag, non_blocking=True)
+        self._watch_ev = torch.cuda.Event()
+        self._watch_ev.record()
+
+    def check_range(self, wait=True):
+        """Raise EsrError if a forward since the last check stored fp16 activations of magnitude >= 2^15 (or inf / NaN).  wait=False looks only
+        at what has already arrived on the host (no synchronisation: what the next forward does by itself); wait=True waits for the last
+        forward's flag first — call it where a result is consumed (RRDBNet.forward callers that hand images on, bench.py after its timed loop)."""
+        ev = self._watch_ev
+        if self._watch is None or ev is None or torch.cuda.is_current_stream_capturing():
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._watch_ev = None
+        tag = int(self._watch_host[0])
+        if tag == -1:
+            return
+        names = self._watch.names
+        name = names[tag] if 0 <= tag < len(names) else 'launch %d' % tag
+        self._watch.flag.fill_(-1)
+        self._watch_host.fill_(-1)
+        raise EsrError("precision %r: the activations stored by layer '%s' reached fp16's last binade (|x| >= 32768) or are not finite — the "
+                       "fp16 modes cannot hold this network's range; use set_precision('split') (fp32-class) or 'bf16'" % (
+                           self.split if isinstance(self.split, str) else 'split', name))
 
     # ------------------------------------------------------------------ weights
     def invalidate(self):
@@ -333,19 +383,28 @@ class RRDBEngine:
         sf, has_lat, lat1 = self._check(x)
         B, Ct, h0, w0 = x.shape
         self.packed()                         # weight packs refreshed here, outside any recording: replays assume current packs
+        self.check_range(wait=False)          # an earlier forward's verdict, if it has arrived
+        watch = self._watching(x.device)
         bufs = self._buffers(B, h0 + 2 * pad, w0 + 2 * pad, x.device, keep)
         g = torch.empty(B, net.out_nc, sf * (h0 + 2 * pad), sf * (w0 + 2 * pad), dtype=torch.float32, device=x.device)
         if not self.use_plans or bufs.get('_ephemeral') or A._rec() is not None:
-            self._forward_launches(x, pad, keep, bufs, g)
+            if watch is not None:
+                watch.names = []
+            with A.watching(watch):
+                self._forward_launches(x, pad, keep, bufs, g)
+            self._post_range()
             return g, bufs
         key = self._plan_key('fwd', tuple(x.shape), pad, keep)
         plan = bufs['_plans'].get(key)
         if plan is None:
             rec = A.Recorder({'x': x, 'g': g})
-            with A.recording(rec):
+            if watch is not None:
+                watch.names = []              # (every forward of this network issues the same launches in the same order: one name list serves all plans)
+            with A.recording(rec), A.watching(watch):
                 self._forward_launches(x, pad, keep, bufs, g)
             plan = bufs['_plans'][key] = rec.finish()
         plan.run({'x': x, 'g': g})
+        self._post_range()
         return g, bufs
 
     def _forward_launches(self, x, pad, keep, bufs, g):
@@ -382,7 +441,7 @@ class RRDBEngine:
             return rdb[j] if keep is True else rdb[j % 3]
 
         # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
-        conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, 8) if net.nb else None)
+        conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, 8) if net.nb else None, name='fea_conv')
         # 'mixed': the dense blocks' intermediate activations (outputs of convs 0-3, read only inside their RDB) are ONE fp16 plane; only
         # the RDB input (groups 0:8, the residual stream) keeps hi+lo.  Their lo planes are never written (they stay zero).
         mixed = self.split == 'mixed'
@@ -399,17 +458,17 @@ class RRDBEngine:
                 for i in range(4):
                     o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
                     conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
+                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
-                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), **lo_c4)
+                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
                 else:         # RRDB output: 0.2*(0.2*conv5 + x) + x_rrdb   (block.py:270); lands in the next RRDB's first buffer
                     # (inference: that is rrdb_in's own buffer when the three buffers rotate; the kernel's in-place residual is safe)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.04, res1=buf.view(0, 8), beta1=0.2,
-                         res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8), **lo_c4)
+                         res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
         last = buf_of(nrdb).view(0, 8) if net.nb else bufs['fea'].view()
         # LR_conv + trunk shortcut (block.py:96)
-        conv(pk['lr_conv'], last, B, h, w, 64, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view())
+        conv(pk['lr_conv'], last, B, h, w, 64, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view(), name='LR_conv')
         # upsamplers: nearest xs folded into the conv's input read
         src, s = bufs['trunk'], 1
         for j in range(self.n_up):
@@ -417,11 +476,11 @@ class RRDBEngine:
             s *= f
             if self._pshuf:     # conv 64 -> 64*f^2 at the INPUT resolution, pixel shuffle folded into the store, LeakyReLU before it (it commutes)
                 for q in range(f * f):
-                    conv(pk['up%d' % j, q], src.view(), B, s // f * h, s // f * w, 64, act_slope=0.2, out=bufs['ups'][j].view(), pixel_shuffle=f, ps_rowgroup0=8 * q)
+                    conv(pk['up%d' % j, q], src.view(), B, s // f * h, s // f * w, 64, act_slope=0.2, out=bufs['ups'][j].view(), pixel_shuffle=f, ps_rowgroup0=8 * q, name='upconv%d' % j)
             else:
-                conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view())
+                conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view(), name='upconv%d' % j)
             src = bufs['ups'][j]
-        conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view())
+        conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view(), name='HR_conv0')
         conv(pk['hr1'], bufs['hr0'].view(), B, H, W, net.out_nc, in0=zhr, out_nchw=g)
         A.host_op(lambda ctx: self._ev and self._ev[1].record())
 

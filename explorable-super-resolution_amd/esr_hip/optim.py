@@ -52,7 +52,7 @@ class Adam(torch.optim.Optimizer):
                     self.state[p]['step'] = first
             t = float(first) + 1
             # everything the uploaded table points at: parameters, gradients AND both moment tensors (load_state_dict replaces the latter)
-            fp = tuple((p.data_ptr(), g.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p, g in zip(ps, grads))
+            fp = tuple((p.data_ptr(), g.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr(), p.numel()) for p, g in zip(ps, grads))
             # a few tables per group, keyed by the pointer fingerprint: gradient storages typically alternate between two or three addresses
             # (the allocator hands back the blocks of the step before last), and a table that is still on the device costs nothing
             cache = self._tables.setdefault(gi, {})
@@ -64,9 +64,14 @@ class Adam(torch.optim.Optimizer):
                     a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
                 need = _lib.lib.esr_adam_workspace_bytes(arr, len(ps))
                 _lib.check(min(need, 0), 'esr_adam_workspace_bytes')
+                ws = None
                 if len(cache) >= 4:
-                    cache.pop(next(iter(cache)))          # (oldest entry; its workspace is freed stream-ordered by the caching allocator)
-                ws = torch.empty(int(need), dtype=torch.uint8, device=ps[0].device)
+                    old = cache.pop(next(iter(cache)))    # oldest entry: its device workspace is taken over when it is large enough
+                    if old[1].numel() >= int(need) and old[1].device == ps[0].device:
+                        ws = old[1]                       # (stream-ordered: the table copy below queues behind the launch that last read it; the pinned
+                                                          # block is NOT reused — the host would overwrite it while an earlier copy may still be queued)
+                if ws is None:
+                    ws = torch.empty(int(need), dtype=torch.uint8, device=ps[0].device)
                 # the table goes through PINNED host memory and an asynchronous copy on the step's stream: gradient tensors are new storages
                 # every step more often than not (autograd hands over the buffers the backward pass produced), and a blocking upload here
                 # stalled the host until the whole backward pass had run — the next step's launches then started from an idle GPU

@@ -284,6 +284,10 @@ class SRRaGANModel(BaseModel):
         else:
             self.fake_H = self.netG(self.model_input)
         self.output_image = 1 * self.fake_H
+        G = self.netG.module if hasattr(self.netG, 'module') else self.netG
+        G = getattr(G, 'generated_image_model', G)
+        if hasattr(G, 'check_range'):
+            G.check_range()                    # fp16 precisions: an image built from saturated activations is an error, not a result
         self.netG.train()
 
     # ------------------------------------------------------------------ training step (reference :280-521)
@@ -300,24 +304,34 @@ class SRRaGANModel(BaseModel):
             gc.unfreeze()
             self._gc_frozen = False
 
-    def _D_fall_back(self, reason):
-        """network_D.engine = 'auto' leaving the library's kernels for the stock nn.Module: never silently."""
+    def _D_fall_back(self, reason, permanent=True):
+        """network_D.engine = 'auto' leaving the library's kernels for the stock nn.Module: never silently.  permanent=False: for this call only
+        (an input size the kernels do not run — a ragged validation crop); the engine stays for the sizes it covers."""
         import logging
-        self.D_engine, self.D_engine_fallback = None, reason
-        msg = "network_D.engine = 'auto': the critic runs as the stock nn.Module on MIOpen, NOT on libesr_hip (%s)" % reason
-        logging.getLogger('base').warning(msg)
-        print('WARNING: ' + msg)
+        if permanent:
+            self.D_engine = None
+        first = self.D_engine_fallback != reason
+        self.D_engine_fallback = reason
+        if first:                              # (a per-call fallback repeats: one line per distinct reason, not one per batch)
+            msg = "network_D.engine = 'auto': the critic runs as the stock nn.Module on MIOpen, NOT on libesr_hip (%s)%s" % (
+                reason, '' if permanent else ' — for inputs of this size only')
+            logging.getLogger('base').warning(msg)
+            print('WARNING: ' + msg)
 
-    def _D_engine_for(self, x):
-        """The critic engine if it runs inputs of x's size (CriticEngine.unsupported_input), else the documented fallback / error."""
+    def _D_engine_for(self, xs):
+        """The critic engine if it runs inputs of the sizes of `xs` (a tensor or a list of them; CriticEngine.unsupported_input), else the
+        documented fallback for THIS call (the engine is kept: later batches of a supported size run on it again) / the error."""
         if self.D_engine is None:
             return None
-        reason = self.D_engine.unsupported_input(x.shape[-2], x.shape[-1])
-        if reason is not None:
-            if self.D_engine_mode == 'hip':
-                raise EsrError("network_D.engine = 'hip': " + reason)
-            self._D_fall_back(reason)
-            return None
+        for x in (xs if isinstance(xs, (list, tuple)) else (xs,)):
+            reason = self.D_engine.unsupported_input(x.shape[-2], x.shape[-1])
+            if reason is not None:
+                if self.D_engine_mode == 'hip':
+                    raise EsrError("network_D.engine = 'hip': " + reason)
+                self._D_fall_back(reason, permanent=False)
+                return None
+        if self.D_engine_fallback is not None and self.D_engine_mode != 'stock':
+            self.D_engine_fallback = None      # back on the library's kernels
         self.D_engine.set_precision('bf16' if self.D_dtype is torch.bfloat16 else 'split')
         return self.D_engine
 
@@ -336,7 +350,7 @@ class SRRaGANModel(BaseModel):
     def _D_group(self, xs):
         """[self._D(x) for x in xs] — on the library's kernels as ONE pass over the concatenated batches (same values: every batch keeps its own
         BatchNorm statistics, the running statistics see them in this order; esr_hip.critic.critic_forward_group)."""
-        eng = self._D_engine_for(xs[0])
+        eng = self._D_engine_for(xs)
         if eng is not None:
             return critic_forward_group(eng, xs)
         return [self._D(x) for x in xs]

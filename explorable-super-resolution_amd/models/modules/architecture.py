@@ -90,6 +90,13 @@ class RRDBNet(nn.Module):
         assert precision in ('split', 'mixed', 'f16x2', 'f16', 'bf16')
         self.engine.set_precision(precision)
 
+    def check_range(self, wait=True):
+        """fp16 precisions ('mixed', 'f16x2', 'f16'): raise EsrError if a forward since the last check stored activations that reached fp16's last
+        binade or are not finite, naming the first such layer (esr_hip/engine.py: RRDBEngine.check_range; the kernels report it without an
+        extra pass).  A forward looks at what has arrived by itself, without synchronising; call this where a result is consumed."""
+        if self._engine is not None:
+            self._engine.check_range(wait=wait)
+
     def invalidate_packs(self):
         """Call after editing parameters through `.data` (such writes bypass torch's version counters, which is what the engine watches)."""
         if self._engine is not None:

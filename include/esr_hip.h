@@ -137,6 +137,13 @@ typedef struct {
     /* scheduling hint, no effect on the result: 0 = the library picks the form by launch size (launches with no more workgroups than CUs
      * pipeline their own LDS-DMA through two stages, larger ones run two single-stage workgroups per CU); 1 / 2 = force that form. */
     int32_t lds_stages;
+    /* fp16 formats only, optional (NULL: off): range watch.  The reference computes in fp32 (codes/models/modules/block.py:230-235) and has no
+     * magnitude cliff; an fp16 activation plane saturates at 65504.  When a value the launch stores has magnitude >= 32768 (one binade of head
+     * room left) or is not finite, the kernel does atomicMin(*range_flag, range_tag) — no extra pass, nothing on the path of a launch that stays
+     * in range.  The caller initialises the word to 0xFFFFFFFF, gives every launch of a pass its own tag (its index) and reads the word when it
+     * consumes the pass's result: the smallest tag names the first layer that left the range. */
+    uint32_t* range_flag;
+    uint32_t range_tag;
 } esr_conv3x3_desc;
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);

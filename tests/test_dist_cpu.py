@@ -160,3 +160,30 @@ def test_grad_buckets_reduce_in_place_out_of_the_flat_gradient_buffer():
         assert sub_in_place == 1
         assert np.allclose(flat2[lo:hi], 4.5)                       # the subset: mean of 3 and 6, in place
         assert np.allclose(flat2[:lo], own) and np.allclose(flat2[hi:], own)     # its neighbours in the same buffer: untouched
+
+
+def _worker_single_rank(port, q):
+    for p in (ROOT, os.path.join(ROOT, 'explorable-super-resolution_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    from esr_hip import dist as D
+    D.init_from_env(backend='gloo')                # launcher variables of a one-rank job: no group, no collectives
+    a = (dist.is_initialized(), D.is_distributed())
+    D.init_from_env(backend='gloo', single_rank=True)        # the explicit opt-in of bench.py / the RCCL tests
+    b = (dist.is_initialized(), D.is_distributed(), D.all_reduce_mean_scalar(3.5))
+    dist.destroy_process_group()
+    q.put((a, b))
+
+
+def test_a_single_rank_job_runs_no_collectives_unless_asked_to():
+    """ADVICE r4: WORLD_SIZE = 1 in the environment (torchrun --nproc-per-node 1, SLURM) must not cost a process group and per-step collectives;
+    init_from_env(single_rank=True) is the opt-in that keeps the collective code path testable on one GPU."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_single_rank, args=(_free_port(), q))
+    p.start()
+    a, b = q.get(timeout=120)
+    p.join(30)
+    assert a == (False, False)
+    assert b == (True, True, 3.5)

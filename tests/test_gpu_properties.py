@@ -208,6 +208,7 @@ def test_headline_precision_against_the_oracle_over_weight_scales(full, kind, ga
     on the same weights for the record: its one-plane dense-block operands cost it accuracy as the gain grows, and fp16 cannot hold the
     activations of the gain-2.0 set at all (they reach 1e9)."""
     from oracle import rrdb_oracle as ro
+    from esr_hip import EsrError
     cem, G, x, _ = full
     net = G.generated_image_model
     backup = {k: v.detach().clone() for k, v in G.state_dict().items()}
@@ -223,6 +224,13 @@ def test_headline_precision_against_the_oracle_over_weight_scales(full, kind, ga
             net.set_precision(prec)
             with torch.no_grad():
                 got = net(x[:1], pad=10).cpu()
+            if prec == 'mixed' and kind == 'formula' and gain == 2.0:
+                # fp16 cannot hold these activations: the kernels' range watch names the first layer that left the range
+                with pytest.raises(EsrError, match='reached fp16'):
+                    net.check_range()
+                net.check_range()                 # the verdict is consumed: nothing pending
+            else:
+                net.check_range()                 # everything else stays in range
             res[prec] = (float((got - ref).abs().max() / ref.abs().max()), float((got - ref).norm() / ref.norm()))
         print('%s gain %s: |out|max %.3g; split rel-max %.2e rel-l2 %.2e; mixed rel-max %.2e rel-l2 %.2e' % ((kind, gain, float(ref.abs().max())) + res['split'] + res['mixed']))
         assert res['split'][0] <= 3e-4 and res['split'][1] <= 1e-4, res['split']

@@ -97,7 +97,7 @@ def _worker(rank, world, port, what, q):
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                           HSA_ENABLE_IPC_MODE_LEGACY='0')
         from esr_hip import dist as D
-        D.init_from_env()                         # default backend with a GPU: 'nccl' (= RCCL), device_id = cuda:LOCAL_RANK
+        D.init_from_env(single_rank=True)         # default backend with a GPU: 'nccl' (= RCCL), device_id = cuda:LOCAL_RANK; one rank: collectives ON
         import torch.distributed as dist
         info = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'device': torch.cuda.current_device(),
                 'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version())}

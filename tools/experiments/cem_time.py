@@ -1,6 +1,6 @@
 """The CEM filter kernels and the fused projection at the configs[1] size (x4 bicubic, 32 x 128x128 -> 512x512, G output on the padded 148x148
 frame = 592x592) and at the configs[4] size (x8, 'blurry_cubic_2.0': 45x45 / 35x35 taps, 16 x 256x256 -> 2048x2048).
-ESR_CEM_SEPARABLE=0 times the general 2-D kernels instead of the separable fast path."""
+esr_hip.cem_ops.USE_SEPARABLE = False times the general 2-D kernels instead of the separable fast path (the ESR_CEM_SEPARABLE variable of round 2 is no longer read)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd')); sys.path.insert(0, ROOT)

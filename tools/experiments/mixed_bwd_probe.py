@@ -1,5 +1,5 @@
 """Input-gradient accuracy of the precision modes against the reference's golden gradients (fixture F4) and, at full depth (RRDB-23,
-kaiming x0.1 weights), against autograd through the fp32 CPU oracle.  ESR_MIXED_BWD=bf16|f16 selects the data-gradient format of 'mixed'."""
+kaiming x0.1 weights), against autograd through the fp32 CPU oracle.  RRDBEngine.mixed_bwd = 'bf16' | 'f16' selects the data-gradient format of 'mixed' (the ESR_MIXED_BWD variable of round 2 is no longer read)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'explorable-super-resolution_amd')); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
