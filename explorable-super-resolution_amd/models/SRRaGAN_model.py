@@ -4,13 +4,14 @@ packing.  What is reproduced:
   * Prepare_Input: [Z viewed as B x (lat*sf^2) x h x w | LR] (raw view, :230-236); GetLatent; feed_data's Z sampling (:244-278)
   * test(): eval mode (CEM pre-padding) with or without autograd (:523-531); Output_Batch
   * optimize_parameters() (:280-521): gradient accumulation, the D / G step gating (D_init_iters, D_update_ratio, D_verification
-    'current' / 'past'), the discriminator step (relativistic or plain; vanilla / lsgan / wgan-gp with the gradient penalty's double
+    'current' / 'past' / 'convergence'), the discriminator step (relativistic or plain; vanilla / lsgan / wgan-gp with the gradient penalty's double
     backward through D), the generator step (pixel, range, GAN and optimal-Z reference losses; the optimal-Z dual step runs
     Z_optimizer through the frozen generator), Adam for both — with G's and D's gradients all-reduced over RCCL when several ranks
     run (one process per GPU) instead of nn.DataParallel
   * perform_validation / save_log / save / load (G, D, optimizers, logs.npz) through BaseModel (positional checkpoint loading)
-Not reproduced, and refused loudly: the VGG-feature loss (define_F needs torchvision), FilterLoss (train.latent_weight), the
-'convergence' D-verification and the LR-rollback heuristics (:592-632), D_update_ratio given as a controller range.
+  * FilterLoss for train.latent_weight (structure-tensor statistics on the library's kernels, esr_hip/zobj.py)
+Not reproduced, and refused loudly: the VGG-feature loss (define_F needs torchvision), the LR-rollback heuristics (:592-632), D_update_ratio
+given as a controller range.
 """
 import os
 from collections import OrderedDict

@@ -42,7 +42,11 @@ class RRDBNet(nn.Module):
             # the fused kernels implement conv -> LeakyReLU(0.2) (what define_G hard-wires, networks.py:97-99) and nothing else
             raise NotImplementedError("RRDBNet(act_type=%r, mode=%r): the HIP engine implements act_type='leakyrelu', mode='CNA' only" % (act_type, mode))
         if nf != 64 or out_nc < 1 or in_nc < 1:
-            raise NotImplementedError('RRDBNet(nf=%r): the dense-block buffer layout is built for nf = 64, gc = 32 (the reference ignores gc too)' % nf)
+            # not a one-line generalisation: a dense block lives in ONE 24-group activation buffer (8 groups of the block input + 4 x 4 of the
+            # growth convs) whose slices are the MFMA tiles — 32 output channels per conv = one M tile, the 64-channel block output = two —
+            # and the RDB-residual-from-LDS epilogue, the two-slice form of the small launches and the mirrored data gradient all assume it
+            raise NotImplementedError('RRDBNet(nf=%r): the dense-block buffer layout and the MFMA tiling are built for nf = 64, gc = 32 (every '
+                                      'RRDB options file of the reference uses nf = 64; it ignores gc too)' % nf)
 
         fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, return_module_list=True)
         # NB: like the reference (architecture.py:250) the `gc` argument is ignored: growth channels are 32.
