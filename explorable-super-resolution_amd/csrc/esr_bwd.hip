@@ -734,266 +734,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int group, 
 #undef ESR_WG_ISSUE2
 #undef ESR_WTR
 
-// ---- pair form (round 5).  Two (layer, input tile, output tile) blocks of identical geometry per 8-wave workgroup, waves 4p .. 4p+3 = block p.
-// The batched launch above moves 38 GB through LDS-DMA per configs[2] backward — the chip-wide fill rate for the whole 5.3 ms (profiles/
-// r04_wgrad_v11_pmc.json): what bounds it is bytes INTO LDS per MFMA, 265 (a 10 x 34 X tile + an 8 x 32 dY tile per 144 MFMAs).  Blocks that
-// share an operand stage it ONCE:
-//   mode 1 (share X): the two 32-channel halves of a 64-channel layer's output against the same input tile       190 B per MFMA
-//   mode 2 (share dY): two input tiles of a 32-channel layer against the same output gradient                     208 B per MFMA
-//   mode 0: unrelated blocks of the same geometry (odd tiles left over) — no saving, no idle waves
-// One-plane operands, 8 x 32 tiles, no upsampled source, all nine taps (the generator's dense blocks); everything else stays with
-// wgrad_body.  LDS per stage [X0 | X1 | dY0 | dY1] = 75 KiB, two stages; the copies of a shared operand are split between the two blocks'
-// waves so that every wave issues the same number (7 or 8 instead of 10).  Per block the arithmetic — which products, in which order, the
-// four waves' partial sums folded in wave order — is wgrad_body's: results are bit-identical to the unpaired launch.
-constexpr int PAIR_STAGE = 2 * WG_X_BYTES + 2 * WG_Y_BYTES;
-template <int FMT>
-__device__ __forceinline__ void wgrad_pair_body(const WgradArgs* __restrict__ table, const int4 m, unsigned char* const smem) {
-    constexpr int TW = WG_TW, TH = WG_TH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pr = wave8 >> 2, wave = wave8 & 3;                 // block of this wave, wave inside the block
-    const int mode = (m.y >> 28) & 3;
-    // bit 30: the layer's LATENT input tile (<= 3 channels; wgrad_body's one-MFMA-tile form) is folded into its cit == 0 blocks: the same dY
-    // fragment multiplies one more tile per K step, out of a ninth X plane staged where the mode leaves an operand image unused (X1 when X is
-    // shared, dY1 when dY is).  As work items of their own the 345 latent tiles of a generator backward re-streamed every dY tile for one MFMA
-    // per K step: a 2.2 ms launch of pure copies once the main blocks had left for the pair form.
-    const bool fold = (m.y >> 30) & 1;
-    const int e = __builtin_amdgcn_readfirstlane(pr ? m.w : m.x);
-    const int group = __builtin_amdgcn_readfirstlane(pr ? (m.y >> 14) & 0x3FFF : m.y & 0x3FFF), slice = __builtin_amdgcn_readfirstlane(m.z);
-    const WgradArgs a = table[e];
-    const int cit = group / a.mt, cot = group % a.mt;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    // which LDS image this block multiplies out of, and which slots of it this wave copies
-    const int xi = mode == 1 ? 0 : pr, yi = mode == 2 ? 0 : pr;
-    const int xs0 = mode == 1 ? pr * (XSLOTS / 2) : 0, xs1 = mode == 1 ? xs0 + XSLOTS / 2 : XSLOTS;
-    const int ys0 = mode == 2 ? pr * (YSLOTS / 2) : 0, ys1 = mode == 2 ? ys0 + YSLOTS / 2 : YSLOTS;
-
-    f32x16_t acc[9], accb;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accb[i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    const bool do_bias = (cit == 0) && a.db;
-    const bool do_lat = fold && cit == 0;                        // this block also owns the latent tile's products with its dY
-    const int lat_off = mode == 1 ? WG_X_BYTES : 2 * WG_X_BYTES + WG_Y_BYTES;      // the ninth plane inside a stage
-    f32x16_t accl;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accl[i] = 0.f;
-    constexpr uint32_t ONE2 = FMT == ESR_FMT_F16 ? 0x3C003C00u : 0x3F803F80u;
-    const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
-
-    const int li = lane & 15, grp16 = lane >> 4;
-    const int rb2 = (grp16 & 1) * 2 + ((li & 3) >> 1);
-    const int kb = (grp16 >> 1) * 8 + (li >> 2);
-    const int frag_off = kb * 16 + (li & 1) * 8;
-    const int xs_off = xi * WG_X_BYTES + rb2 * XP * 16 + frag_off;
-    const int ys_off = 2 * WG_X_BYTES + yi * WG_Y_BYTES + rb2 * YPP * 16 + frag_off;
-
-    const int xcg = cit * 4 + wave;
-    const bool xhave = xcg < a.x.ncg;
-    const int ycg = cot * 4 + wave;
-    const bool yhave = ycg < a.dy.ncg;
-    int xrel[XSLOTS], yrel[YSLOTS];
-    unsigned vbits = 0;
-    {
-        const int x_last = (a.tiles_x - 1) * TW, y_last = (a.tiles_y - 1) * TH;
-#pragma unroll
-        for (int sl = 0; sl < XSLOTS; ++sl) {
-            const int p = sl * 64 + lane;
-            const int rr = p / (TW + 2), cc = p - rr * (TW + 2);
-            xrel[sl] = rr * a.Wx_p + cc;
-            if (x_last + cc < a.W + 2) vbits |= 1u << (2 * sl);
-            if (y_last + rr < a.H + 2) vbits |= 2u << (2 * sl);
-        }
-#pragma unroll
-        for (int sl = 0; sl < YSLOTS; ++sl) {
-            const int p = sl * 64 + lane;
-            const int rr = p >> 5, cc = p & (TW - 1);
-            yrel[sl] = rr * (a.W + 2) + cc;
-            if (x_last + cc < a.W) vbits |= 1u << (2 * (XSLOTS + sl));
-            if (y_last + rr < a.H) vbits |= 2u << (2 * (XSLOTS + sl));
-        }
-    }
-    int it_tx, it_ty, it_b, d_tx, d_ty, d_b;
-    {
-        const int r1 = slice / a.tiles_x, per = a.tiles_x * a.tiles_y, rem = a.nslices % per;
-        it_tx = slice - r1 * a.tiles_x; it_b = r1 / a.tiles_y; it_ty = r1 - it_b * a.tiles_y;
-        d_b = a.nslices / per; d_ty = rem / a.tiles_x; d_tx = rem - d_ty * a.tiles_x;
-    }
-    // The copies of a tile, in four parts: part q = the copies j = q (mod 4) of the wave's list (j < XSLOTS: X slot j, else dY slot j - XSLOTS).
-    // They are issued BETWEEN the four K steps of the previous tile's MFMAs: an in-order wave is held ~100 cycles by each 1-KiB copy, and the
-    // other wave of its SIMD (the other block's) multiplies meanwhile — with all copies up front and two barriers per tile the eight waves ran
-    // in lockstep and the pair form lost 1.6 ms to the two independent workgroups per CU it replaces (profiles/r05_wgrad_pair_ab.log).
-    auto issue_part = [&](const unsigned st_, const int q) {
-        const int x0_ = it_tx * TW, y0_ = it_ty * TH, b_ = it_b;
-        unsigned um = (it_tx == a.tiles_x - 1 ? 0u : 0x55555555u) | (it_ty == a.tiles_y - 1 ? 0u : 0xAAAAAAAAu);
-        unsigned keep = 0xFFFFFFFFu;
-        if (!xhave) keep &= ~((1u << (2 * XSLOTS)) - 1u);
-        if (!yhave) keep &= (1u << (2 * XSLOTS)) - 1u;
-        const unsigned mk = (vbits | um) & keep;
-        const uint4* const xh_ = a.x.hi + b_ * a.x.bs + (xhave ? xcg : 0) * a.x.cs;
-        const unsigned xd_ = st_ + xi * WG_X_BYTES + wave * XP * 16;
-        const int xb_ = y0_ * a.Wx_p + x0_;
-        const uint4* const yh_ = a.dy.hi + b_ * a.dy.bs + (yhave ? ycg : 0) * a.dy.cs;
-        const unsigned yd_ = st_ + 2 * WG_X_BYTES + yi * WG_Y_BYTES + wave * YPP * 16;
-        const int yb_ = (y0_ + 1) * (a.W + 2) + x0_ + 1;
-#pragma unroll
-        for (int j = 0; j < XSLOTS + YSLOTS; ++j) {
-            if ((j & 3) != q) continue;                          // (q is an unrolled constant at every call site)
-            if (j < XSLOTS) {
-                const int sl = j;
-                if (sl < xs0 || sl >= xs1) continue;             // uniform: the other block's waves copy the rest of a shared tile
-                const unsigned vo = ((mk >> (2 * sl)) & 3u) == 3u ? (unsigned)(xrel[sl] + xb_) * 16u : 0u;
-                if (sl * 64 + lane < XP) glds16ws(xh_, vo, xd_ + sl * 1024);
-            } else {
-                const int sl = j - XSLOTS;
-                if (sl < ys0 || sl >= ys1) continue;
-                const unsigned vo = ((mk >> (2 * (XSLOTS + sl))) & 3u) == 3u ? (unsigned)(yrel[sl] + yb_) * 16u : 0u;
-                glds16ws(yh_, vo, yd_ + sl * 1024);
-            }
-        }
-        if (q == 3 && fold && wave8 < XSLOTS) {                  // the latent plane (one channel group): slot w by wave w of the workgroup
-            // (same geometry as an X slot: the wave's own validity bits for slot `wave8` are in vbits only if wave8 is one of ITS slots — they
-            // all are: every wave computed all XSLOTS of them above)
-#pragma unroll
-            for (int sl = 0; sl < XSLOTS; ++sl) {
-                if (sl != wave8) continue;
-                const unsigned okb = ((vbits | um) >> (2 * sl)) & 3u;
-                const unsigned vo = okb == 3u ? (unsigned)(xrel[sl] + xb_) * 16u : 0u;
-                const uint4* const lh_ = a.xlat.hi + b_ * a.xlat.bs;
-                if (sl * 64 + lane < XP) glds16ws(lh_, vo, st_ + lat_off + sl * 1024);
-            }
-        }
-    };
-    auto issue_step = [&]() {
-        it_tx += d_tx;
-        if (it_tx >= a.tiles_x) { it_tx -= a.tiles_x; ++it_ty; }
-        it_ty += d_ty;
-        if (it_ty >= a.tiles_y) { it_ty -= a.tiles_y; ++it_b; }
-        it_b += d_b;
-    };
-    int cur = 0;
-    if (slice < ntiles) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_part(lds0, q);
-        issue_step();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ONE barrier per tile: behind it every wave has finished reading stage `cur` (its MFMAs of this tile) and has seen its own copies of the next
-    // tile land in the other stage
-    for (int tile = slice; tile < ntiles; tile += a.nslices) {
-        const bool more = tile + a.nslices < ntiles;
-        const unsigned nst_ = lds0 + (cur ^ 1) * PAIR_STAGE;
-        const unsigned char* const sx = smem + cur * PAIR_STAGE + xs_off;
-        const unsigned char* const sy = smem + cur * PAIR_STAGE + ys_off;
-#pragma unroll
-        for (int rq = 0; rq < WG_TH / 4; ++rq) {
-            const int rr = wave + rq * 4;
-#pragma unroll
-            for (int ks = 0; ks < WG_TW / 16; ++ks) {
-                const uint4 fa = frag_tr(sy + (rr * WG_TW + ks * 16) * 16);
-                if (do_bias) accb = mfma_e<FMT>(fa, ones, accb);
-                if (do_lat) {
-                    // B fragment by gather (wgrad_body's LATK form): this lane's column n = lane & 31 -> (tap n / 3, channel n % 3); its 8 K values
-                    // are pixels kblk * 8 .. + 7 of the K step at that tap's shift
-                    const int n = lane & 31, tcol = n < 27 ? n / 3 : 8, ccol = n < 27 ? n % 3 : 0;
-                    const unsigned char* const g0 = smem + cur * PAIR_STAGE + lat_off + ((rr + tcol / 3) * (TW + 2) + ks * 16 + (lane >> 5) * 8 + tcol % 3) * 16 + ccol * 2;
-                    uint32_t w[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        w[q] = (uint32_t)(*(const unsigned short*)(g0 + (2 * q) * 16)) | ((uint32_t)(*(const unsigned short*)(g0 + (2 * q + 1) * 16)) << 16);
-                    accl = mfma_e<FMT>(fa, make_uint4(w[0], w[1], w[2], w[3]), accl);
-                }
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const uint4 fb = frag_tr(sx + ((rr + t / 3) * (TW + 2) + ks * 16 + t % 3) * 16);
-                    acc[t] = mfma_e<FMT>(fa, fb, acc[t]);
-                }
-                if (more) issue_part(nst_, rq * 2 + ks);
-            }
-        }
-        if (more) issue_step();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-    // ---- fold each block's four waves through LDS (three passes of four accumulator tiles: 8 waves x 4 x 4 KiB = 128 KiB), then dW / db
-    // (nslices == 1: the block is this workgroup's alone) or this slice's partial tiles, exactly as wgrad_body
-    float* const red = (float*)smem;                             // [wave of the workgroup][tile in pass][16][64]
-    const bool direct = a.nslices == 1;
-    float* const wsp = direct ? nullptr : a.ws + ((size_t)group * a.nslices + slice) * (9 * 1024);
-    const int tp = tid & 255;                                    // thread inside the block
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-        const int t0 = pass * 4, nt = pass < 2 ? 4 : 1;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (t < nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[((wave8 * 4 + t) * 16 + i) * 64 + lane] = acc[t0 + t][i];
-        if (pass == 2 && do_bias)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) red[((wave8 * 4 + 1) * 16 + i) * 64 + lane] = accb[i];
-        if (pass == 2 && do_lat)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) red[((wave8 * 4 + 2) * 16 + i) * 64 + lane] = accl[i];
-        __syncthreads();
-        const float* const rp = red + pr * 4 * 4 * 1024;          // this block's four waves
-        for (int el = tp; el < nt * 1024; el += 256) {
-            float v = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += rp[w4 * 4 * 1024 + el];
-            if (direct) {
-                const int ln = el & 63, i = (el >> 6) & 15, t = t0 + (el >> 10);
-                const int co = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
-                const int c = ln & 31;
-                const int ci = cit * 32 + c < a.cin_main ? a.lat + cit * 32 + c : -1;
-                if (co < a.cout && ci >= 0) a.dw[((long long)co * a.cin_total + ci) * 9 + t] += a.alpha * v;
-            } else {
-                wsp[t0 * 1024 + el] = v;
-            }
-        }
-        if (pass == 2 && do_bias && tp < 32) {
-            const int row = tp, i = (row & 3) + 4 * (row >> 3), ln = ((row >> 2) & 1) * 32;
-            float v = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += rp[((w4 * 4 + 1) * 16 + i) * 64 + ln];
-            if (direct) { if (cot * 32 + row < a.cout) a.db[cot * 32 + row] += a.alpha * v; }
-            else a.ws[(size_t)a.ngroups * a.nslices * (9 * 1024) + ((size_t)cot * a.nslices + slice) * 32 + row] = v;
-        }
-        if (pass == 2 && do_lat) {
-            // the latent tile: column n = (tap n / 3, channel n % 3), scattered to where the nine-tap form puts the same numbers (dW, or the
-            // partial tiles of the layer's latent group for this output tile) — as wgrad_body<..., LATK>
-            float* const wl = direct ? nullptr : a.ws + ((size_t)(a.ncit_main * a.mt + cot) * a.nslices + slice) * (9 * 1024);
-            for (int el = tp; el < 1024; el += 256) {
-                float v = 0.f;
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) v += rp[(w4 * 4 + 2) * 1024 + el];
-                const int ln = el & 63, i = el >> 6, n = ln & 31, half = ln >> 5;
-                if (n >= 27) continue;
-                const int t = n / 3, c = n % 3;
-                if (c >= a.lat) continue;
-                const int co = cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (direct) { if (co < a.cout) a.dw[((long long)co * a.cin_total + c) * 9 + t] += a.alpha * v; }
-                else wl[t * 1024 + i * 64 + half * 32 + c] = v;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-template <int FMT>
-__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_pair_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int4 m = map[blockIdx.x];
-    if (m.x < 0) return;                                         // padding of the XCD-aware order (uniform)
-    wgrad_pair_body<FMT>(table, m, smem);
-}
-
 // s2d (WgradArgs.tapmode == 1): the layer is a stride-2 conv run as a 3x3 conv over the space-to-depth input (esr_hip/critic.py): main input
 // tile i (one 32-channel quad of one parity) has non-zero weights only at the taps S2D_TAPS[i & 3] — five copies of the body, picked by a
 // uniform switch, each with its tap set as a compile-time constant
@@ -1212,7 +952,7 @@ static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
         b.nwg += (int64_t)p.ngroups * p.nslices;
         b.partial_floats += wgrad_partial_floats(p);
     }
-    b.nwg = (b.nwg + 64 + 1023) / 1024 * 1024;                  // map entries: the two work lists (single blocks, pairs), each padded to whole rounds of the XCD-aware order
+    b.nwg = (b.nwg + 1023) / 1024 * 1024;                       // map entries: the work items padded to whole rounds of the XCD-aware order
     b.table_bytes = (((int64_t)n * sizeof(WgradArgs)) + 255) / 256 * 256;
     b.map_bytes = ((b.nwg * (int64_t)sizeof(int4)) + 255) / 256 * 256;
     return b;
@@ -1276,80 +1016,41 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
     const BatchPlan b = batch_plan(descs, n);
     std::vector<WgradArgs> table(n);
-    std::vector<int4> work;                                      // single blocks (wgrad_body), in their natural order (layer, slice, group)
-    std::vector<int4> pairs;                                     // pairs of blocks (wgrad_pair_body): (entry 0, group 0 | group 1 << 14 | mode << 28, slice, entry 1)
+    std::vector<int4> work;                                      // the work list in its natural order (layer, slice, group)
     work.reserve((size_t)b.nwg);
     const bool shapes = batch_is_s2d(descs, n);
     float* partials = (float*)((char*)workspace + b.table_bytes + b.map_bytes);
     int64_t pf = 0;
     int max_red = 0;
-    struct Single { int e, g; long long key; };
-    std::vector<Single> odd;                                     // main-tile blocks without a partner inside their own layer
-    auto add_pair = [&](int e0, int g0, int e1, int g1, int mode, int nslices) {
-        for (int sl = 0; sl < nslices; ++sl) pairs.push_back(make_int4(e0, g0 | (g1 << 14) | (mode << 28), sl, e1));
-    };
     for (int i = 0; i < n; ++i) {
         const WgradPlan p = batch_entry_plan(&descs[i], b.unit, shapes);
         table[i] = wgrad_args(&descs[i], p, partials + pf);
         pf += wgrad_partial_floats(p);
+        entry_work(i, p, work);
         if (p.nslices > 1 && p.ngroups * 9 * 1024 + p.mt * 32 > max_red) max_red = p.ngroups * 9 * 1024 + p.mt * 32;
-        // the pair form (wgrad_pair_body) takes the main-input blocks of plain one-plane layers: both halves of a 64-channel output against one
-        // input tile, or two input tiles of a 32-channel output against one dY tile; what is left over pairs up across layers of equal geometry
-        const WgradArgs& a = table[i];
-        const bool pairable = !split && a.ups == 1 && a.tapmode == 0 && p.shape == 0 && p.mt <= 2 && p.ngroups < (1 << 14) && p.ncit_main > 0;
-        if (!pairable) { entry_work(i, p, work); continue; }
-        const long long key = ((long long)p.tiles_x * p.tiles_y * descs[i].B << 20) | p.nslices;
-        // the latent tile rides with the cit == 0 blocks when those run as a sharing pair (bit 30 of the mode word; wgrad_pair_body)
-        const bool fold = a.latk && p.ncit > p.ncit_main && (p.mt == 2 || p.ncit_main >= 2);
-        if (p.mt == 2) {
-            for (int cit = 0; cit < p.ncit_main; ++cit) add_pair(i, cit * 2, i, cit * 2 + 1, 1 | ((fold && cit == 0) ? 4 : 0), p.nslices);
-        } else {
-            int cit = 0;
-            for (; cit + 1 < p.ncit_main; cit += 2) add_pair(i, cit, i, cit + 1, 2 | ((fold && cit == 0) ? 4 : 0), p.nslices);
-            if (cit < p.ncit_main) odd.push_back(Single{i, cit, key});
-        }
-        if (!fold)
-            for (int sl = 0; sl < p.nslices; ++sl)               // a latent tile that found no sharing pair stays a block of its own (wgrad_body)
-                for (int g = p.ncit_main * p.mt; g < p.ngroups; ++g) work.push_back(make_int4(i, g, sl, 0));
     }
-    {
-        // leftovers: consecutive entries of equal (tile count, slices) share a workgroup without sharing data; a last one runs alone
-        std::vector<char> used(odd.size(), 0);
-        for (size_t u = 0; u < odd.size(); ++u) {
-            if (used[u]) continue;
-            size_t v = u + 1;
-            while (v < odd.size() && (used[v] || odd[v].key != odd[u].key)) ++v;
-            const int ns = table[odd[u].e].nslices;
-            if (v < odd.size()) { used[v] = 1; add_pair(odd[u].e, odd[u].g, odd[v].e, odd[v].g, 0, ns); }
-            else for (int sl = 0; sl < ns; ++sl) work.push_back(make_int4(odd[u].e, odd[u].g, sl, 0));
-        }
-    }
-    // Order of the work lists over the XCDs.  The hardware deals workgroup b to XCD b % 8, so the groups of one layer (same dY tiles for a cot, same
+    // Order of the work list over the XCDs.  The hardware deals workgroup b to XCD b % 8, so the groups of one layer (same dY tiles for a cot, same
     // X tiles for a cit: neighbours in the list) run on eight different L2s: 25 GB of L2 misses per configs[2] launch (bf16) for 1.9 GB of distinct
     // operands, hit rate 32 %.  Handing each XCD runs of `run` consecutive items cuts the misses (9 vs 12.5 M FETCH_SIZE units at a whole eighth per
     // XCD) — and does NOT buy time: 6.26 (dealt) / 6.10 (runs of 4) / 6.20 (16) / 7.51 (64) / 7.09 ms (an eighth each; the critic's ten unequal
     // layers 0.60 / 0.60 / 0.65 / 0.71 / 1.83 ms): long runs unbalance the XCDs, and the launch is bound by neither the fabric nor the MFMA pipe
     // (37 % busy) but by each workgroup's copy -> wait -> multiply chain.  Runs of 4: the traffic saving that costs nothing.
+    std::vector<int4> map((size_t)b.nwg, make_int4(-1, 0, 0, 0));
+    const int64_t npair = ((int64_t)work.size() + 1023) / 1024 * 1024;       // grid of the launch
+    if (npair > b.nwg) return ESR_E_UNSUPPORTED;
     constexpr int64_t run = 4;
-    const int64_t nsingle = ((int64_t)work.size() + 8 * run - 1) / (8 * run) * (8 * run), npairs = ((int64_t)pairs.size() + 8 * run - 1) / (8 * run) * (8 * run);
-    if (nsingle + npairs > b.nwg) return ESR_E_UNSUPPORTED;
-    std::vector<int4> map((size_t)(nsingle + npairs), make_int4(-1, 0, 0, 0));
-    auto deal = [&](const std::vector<int4>& items, int64_t count, int4* dst) {
-        for (int64_t blk = 0; blk < count; ++blk) {
-            const int64_t xcd = blk % 8, k = blk / 8;
-            const int64_t item = ((k / run) * 8 + xcd) * run + k % run;
-            if (item < (int64_t)items.size()) dst[blk] = items[(size_t)item];
-        }
-    };
-    deal(work, nsingle, map.data());
-    deal(pairs, npairs, map.data() + nsingle);
+    for (int64_t blk = 0; blk < npair; ++blk) {
+        const int64_t xcd = blk % 8, k = blk / 8;
+        const int64_t item = ((k / run) * 8 + xcd) * run + k % run;
+        if (item < (int64_t)work.size()) map[(size_t)blk] = work[(size_t)item];
+    }
     hipStream_t s = (hipStream_t)stream;
     // pageable host memory: the runtime stages it before returning (the vectors go out of scope); a host-blocking copy, not graph-capturable —
     // which is why it is its own entry point: callers upload once per descriptor set and replay esr_conv3x3_wgrad_batch_run
     if (hipMemcpyAsync(workspace, table.data(), (size_t)n * sizeof(WgradArgs), hipMemcpyHostToDevice, s) != hipSuccess) return ESR_E_LAUNCH;
-    if (!map.empty() && hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), map.size() * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
+    if (hipMemcpyAsync((char*)workspace + b.table_bytes, map.data(), (size_t)b.nwg * sizeof(int4), hipMemcpyHostToDevice, s) != hipSuccess)
         return ESR_E_LAUNCH;
-    plan->nwg = nsingle;                                         // grid of the single-block launch; its map is followed by the pairs' (plan->reserved entries)
+    plan->nwg = npair;
     plan->table_bytes = b.table_bytes;
     plan->n = n;
     plan->max_red = max_red;
@@ -1357,34 +1058,26 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
     plan->f16 = descs[0].dy.fmt == ESR_FMT_F16 ? 1 : 0;
     plan->s2d = 0;
     for (const WgradArgs& t : table) plan->s2d |= t.tapmode == 1 ? 1 : 0;
-    plan->reserved = (int32_t)npairs;
+    plan->reserved = 0;
     return ESR_OK;
 }
 
 extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
-    if (!workspace || !plan || plan->n <= 0 || plan->nwg < 0 || plan->reserved < 0 || plan->nwg + plan->reserved <= 0) return ESR_E_ARG;
+    if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = plan->f16 != 0, split = plan->split != 0;
-    const int4* const map = (const int4*)((const char*)workspace + plan->table_bytes);
+    const int nst = wgrad_stages(!split);
+    void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
+                                             : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
+                                                     : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
+    if (plan->s2d && !f16)        // some layers are space-to-depth embedded stride-2 convs: the variant that skips their zero blocks
+        k = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0, true> : conv3x3_wgrad_batch_kernel<2, 1, 0, true>)
+                  : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0, true> : conv3x3_wgrad_batch_kernel<1, 1, 0, true>);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
-    if (plan->reserved > 0) {                                    // the paired blocks first: the longer launch
-        void (*kp)(const WgradArgs*, const int4*) = f16 ? conv3x3_wgrad_pair_kernel<1> : conv3x3_wgrad_pair_kernel<0>;
-        (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kp, dim3((unsigned)plan->reserved), dim3(512), 2 * PAIR_STAGE, s, (const WgradArgs*)workspace, map + plan->nwg);
-        ESR_CHECK_LAUNCH();
-    }
-    if (plan->nwg > 0) {
-        const int nst = wgrad_stages(!split);
-        void (*k)(const WgradArgs*, const int4*) = f16 ? (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 1> : conv3x3_wgrad_batch_kernel<1, 1, 1>)
-                                                 : split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0> : conv3x3_wgrad_batch_kernel<2, 1, 0>)
-                                                         : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0> : conv3x3_wgrad_batch_kernel<1, 1, 0>);
-        if (plan->s2d && !f16)        // some layers are space-to-depth embedded stride-2 convs: the variant that skips their zero blocks
-            k = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0, true> : conv3x3_wgrad_batch_kernel<2, 1, 0, true>)
-                      : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0, true> : conv3x3_wgrad_batch_kernel<1, 1, 0, true>);
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
-        hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace, map);
-        ESR_CHECK_LAUNCH();
-    }
+    hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,
+                       (const int4*)((const char*)workspace + plan->table_bytes));
+    ESR_CHECK_LAUNCH();
     if (plan->max_red > 0) {
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((plan->max_red + 255) / 256), (unsigned)plan->n), dim3(256), 0, s,
                            (const WgradArgs*)workspace);
