@@ -231,6 +231,9 @@ def parse_args(argv=None):
                     help="c2 default 'split' (headline): bf16 hi+lo operands in every product; 'mixed': fp16 one-MFMA dense blocks, reported in the "
                          "alt_precision block.  c3 default 'bf16' (configs[2] names bf16)")
     ap.add_argument('--batch', type=int, default=BATCH, help='experiments only: the headline workload is batch 32')
+    ap.add_argument('--early-exchange', action='store_true',
+                    help="c3, N > 1 (or one rank under a launcher): exchange the generator's gradients bucket by bucket from INSIDE the backward pass "
+                         "(one weight-gradient launch per bucket, each followed by its all-reduce: esr_hip.dist.EarlyBucketReducer) instead of after it")
     ap.add_argument('--no-extra-workloads', action='store_true',
                     help="skip the short configs[2] / configs[4] runs appended (after the headline's timed region) as `extra_workloads`")
     return ap.parse_args(argv)
@@ -496,6 +499,8 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     import models
     from esr_hip import dist as D
     precision = args.precision or 'bf16'
+    if getattr(args, 'early_exchange', False):
+        D.EarlyBucketReducer.ENABLED = True
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         model = models.create_model(bench_paths.make_opt(True, with_D=True))
@@ -538,6 +543,8 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
             'config': {'workload': 'configs[2] per-GPU shape: SRRaGANModel.optimize_parameters(), G+D step, %d crops of 52x52 (HR 208x208, latent 3) per GPU' % B,
                        'global_batch': B * world, 'parallelism': 'dp%d (G and D gradients all-reduced over RCCL)' % world},
             'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],
+            'gradient_exchange': ('inside the backward, %d buckets' % model.grad_reducer.early_buckets) if model.grad_reducer.early_buckets else
+                                 ('after the backward, %d buckets' % len(model.grad_reducer.buckets) if dist is not None else 'none (one process)'),
             'phases_ms': split_ms, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
             'roofline': {'bound': 'mfma', 'kernel': 'generator convs (forward + data gradient + weight gradient)', 'achieved': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 1e12,
                          'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 2.5e15, 'traffic': None,

@@ -938,7 +938,7 @@ static void entry_work(int i, const WgradPlan& p, std::vector<int4>& pairs) {
     for (int sl = 0; sl < p.nslices; ++sl)
         for (int g = 0; g < p.ngroups; ++g) pairs.push_back(make_int4(i, g, sl, 0));
 }
-static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
+static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n, int64_t unit_override = 0) {
     BatchPlan b{};
     int64_t work = 0;
     const bool shapes = batch_is_s2d(descs, n);
@@ -947,6 +947,7 @@ static BatchPlan batch_plan(const esr_wgrad_desc* descs, int n) {
         work += (int64_t)p.ngroups * p.tiles_x * p.tiles_y * descs[i].B;
     }
     b.unit = work / 768 > 0 ? work / 768 : 1;
+    if (unit_override > 0) b.unit = unit_override;      // the slicing of a LARGER set this one is a part of (esr_conv3x3_wgrad_batch_unit)
     for (int i = 0; i < n; ++i) {
         const WgradPlan p = batch_entry_plan(&descs[i], b.unit, shapes);
         b.nwg += (int64_t)p.ngroups * p.nslices;
@@ -996,16 +997,32 @@ extern "C" int esr_conv3x3_wgrad(const esr_wgrad_desc* d, esr_stream_t stream) {
     return ESR_OK;
 }
 
-extern "C" int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc* descs, int n) {
+static int64_t batch_workspace_bytes(const esr_wgrad_desc* descs, int n, int64_t unit) {
+    if (!descs || n <= 0 || unit < 0) return ESR_E_ARG;
+    for (int i = 0; i < n; ++i)
+        if (descs[i].B <= 0 || descs[i].H <= 0 || descs[i].W <= 0 || descs[i].cout <= 0 || descs[i].cin_main <= 0) return ESR_E_ARG;
+    const BatchPlan b = batch_plan(descs, n, unit);
+    return b.table_bytes + b.map_bytes + (b.partial_floats + 1) * 4;
+}
+extern "C" int64_t esr_conv3x3_wgrad_batch_workspace_bytes(const esr_wgrad_desc* descs, int n) { return batch_workspace_bytes(descs, n, 0); }
+extern "C" int64_t esr_conv3x3_wgrad_batch_part_workspace_bytes(const esr_wgrad_desc* descs, int n, int64_t unit) { return batch_workspace_bytes(descs, n, unit); }
+extern "C" int64_t esr_conv3x3_wgrad_batch_unit(const esr_wgrad_desc* descs, int n) {
     if (!descs || n <= 0) return ESR_E_ARG;
     for (int i = 0; i < n; ++i)
         if (descs[i].B <= 0 || descs[i].H <= 0 || descs[i].W <= 0 || descs[i].cout <= 0 || descs[i].cin_main <= 0) return ESR_E_ARG;
-    const BatchPlan b = batch_plan(descs, n);
-    return b.table_bytes + b.map_bytes + (b.partial_floats + 1) * 4;
+    return batch_plan(descs, n).unit;
 }
 
+static int batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan, int64_t unit, esr_stream_t stream);
 extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                               esr_stream_t stream) {
+    return batch_upload(descs, n, workspace, workspace_bytes, plan, 0, stream);
+}
+extern "C" int esr_conv3x3_wgrad_batch_part_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
+                                                   int64_t unit, esr_stream_t stream) {
+    return unit > 0 ? batch_upload(descs, n, workspace, workspace_bytes, plan, unit, stream) : ESR_E_ARG;
+}
+static int batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan, int64_t unit, esr_stream_t stream) {
     if (!descs || n <= 0 || !workspace || !plan) return ESR_E_ARG;
     const bool split = descs[0].dy.lo != nullptr;
     for (int i = 0; i < n; ++i) {
@@ -1013,8 +1030,8 @@ extern "C" int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n
         if (rc != ESR_OK) return rc;
         if ((descs[i].dy.lo != nullptr) != split || descs[i].dy.fmt != descs[0].dy.fmt) return ESR_E_ARG;      // one operand format per batch
     }
-    if (workspace_bytes < esr_conv3x3_wgrad_batch_workspace_bytes(descs, n)) return ESR_E_ARG;
-    const BatchPlan b = batch_plan(descs, n);
+    if (workspace_bytes < batch_workspace_bytes(descs, n, unit)) return ESR_E_ARG;
+    const BatchPlan b = batch_plan(descs, n, unit);
     std::vector<WgradArgs> table(n);
     std::vector<int4> work;                                      // the work list in its natural order (layer, slice, group)
     work.reserve((size_t)b.nwg);

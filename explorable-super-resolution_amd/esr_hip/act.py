@@ -707,26 +707,23 @@ _WGB = {}        # fallback cache for callers without an engine: {device index: 
 _WGB_KEEP = 4    # descriptor sets kept per cache (a dual pass / gradient accumulation alternates between a few)
 
 
-def conv3x3_wgrad_batch(descs, device, cache=None):
+def conv3x3_wgrad_batch(descs, device, cache=None, unit=0):
     """All recorded layers' weight gradients in one launch (esr_conv3x3_wgrad_batch_upload / _run).  The caller keeps every dy / x buffer
     alive and unmodified until this returns (the launch is enqueued behind the kernels that produced them).  The descriptor table is
     uploaded only when it differs from the ones already on the device: with pooled gradient buffers and the allocator handing back the same
     dW storage, a steady-state training step re-runs a table that is already there (no host->device copy).  `cache`: the owner's dict (one
     per engine, so that two models — or two streams — never share a table a launch in flight may still be reading); each distinct descriptor
-    set gets its OWN workspace, a small LRU of them is kept."""
+    set gets its OWN workspace, a small LRU of them is kept.  unit > 0: `descs` is one PART of a larger set launched part by part
+    (wgrad_batch_unit of the whole set: every layer's pixel sum is sliced as in the one-launch form, results bit-identical to it)."""
     if not descs:
         return
     arr = (_lib.WgradDesc * len(descs))(*descs)
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    raw = bytes(arr)
+    raw = bytes(arr) + unit.to_bytes(8, 'little')
     entries = (_WGB if cache is None else cache).setdefault(key, [])
     hit = next((e for e in entries if e[0] == raw), None)
     if hit is None:
-        need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, len(descs))
-        check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
-        ws = torch.empty(int(need), dtype=torch.uint8, device=device)
-        plan = _lib.WgradBatchPlan()
-        check(_lib.lib.esr_conv3x3_wgrad_batch_upload(arr, len(descs), ws.data_ptr(), ws.numel(), C.byref(plan), stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
+        ws, plan = wgrad_batch_upload(arr, device, unit)
         hit = (raw, ws, plan)
         entries.insert(0, hit)
         del entries[_WGB_KEEP:]
@@ -734,6 +731,28 @@ def conv3x3_wgrad_batch(descs, device, cache=None):
         entries.remove(hit)
         entries.insert(0, hit)
     check(_lib.lib.esr_conv3x3_wgrad_batch_run(hit[1].data_ptr(), C.byref(hit[2]), stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
+
+
+def wgrad_batch_unit(descs):
+    """The slicing granule of the one-launch form for this whole set of layers (esr_conv3x3_wgrad_batch_unit)."""
+    arr = (_lib.WgradDesc * len(descs))(*descs)
+    unit = _lib.lib.esr_conv3x3_wgrad_batch_unit(arr, len(descs))
+    check(min(unit, 0), 'esr_conv3x3_wgrad_batch_unit')
+    return int(unit)
+
+
+def wgrad_batch_upload(arr, device, unit=0):
+    """(workspace tensor, plan) of a descriptor array uploaded for esr_conv3x3_wgrad_batch_run; unit: see conv3x3_wgrad_batch."""
+    n = len(arr)
+    need = _lib.lib.esr_conv3x3_wgrad_batch_part_workspace_bytes(arr, n, unit) if unit else _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(arr, n)
+    check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
+    ws = torch.empty(int(need), dtype=torch.uint8, device=device)
+    plan = _lib.WgradBatchPlan()
+    if unit:
+        check(_lib.lib.esr_conv3x3_wgrad_batch_part_upload(arr, n, ws.data_ptr(), ws.numel(), C.byref(plan), unit, stream_ptr()), 'esr_conv3x3_wgrad_batch_part_upload')
+    else:
+        check(_lib.lib.esr_conv3x3_wgrad_batch_upload(arr, n, ws.data_ptr(), ws.numel(), C.byref(plan), stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
+    return ws, plan
 
 
 _WS = {}

@@ -152,6 +152,57 @@ class GradBucketAllReducer:
                 off += n
 
 
+class EarlyBucketReducer:
+    """The generator's gradient exchange started from INSIDE its backward pass.  The engine cuts the batched weight-gradient launch into one
+    launch per bucket (RRDBEngine.wgrad_exchange) and calls start(i, bucket) behind launch i: the bucket's in-place all-reduce is queued on the
+    collective stream behind that launch and runs under the launches of the following buckets (xGMI is point to point: a 23 MB ring step and
+    a 1.7 ms MFMA launch do not compete for anything).  finish() — behind the last launch — makes the compute stream wait for the collectives
+    and scales the sums to means, before autograd hands the views on as .grad; only the LAST bucket's collective is exposed (0.5 of 1.5 ms at 8
+    GPUs by DESIGN section 6's estimate).  Calling the object where GradBucketAllReducer used to be called does nothing when the exchange has
+    already happened in this step, and falls back to the late, bucketed exchange otherwise (gradient accumulation, pixel-shuffle layers, a
+    backward that did not run on the engine): same sums, same division, bit-identical gradients either way."""
+
+    # OFF by default: cutting the one weight-gradient launch into three costs 1.7 ms of a 25.6 ms configs[2] step at one rank (each part ends in
+    # its own half-empty round of workgroups; profiles/r05_c3_exchange_ab.log) — more than the ~1 ms of all-reduce it can hide at 8 GPUs by the
+    # estimate of DESIGN section 6.  Switch it on (train.early_gradient_exchange, bench.py --early-exchange) where a measured scaling run shows the
+    # exposed exchange to be the larger number.
+    ENABLED = False
+
+    def __init__(self, params, bucket_mb=32.0):
+        self.late = GradBucketAllReducer(params, bucket_mb)
+        self.bucket_bytes = int(bucket_mb * 2 ** 20)
+        self._work, self._done = [], False
+        self.early_buckets = 0        # buckets of the last step that were exchanged from inside the backward (diagnostics / tests)
+
+    buckets = property(lambda self: self.late.buckets)
+    params = property(lambda self: self.late.params)
+
+    @property
+    def in_place(self):
+        return self.early_buckets or self.late.in_place
+
+    def start(self, i, t):
+        if not is_distributed():
+            return
+        if i == 0:
+            self._work = []
+        self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
+
+    def finish(self):
+        w = world_size()
+        for handle, t in self._work:
+            handle.wait()             # (RCCL: the compute stream waits; the host does not)
+            t.div_(w)
+        self._done, self.early_buckets, self._work = bool(self._work), len(self._work), []
+
+    def __call__(self):
+        if self._done:
+            self._done = False
+            return
+        self.early_buckets = 0
+        self.late()
+
+
 def broadcast_tensor(t, src=0):
     """Every rank gets rank `src`'s value of `t` (in place on a contiguous clone); identity when not distributed."""
     if not is_distributed():

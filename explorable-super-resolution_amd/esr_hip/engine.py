@@ -67,6 +67,12 @@ class RRDBEngine:
         # without synchronising at the start of the next one — or, synchronising, by check_range().  The reference's fp32 path has no such cliff
         # (codes/models/modules/architecture.py:278-302): leaving the range raises EsrError naming the layer instead of returning inf / NaN images.
         self._watch, self._watch_host, self._watch_ev = None, None, None
+        # Data parallelism (esr_hip/dist.py: EarlyBucketReducer): when set, the backward's batched weight-gradient launch is cut into one launch per
+        # gradient bucket (contiguous runs of layers of ~bucket_bytes in the flat dW buffer), and `wgrad_exchange.start(i, flat[o0:o1])` is called
+        # behind launch i — the bucket's all-reduce then runs on RCCL's stream under the launches of the buckets that follow; `.finish()` is called
+        # behind the last one (it makes the compute stream wait for the collectives and scales the sums).  None (the default, and always for a
+        # one-process job): ONE launch, nothing exchanged here.
+        self.wgrad_exchange = None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
@@ -512,7 +518,7 @@ class RRDBEngine:
         ext = {'dg': dg}
         if dx is not None:
             ext['dx'] = dx
-        key = self._plan_key('bwd', tuple(x_shape), pad, bool(need_dx), bool(need_dw))
+        key = self._plan_key('bwd', tuple(x_shape), pad, bool(need_dx), bool(need_dw), None if self.wgrad_exchange is None else int(self.wgrad_exchange.bucket_bytes))
         entry = bufs['_plans'].get(key)
         if entry is None:
             wg = WGrad(self, need_dw, B)
@@ -766,7 +772,7 @@ class WGrad:
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
-        self.descs, self.keep, self.permuted = [], [], []
+        self.descs, self.keep, self.permuted, self.desc_off = [], [], [], []
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0
@@ -794,6 +800,7 @@ class WGrad:
             self.scaled.append((o, nw + c.weight.shape[0], self.gscale))
         d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device, out=out)
         self.descs.append(d)
+        self.desc_off.append(o)
         self.keep.extend(keep)
         if rows is not None:
             dw, db = final
@@ -803,29 +810,65 @@ class WGrad:
         else:
             self.keep.append(db)
 
+    def _groups(self):
+        """[(flat start, flat end, [indices into self.descs])]: ONE group normally; with an exchange attached (engine.wgrad_exchange) one per
+        gradient bucket — contiguous runs of layers, in the flat buffer's order, of about exchange.bucket_bytes each."""
+        ex = self.engine.wgrad_exchange
+        n = self.flat.numel() if self.flat is not None else self._n
+        if ex is None or self.permuted or self.scaled:
+            return [(0, n, list(range(len(self.descs))))]
+        names = list(self.mods)
+        bounds, start = [], 0
+        for k, name in enumerate(names):                  # bucket boundaries at layer boundaries of the flat layout
+            end = self.offsets[names[k + 1]] if k + 1 < len(names) else n
+            if (end - start) * 4 >= ex.bucket_bytes or k + 1 == len(names):
+                bounds.append((start, end))
+                start = end
+        groups = []
+        for o0, o1 in bounds:
+            idx = [i for i, o in enumerate(self.desc_off) if o0 <= o < o1]
+            if idx:
+                groups.append((o0, o1, idx))
+        # every element of the flat buffer belongs to exactly one bucket: stretch the groups over the gaps of layers without a recorded gradient
+        for k in range(len(groups)):
+            lo = 0 if k == 0 else groups[k - 1][1]
+            hi = n if k + 1 == len(groups) else groups[k][1]
+            groups[k] = (lo, hi, groups[k][2])
+        return groups or [(0, n, [])]
+
     def result(self):
         if self.enabled and self.descs:
             rec = A._rec()
             dev = self.flat.device
+            groups = self._groups()
+            # several launches slice every layer's pixel sum exactly as the one launch over all layers would (bit-identical gradients)
+            unit = A.wgrad_batch_unit(self.descs) if len(groups) > 1 else 0
+            ex = None if self.permuted else self.engine.wgrad_exchange      # (pixel-shuffle layers' gradients are un-permuted after the launch: exchanged by the caller)
             if rec is not None:
                 # recorded pass: the descriptor tables go to the device now, their launches into the list; rebind() serves the replays
                 self._flat_ptr = self.flat.data_ptr()
-                self._ws = self._plan = None
-                if self.descs:
-                    self._arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
-                    need = _lib.lib.esr_conv3x3_wgrad_batch_workspace_bytes(self._arr, len(self.descs))
-                    _lib.check(min(need, 0), 'esr_conv3x3_wgrad_batch_workspace_bytes')
-                    self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
-                    self._upload()
-                    rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(self._ws.data_ptr(), self._plan))
-                    rec.keep.append(self._ws)
+                self._cur_flat = self.flat
+                self._tables = []                 # [(descriptor array, workspace, plan)] one per group
+                for gi, (o0, o1, idx) in enumerate(groups):
+                    if idx:
+                        arr = (_lib.WgradDesc * len(idx))(*[self.descs[i] for i in idx])
+                        ws, plan = A.wgrad_batch_upload(arr, dev, unit)
+                        self._tables.append((arr, ws, plan))
+                        rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(ws.data_ptr(), plan))
+                        rec.keep.append(ws)
+                    if ex is not None:            # replayed between two segments of the list: the bucket of the launch just enqueued
+                        A.host_op(lambda ctx, wg=self, gi=gi, o0=o0, o1=o1, last=(gi + 1 == len(groups)): wg._exchange(gi, o0, o1, last))
                 rec.keep.extend(self.keep)
                 assert not self.permuted and not self.scaled
                 self._n, self._dev = self.flat.numel(), dev
                 grads, self.descs, self.keep, self.flat, self.grads = self.grads, [], [], None, None      # hold no reference to a step's gradients
                 return grads
-            if self.descs:
-                A.conv3x3_wgrad_batch(self.descs, dev, cache=self.engine._wgb)
+            self._cur_flat = self.flat
+            for gi, (o0, o1, idx) in enumerate(groups):
+                if idx:
+                    A.conv3x3_wgrad_batch([self.descs[i] for i in idx], dev, cache=self.engine._wgb, unit=unit)
+                if ex is not None:
+                    self._exchange(gi, o0, o1, gi + 1 == len(groups))
             for (tdw, tdb), (dw, db), rows in self.permuted:
                 dw.index_copy_(0, rows, tdw)
                 db.index_copy_(0, rows, tdb)
@@ -841,10 +884,14 @@ class WGrad:
             self.descs, self.keep = [], []
         return self.grads
 
-    def _upload(self):
-        self._plan = _lib.WgradBatchPlan()
-        _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_upload(self._arr, len(self._arr), self._ws.data_ptr(), self._ws.numel(), C.byref(self._plan),
-                                                           A.stream_ptr()), 'esr_conv3x3_wgrad_batch_upload')
+    def _exchange(self, gi, o0, o1, last):
+        ex = self.engine.wgrad_exchange
+        if ex is None or self._cur_flat is None:
+            return
+        ex.start(gi, self._cur_flat[o0:o1])
+        if last:
+            ex.finish()
+            self._cur_flat = None
 
     def rebind(self):
         """Replay of a recorded pass: a fresh zeroed flat buffer (its views become the parameters' .grad), the descriptor table re-pointed
@@ -852,10 +899,11 @@ class WGrad:
         if not self.enabled:
             return None
         flat = torch.zeros(self._n, dtype=torch.float32, device=self._dev)
+        self._cur_flat = flat                 # what the recorded exchange hooks slice (WGrad._exchange)
         delta = flat.data_ptr() - self._flat_ptr
         if delta:             # the tables' dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
-            if self._ws is not None:
-                _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(self._ws.data_ptr(), C.byref(self._plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
+            for arr, ws, plan in self._tables:
+                _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_rebase(ws.data_ptr(), C.byref(plan), delta, A.stream_ptr()), 'esr_conv3x3_wgrad_batch_rebase')
             self._flat_ptr += delta
         parts = flat.split(self._sizes)
         grads = {}

@@ -177,7 +177,9 @@ class SRRaGANModel(BaseModel):
             self.optimizer_G = Adam(optim_params, lr=self.lr_G, weight_decay=wd_G,
                                     betas=(train_opt['beta1_G'] or 0.9, train_opt['beta2_G'] if train_opt['beta2_G'] is not None else 0.999), **fused)
             self.optimizers.append(self.optimizer_G)
-            self.grad_reducer = esr_dist.GradBucketAllReducer(optim_params)
+            self.grad_reducer = esr_dist.EarlyBucketReducer(optim_params)      # train.early_gradient_exchange: exchanged from inside the backward (see _G_backward)
+            if train_opt.get('early_gradient_exchange'):
+                self.grad_reducer.ENABLED = True
             if self.D_exists:
                 wd_D = train_opt['weight_decay_D'] if train_opt['weight_decay_D'] else 0
                 # (the one-launch Adam steps contiguous fp32 tensors: a channels_last critic keeps torch's)
@@ -304,6 +306,23 @@ class SRRaGANModel(BaseModel):
             import gc
             gc.unfreeze()
             self._gc_frozen = False
+
+    def _G_backward(self, loss, early):
+        """loss.backward() — with the gradient exchange of a multi-rank job started from inside the generator's backward pass when this is the
+        step's only backward into the generator (no accumulation: the .grad tensors are the flat buffer's views themselves): the engine launches
+        its weight gradients bucket by bucket and every bucket's all-reduce overlaps the launches behind it (esr_hip.dist.EarlyBucketReducer)."""
+        G = self.netG.module if hasattr(self.netG, 'module') else self.netG
+        G = getattr(G, 'generated_image_model', G)
+        eng = getattr(G, '_engine', None)
+        use = (early and eng is not None and self.grad_reducer.ENABLED and esr_dist.is_distributed() and
+               all(p.grad is None for p in self.grad_reducer.params))
+        if use:
+            eng.wgrad_exchange = self.grad_reducer
+        try:
+            loss.backward()
+        finally:
+            if use:
+                eng.wgrad_exchange = None
 
     def _D_fall_back(self, reason, permanent=True):
         """network_D.engine = 'auto' leaving the library's kernels for the stock nn.Module: never silently.  permanent=False: for this call only
@@ -535,7 +554,7 @@ class SRRaGANModel(BaseModel):
                         l_g_gan = self.l_gan_w * self.cri_gan(pred_g_fake, True) / scale
                     l_g_total = l_g_total + l_g_gan
                     self._g_acc['l_g_gan'].append(l_g_gan.detach())
-                l_g_total.backward()
+                self._G_backward(l_g_total, early=(last_acc_G and last_dual and scale == 1))
                 self._tick('G_losses_and_backward')
                 # The reference reads every loss value back right here (.item(), :483-493): a host synchronisation per step.  Here they
                 # stay on the device and are read when somebody looks at the log (log_dict / get_current_log).

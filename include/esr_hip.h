@@ -300,6 +300,15 @@ typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16, s2d, 
 int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                    esr_stream_t stream);
 int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
+/* A backward pass's layers as SEVERAL launches (one per gradient bucket of a data-parallel job, so that each bucket's all-reduce starts behind its
+ * launch and overlaps the launches that follow — torch.distributed over RCCL; the reference's nn.DataParallel reduces after the whole backward,
+ * codes/models/SRRaGAN_model.py:418-499): _unit returns the slicing granule the ONE-launch form would use for the whole set; passing it to
+ * _part_workspace_bytes / _part_upload for every part keeps each layer's pixel sum cut exactly as in the one launch — the parts' results are
+ * bit-identical to it.  _run is the same for parts. */
+int64_t esr_conv3x3_wgrad_batch_unit(const esr_wgrad_desc* descs, int n);
+int64_t esr_conv3x3_wgrad_batch_part_workspace_bytes(const esr_wgrad_desc* descs, int n, int64_t unit);
+int esr_conv3x3_wgrad_batch_part_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
+                                        int64_t unit, esr_stream_t stream);
 /* Every dw / db of an uploaded table moved by the same byte offset (all layers' gradients are views of one flat buffer and the caller got a new
  * flat buffer for this pass): patch the table on the device — one tiny launch, no host traffic, stream-ordered behind the previous run. */
 int esr_conv3x3_wgrad_batch_rebase(void* workspace, const esr_wgrad_batch_plan* plan, int64_t delta_bytes, esr_stream_t stream);

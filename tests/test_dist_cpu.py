@@ -187,3 +187,38 @@ def test_a_single_rank_job_runs_no_collectives_unless_asked_to():
     p.join(30)
     assert a == (False, False)
     assert b == (True, True, 3.5)
+
+
+def _worker_early(rank, world, port, q):
+    D = _setup(rank, world, port)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 7, 3, 9)]
+    flat = torch.arange(24, dtype=torch.float32) * (rank + 1)                 # the "flat weight-gradient buffer" of a backward pass
+    red = D.EarlyBucketReducer(params, bucket_mb=1e-5)
+    # what the engine does: one start() per bucket behind its launch, finish() behind the last
+    red.start(0, flat[:12])
+    red.start(1, flat[12:])
+    red.finish()
+    early = (red.early_buckets, flat.clone().numpy())
+    red()                                                                      # the step's exchange already happened: a no-op
+    after = flat.clone().numpy()
+    # a step whose backward did not go through the engine: the late, bucketed exchange over .grad
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    red()
+    q.put((rank, early, after, [float(p.grad[0]) for p in params], red.early_buckets))
+    dist.destroy_process_group()
+
+
+def test_early_bucket_reducer_averages_in_place_and_falls_back_to_the_late_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_early, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(30) for p in procs]
+    want = np.arange(24, dtype=np.float32) * 1.5                               # mean of x1 and x2
+    for rank, (nb, flat), after, late, early_after in res:
+        assert nb == 2 and np.array_equal(flat, want) and np.array_equal(after, want)
+        assert late == [1.5, 3.0, 4.5, 6.0] and early_after == 0

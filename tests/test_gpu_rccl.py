@@ -42,7 +42,7 @@ def _digest(tensors):
     return h.hexdigest()
 
 
-def _generator_steps(shard=None):
+def _generator_steps(shard=None, bucket_kb=None):
     """Two SRRaGANModel generator steps (RRDB-2 + CEM, L1): digests of the gradients after the all-reduce and of the weights after Adam."""
     _paths()
     import models
@@ -52,13 +52,16 @@ def _generator_steps(shard=None):
     opt['gpu_ids'] = [0]
     torch.manual_seed(D.rank())                  # rank-dependent initial weights: the constructor's broadcast makes them rank 0's
     m = models.create_model(opt)
+    if bucket_kb is not None:                    # small buckets: the backward's weight-gradient launch is cut into several, each followed by its all-reduce
+        m.grad_reducer.bucket_bytes = bucket_kb * 1024
+        m.grad_reducer.ENABLED = True             # (off by default: train.early_gradient_exchange)
     lr, hr = seeded_uniform((4, 3, 24, 28), 301), seeded_uniform((4, 3, 96, 112), 302)
     lo, hi = shard if shard is not None else D.shard_range(4)
     for _ in range(3):
         m.feed_data({'LR': lr[lo:hi], 'HR': hr[lo:hi]})
         m.optimize_parameters()
     ps = [p for p in m.netG.parameters() if p.requires_grad]
-    return {'grads': _digest([p.grad for p in ps]), 'weights': _digest(ps), 'in_place': int(m.grad_reducer.in_place), 'buckets': len(m.grad_reducer.buckets),
+    return {'grads': _digest([p.grad for p in ps]), 'weights': _digest(ps), 'in_place': int(m.grad_reducer.in_place), 'buckets': len(m.grad_reducer.buckets), 'early': int(m.grad_reducer.early_buckets),
             'l_g_pix': float(m.get_current_log()['l_g_pix']), 'gsum': float(sum(p.grad.double().abs().sum() for p in ps))}
 
 
@@ -106,7 +109,7 @@ def _worker(rank, world, port, what, q):
         rows = D.gather_scalars(t[:3])
         info['gather_rows'] = rows.cpu().tolist()
         info['mean_scalar'] = D.all_reduce_mean_scalar(2.5 + rank, torch.device('cuda'))
-        res = _generator_steps() if what == 'g' else _gan_steps()
+        res = _generator_steps() if what == 'g' else (_generator_steps(bucket_kb=256) if what == 'g_small' else _gan_steps())
         q.put((rank, info, res))
         dist.barrier()
         dist.destroy_process_group()
@@ -138,6 +141,20 @@ def test_one_rank_over_rccl_reproduces_the_plain_process_generator_step_bit_for_
     assert got['in_place'] == got['buckets'] >= 1            # every bucket all-reduced IN PLACE on the flat weight-gradient buffer, through RCCL
     assert got['grads'] == ref['grads'] and got['weights'] == ref['weights'], (got, ref)
     assert got['l_g_pix'] == ref['l_g_pix']
+
+
+def test_bucketed_weight_gradient_launches_with_early_all_reduce_are_bit_identical():
+    """under a process group the generator's backward launches its weight gradients bucket by bucket and starts every bucket's
+    in-place all-reduce behind its launch (RRDBEngine.wgrad_exchange / esr_hip.dist.EarlyBucketReducer) — here with 256 KB buckets, so that the
+    RRDB-2 generator's 1.6 MB of gradients are several launches and several RCCL collectives: gradients and weights after three steps are those of
+    the plain process (one launch, no collective) bit for bit."""
+    ref = _generator_steps(shard=(0, 4))
+    assert ref['early'] == 0
+    torch.cuda.synchronize()
+    (_, info, got), = _spawn(1, 'g_small')
+    assert info['backend'] == 'nccl'
+    assert got['early'] >= 3, got                # exchanged from inside the backward, in several buckets
+    assert got['grads'] == ref['grads'] and got['weights'] == ref['weights'], (got, ref)
 
 
 def test_one_rank_over_rccl_runs_the_generator_plus_critic_step_like_the_plain_process():
