@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-B="python bench.py --steps 2 --warmup 1 --no-alt-precision --no-cpu-baseline --precision $PREC"
+B="python bench.py --steps 2 --warmup 1 --no-alt-precision --no-cpu-baseline --no-extra-workloads --precision $PREC"
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))

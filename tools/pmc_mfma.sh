@@ -11,7 +11,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --precision $PREC"
+B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --no-extra-workloads --precision $PREC"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- $B > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq" -- $B > "$OUT/sq.log" 2>&1 || echo "sq pass failed"
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d "$OUT/grbm" -- $B > "$OUT/grbm.log" 2>&1 || echo "grbm pass failed"

@@ -18,12 +18,12 @@ if [ "$PREC" = c3 ]; then
   cp profiles/${TAG}_* gpurun_out/        # (gpurun merges only gpurun_out/ back: copy the summaries there too)
   exit 0
 fi
-B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --precision $PREC"
+B="python bench.py --steps 3 --warmup 1 --no-alt-precision --no-cpu-baseline --no-extra-workloads --precision $PREC"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $B > /dev/null 2>&1
 python tools/summarise_profiles.py --tag "$TAG" --stats "$(dirname "$(find "$OUT/stats" -name '*_kernel_stats.csv' | head -1)")" \
     --fetch "$(dirname "$(find "$OUT/fetch" -name '*_counter_collection.csv' | head -1)")" \
     --write "$(dirname "$(find "$OUT/write" -name '*_counter_collection.csv' | head -1)")"
-python bench.py --steps 10 --warmup 3 --precision "$PREC" | tee "profiles/${TAG}_bench.json.log"
+python bench.py --steps 10 --warmup 3 --no-extra-workloads --precision "$PREC" | tee "profiles/${TAG}_bench.json.log"
 cp profiles/${TAG}_* gpurun_out/
