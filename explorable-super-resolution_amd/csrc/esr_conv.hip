@@ -29,33 +29,18 @@
 
 namespace {
 
-#ifndef ESR_NW
-#define ESR_NW 4
-#endif
-#ifndef ESR_MAXS
-#define ESR_MAXS 3
-#endif
-constexpr int NW = ESR_NW;     // waves per workgroup
+constexpr int NW = 4;          // waves per workgroup
 constexpr int NTHREADS = 64 * NW;
-constexpr int MAXS_BASE = ESR_MAXS;        // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
-// Measured on MI355X (RRDB-23 forward, ms): MT1/MT2 resident workgroups 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is
-// power-limited under this kernel: beyond the overlap that reaches the power cap, more resident waves cost clock.
-#ifndef ESR_EPI_AHEAD
-#define ESR_EPI_AHEAD 0
-#endif
-#ifndef ESR_WGS_MT1
-#define ESR_WGS_MT1 2
-#endif
-#ifndef ESR_WGS_MT2
-#define ESR_WGS_MT2 2
-#endif
-constexpr int WGS_MT1 = ESR_WGS_MT1, WGS_MT2 = ESR_WGS_MT2;   // resident workgroups per CU the kernels are built (registers) and tiled (LDS) for
-#ifndef ESR_R_MT1
-#define ESR_R_MT1 3
-#endif
+constexpr int MAXS_BASE = 3;   // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+// Resident workgroups per CU the single-stage kernels are built (registers) and tiled (LDS) for, per M-tile count.  Measured on MI355X
+// (RRDB-23 forward, ms): MT1/MT2 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is power-limited under this kernel
+// (DESIGN.md): beyond the overlap that reaches the power cap, more resident waves cost clock.
+constexpr int WGS_MT1 = 2, WGS_MT2 = 2;
 // 32-pixel column tiles per wave (R) and activation DMA slots per wave per plane (MAXS), per M-tile count: a workgroup tile holds up to
-// NW*R*32 flattened pixels.  R = 6 for the 32-channel kernels halves their weight DMA per pixel and shrinks the halo (experiment knob).
-constexpr int r_of(int mt) { return mt == 1 ? ESR_R_MT1 : 3; }
+// NW*R*32 flattened pixels.  (R = 6 for the 32-channel kernels — half the weight copies per pixel, less halo — was measured in rounds 3 and 5:
+// no gain at configs[1] / configs[4], -10 % at configs[2]; profiles/r05_r6_tiles_ab.log.  Experiment variants of this file are patches or
+// sed-edited scratch copies built to a side library, never switches in here.)
+constexpr int r_of(int mt) { return 3; }
 constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE; }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
