@@ -72,6 +72,11 @@ typedef struct {
  *
  *   out = alpha * act(conv(in0 ++ in1) + bias) + beta1*res1 + beta2*res2
  *
+ * Limits checked by the entry point (ESR_E_ARG / ESR_E_UNSUPPORTED otherwise): 0 < act_slope <= 1 and alpha >= 0 (the epilogue evaluates
+ * alpha * LeakyReLU(y) as max(alpha*y, alpha*act_slope*y)); H + 2 and W + 2 below 32768, upsample <= 8; every view's image (ncg * cg_stride * 16
+ * bytes) and the fp32 destination's image below 4 GiB (per-lane addresses are a uniform per-image base + a 32-bit offset); res1 / res2 cover
+ * every output group (ncg * 8 >= cout); mask_src covers the masked groups.
+ *
  * When res1 is a channel-group slice of in1 itself (same strides; the RDB's  conv5*0.2 + x, block.py:235) and act_slope == 1,
  * the library notices it from the pointers and takes the residual from the input tile it stages on chip anyway (no extra reads);
  * the result is the same expression evaluated in fp32.
