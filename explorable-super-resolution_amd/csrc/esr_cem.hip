@@ -608,41 +608,50 @@ __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* 
 
 // Polyphase upscale, separable: the vertical pass combines, for every output ROW of the tile, the <= ceil(k/sf) window rows whose taps land on
 // samples (plus the pre == 0 replicate rule) into one row of window-column values; the horizontal pass does the same along the row.
+// Tile of the separable upscale: 64 x 64 high-resolution pixels, a thread owns one quad of columns in FOUR rows (16 rows apart).  (16 x 64 with one
+// quad per thread until round 5: the polyphase index arithmetic of a quad — which taps hit samples, where they start in the window — depends on
+// the column only and is now formed once per thread and serves four rows; a workgroup's latency chain load -> pass -> pass -> store moves four
+// times the pixels.)
+constexpr int US_Y = 64, US_X = 64, US_RPT = US_Y / 16;
 template <bool TWO, int SFT>
 __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf_rt, int pre,
                                                             const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
                                                             int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc, int vp) {
-    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [UT_Y][vp] | vertical pass 2 | tv[k] | th[k]   (vp = 16 mod 32: two rows of a 32-lane group on disjoint banks)
+    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [US_Y][vp] | vertical pass 2 | tv[k] | th[k]   (vp = 16 mod 32: two rows of a 32-lane group on disjoint banks)
     float* const w1 = sm;
     float* const w2 = w1 + wr * wc;
     float* const v1 = w2 + (TWO ? wr * wc : 0);
-    float* const v2 = v1 + UT_Y * vp;
+    float* const v2 = v1 + US_Y * vp;
     const int sf = SFT ? SFT : sf_rt;
     const int Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop, p = k / 2;
     const TileId id = xcd_tile();
     const long long bc = id.bz;
-    const int xo0 = id.bx * UT_X, yo0 = id.by * UT_Y;
+    const int xo0 = id.bx * US_X, yo0 = id.by * US_Y;
     // the taps in LDS: both passes index them per lane (the polyphase offset depends on the output row / column) — through global memory that
     // was one vector load per tap and output
-    float* const tvs = v2 + (TWO ? UT_Y * vp : 0);
+    float* const tvs = v2 + (TWO ? US_Y * vp : 0);
     float* const ths = tvs + k;
     for (int e = threadIdx.x; e < 2 * k; e += 256) tvs[e] = e < k ? tv[e] : th[e - k];
-    // (what the horizontal pass's thread needs of g — 4 consecutive output columns of one row — is requested NOW: its memory round trip runs under
-    // the window staging and both passes instead of after them)
-    static_assert(UT_Y * (UT_X / 4) == 256, "one quad of output columns per thread");
-    const int ry = threadIdx.x / (UT_X / 4), xo = xo0 + 4 * (threadIdx.x % (UT_X / 4));
-    const int yq = yo0 + ry;
-    const bool live = xo < Wo && yq < Ho;
-    const int Y = yq + crop;
-    const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
-    const float* gp = (mode >= 1 && live) ? g + (bc * Hh + Y) * (long long)Wh + xo + crop : nullptr;
+    // (what the horizontal pass's thread needs of g — 4 consecutive output columns of its rows — is requested NOW: its memory round trip runs
+    // under the window staging and both passes instead of after them)
+    static_assert(16 * (US_X / 4) == 256, "one quad of output columns per thread and row step");
+    const int ry = threadIdx.x / (US_X / 4), xo = xo0 + 4 * (threadIdx.x % (US_X / 4));
     const bool full = xo + 3 < Wo;
-    const bool vec_g = live && full && mode >= 1 && ((((size_t)gp) & 15) == 0);
-    float gv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec_g) { const float4 t = *(const float4*)gp; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
-    else if (mode >= 1 && live) {
+    float gv[US_RPT][4];
+    bool vec_g[US_RPT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[t] = gp[t];
+    for (int q = 0; q < US_RPT; ++q) {
+        const int yq = yo0 + ry + 16 * q;
+        const bool live = xo < Wo && yq < Ho;
+        const float* gp = (mode >= 1 && live) ? g + (bc * Hh + yq + crop) * (long long)Wh + xo + crop : nullptr;
+        vec_g[q] = live && full && mode >= 1 && ((((size_t)gp) & 15) == 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gv[q][t] = 0.f;
+        if (vec_g[q]) { const float4 t4 = *(const float4*)gp; gv[q][0] = t4.x; gv[q][1] = t4.y; gv[q][2] = t4.z; gv[q][3] = t4.w; }
+        else if (mode >= 1 && live) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[q][t] = gp[t];
+        }
     }
     const int fy = yo0 + crop - p - pre, fx = xo0 + crop - p - pre;
     const int ib = (fy >= 0 ? fy / sf : -((-fy + sf - 1) / sf)), jb = (fx >= 0 ? fx / sf : -((-fx + sf - 1) / sf));
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
         if (TWO) w2[e] = in ? s2[(long long)i * w + j] : 0.f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < UT_Y * wc; e += 256) {      // vertical pass
+    for (int e = threadIdx.x; e < US_Y * wc; e += 256) {      // vertical pass
         const int ry1 = e / wc, c = e - ry1 * wc;
         const int Y1 = yo0 + ry1 + crop;
         float u1 = 0.f, u2 = 0.f;
@@ -680,47 +689,62 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
         if (TWO) v2[ry1 * vp + c] = u2;
     }
     __syncthreads();
-    // horizontal pass: a thread owns 4 consecutive output columns of one row (16 rows x 16 quads = the 256 threads): g comes in and the
-    // result goes out as 16-byte vectors when the rows are 16-byte aligned (else element by element)
-    if (!live) return;
-    const bool vec_o = full && (((size_t)(out + idx)) & 15) == 0 && (mode != 3 || (((size_t)(out2 + idx)) & 15) == 0);
-    const float* r1 = v1 + ry * vp;
-    const float* r2 = v2 + ry * vp;
-    float res[4], res2[4];
+    // horizontal pass: a thread owns 4 consecutive output columns in US_RPT rows.  Per column: the first tap that lands on a sample, the window
+    // column it meets there and how many taps follow inside the image — once; then every row is that many multiply-adds out of its pass-1 row.
+    // g comes in and the result goes out as 16-byte vectors when the rows are 16-byte aligned (else element by element).
+    if (xo >= Wo) return;
+    int b0[4], jl0[4], nb[4], nrep[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int X = xo + t + crop;
-        float u1 = 0.f, u2 = 0.f;
-        int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
-        int jl = (X + b0 - p - pre) / sf - jb;
-        for (int b = b0; b < k; b += sf, ++jl) {
-            const int xx = X + b - p;
-            if (xx < 0 || xx >= Wh) continue;
-            const float tb = ths[b];
-            u1 = fmaf(tb, r1[jl], u1);
-            if (TWO) u2 = fmaf(tb, r2[jl], u2);
-        }
-        if (pre == 0)
-            for (int b = 0; X + b - p < 0 && b < k; ++b) {
+        int b = (pre + p - X) % sf; if (b < 0) b += sf;
+        int jl = (X + b - p - pre) / sf - jb;
+        while (b < k && X + b - p < 0) { b += sf; ++jl; }          // taps left of the image: dropped (zero-stuffed image, no sample there)
+        int n = 0;
+        for (int bb = b; bb < k && X + bb - p < Wh; bb += sf) ++n;
+        b0[t] = b; jl0[t] = jl; nb[t] = n;
+        int nr = 0;                                                  // pre == 0: the taps that reach left of the image replicate the first sample
+        if (pre == 0) while (nr < k && X + nr - p < 0) ++nr;
+        nrep[t] = nr;
+    }
+#pragma unroll
+    for (int q = 0; q < US_RPT; ++q) {
+        const int yq = yo0 + ry + 16 * q;
+        if (yq >= Ho) continue;
+        const long long idx = (bc * Ho + yq) * (long long)Wo + xo;
+        const bool vec_o = full && (((size_t)(out + idx)) & 15) == 0 && (mode != 3 || (((size_t)(out2 + idx)) & 15) == 0);
+        const float* r1 = v1 + (ry + 16 * q) * vp;
+        const float* r2 = v2 + (ry + 16 * q) * vp;
+        float res[4], res2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float u1 = 0.f, u2 = 0.f;
+            for (int i = 0; i < nb[t]; ++i) {
+                const float tb = ths[b0[t] + i * sf];
+                u1 = fmaf(tb, r1[jl0[t] + i], u1);
+                if (TWO) u2 = fmaf(tb, r2[jl0[t] + i], u2);
+            }
+            for (int b = 0; b < nrep[t]; ++b) {
                 u1 = fmaf(ths[b], r1[-jb], u1);
                 if (TWO) u2 = fmaf(ths[b], r2[-jb], u2);
             }
-        res2[t] = 0.f;
-        if (mode == 0) res[t] = u1;
-        else if (mode == 1) res[t] = gv[t] + u1;
-        else if (mode == 2) res[t] = u1 + tanhf(gv[t] - u2) * range;
-        else { res[t] = u1; res2[t] = gv[t] - u2; }
-    }
-    if (vec_o) {
-        *(float4*)(out + idx) = make_float4(res[0], res[1], res[2], res[3]);
-        if (mode == 3) *(float4*)(out2 + idx) = make_float4(res2[0], res2[1], res2[2], res2[3]);
-    } else {
+            res2[t] = 0.f;
+            if (mode == 0) res[t] = u1;
+            else if (mode == 1) res[t] = gv[q][t] + u1;
+            else if (mode == 2) res[t] = u1 + tanhf(gv[q][t] - u2) * range;
+            else { res[t] = u1; res2[t] = gv[q][t] - u2; }
+        }
+        if (vec_o) {
+            *(float4*)(out + idx) = make_float4(res[0], res[1], res[2], res[3]);
+            if (mode == 3) *(float4*)(out2 + idx) = make_float4(res2[0], res2[1], res2[2], res2[3]);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (xo + t < Wo) {
-                out[idx + t] = res[t];
-                if (mode == 3) out2[idx + t] = res2[t];
-            }
+            for (int t = 0; t < 4; ++t)
+                if (xo + t < Wo) {
+                    out[idx + t] = res[t];
+                    if (mode == 3) out2[idx + t] = res2[t];
+                }
+        }
     }
 }
 
@@ -884,13 +908,13 @@ extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C
     if (!f || !tv || !th || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 2 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
     if (mode < 0 || mode > 3 || crop < 0 || 2 * crop >= h * sf || 2 * crop >= w * sf) return ESR_E_ARG;
     if ((mode >= 1 && !g) || (mode >= 2 && !f2) || (mode == 3 && !out2)) return ESR_E_ARG;
-    const int wr = (UT_Y + 2 * (k / 2)) / sf + 3, wc = (UT_X + 2 * (k / 2)) / sf + 3;
+    const int wr = (US_Y + 2 * (k / 2)) / sf + 3, wc = (US_X + 2 * (k / 2)) / sf + 3;
     const int two = mode >= 2 ? 2 : 1;
     const int vp = wc + (16 - wc % 32 + 32) % 32;                       // pass-1 row pitch = 16 (mod 32)
-    const size_t lds = ((size_t)two * wr * wc + (size_t)two * UT_Y * vp + 2 * (size_t)k) * 4;
+    const size_t lds = ((size_t)two * wr * wc + (size_t)two * US_Y * vp + 2 * (size_t)k) * 4;
     if (lds > 60 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
-    const dim3 tg((Wo + UT_X - 1) / UT_X, (Ho + UT_Y - 1) / UT_Y, B * C);
+    const dim3 tg((Wo + US_X - 1) / US_X, (Ho + US_Y - 1) / US_Y, B * C);
     ESR_CLEAR_ERR();
     typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int);
     up_t kern;
