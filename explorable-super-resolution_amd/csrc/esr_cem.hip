@@ -466,13 +466,14 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
 
 // Streaming form of the separable downscale (round 3).  The tile kernel above stages a ((DT-1) sf + k)^2 window per 16x16 outputs — 109 KB of
 // LDS at sf = 8, k = 45: one workgroup per CU, every one of its seven load batches a full memory round trip (1.9 ms per configs[4] batch,
-// 0.43 TB/s).  Here a workgroup owns a strip of 32 output columns x DS_ROWS output rows and walks down the high-resolution rows 8 at a time:
-// load 8 window rows (coalesced 16-byte vectors, the next step's loads in flight under this step's arithmetic), horizontal pass (thread =
+// 0.43 TB/s).  Here a workgroup owns a strip of 32 output columns x DS_ROWS output rows and walks down the high-resolution rows DS_STEP at a time
+// (16: 0.52 ms at configs[4]; 8 rows 0.82, 24 rows 1.45, 32 rows 1.03 — profiles/r05_cem_stream_step.log):
+// load DS_STEP window rows (coalesced 16-byte vectors, the next step's loads in flight under this step's arithmetic), horizontal pass (thread =
 // (row, output column): k taps out of the de-interleaved row images) into a ring of the last RING h-rows, then every output row whose k
-// h-rows are complete is emitted (vertical pass out of the ring).  ~18 KB of LDS: eight workgroups per CU cover each other's latencies; the
+// h-rows are complete is emitted (vertical pass out of the ring).  ~25 KB of LDS: six workgroups per CU cover each other's latencies; the
 // window overlap re-reads 1.1-1.2x of g instead of 1.7x.  Same index rules (clamped window = replicate padding, strided pick at `pre`),
 // same fused  lr_pad - D(y)  output as the tile kernel; the sums run in the same order (horizontal a0/a1 pairs, then vertical).
-constexpr int DS_COLS = 32, DS_ROWS = 64, DS_STEP = 8, DS_RPT = DS_STEP / 8;      // window rows per step; rows per thread in the horizontal pass
+constexpr int DS_COLS = 32, DS_ROWS = 64, DS_STEP = 16, DS_RPT = DS_STEP / 8, DS_SB = 5;      // window rows per step; rows per thread in the horizontal pass
 template <int SFT>
 __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* __restrict__ y, int h, int w, int sf_rt, int pre, const float* __restrict__ tv,
                                                                  const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* 
     const int Xa = (Xb >> 2) << 2;                           // floor to a multiple of 4 (arithmetic shift: also for negative Xb)
     const int nvec = (Xb + cols - Xa + 3) >> 2;
     const bool vec_ok = (Wh & 3) == 0 && (((size_t)src) & 15) == 0;
-    constexpr int SB = 4;                                    // 16-byte vectors per thread per step: DS_STEP * nvec <= 256 * SB (checked by the host)
+    constexpr int SB = DS_SB;                                // 16-byte vectors per thread per step: DS_STEP * nvec <= 256 * SB (checked by the host)
     constexpr int PD = 2;                                    // steps of loads in flight (a step's arithmetic is much shorter than a memory round trip)
     // A thread's SB vectors sit at the same (row of the step, column) every step: the index arithmetic (two integer divisions, the clamps, the
     // de-interleaved LDS addresses of the four elements) is done ONCE — per step a vector costs one row clamp and one multiply.  (Recomputed
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* 
             const float* const pl = tile + ty * qpitch + tx;
 #pragma unroll 4
             for (int c = 0; c < k; ++c) {
-                const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> lg) : c / sf;
+                const int ph = lg >= 0 ? (c & (sf - 1)) : c % sf, q = lg >= 0 ? (c >> (lg >= 0 ? lg : 0)) : c / sf;
                 const float tc = ths[c];
                 const float* const pc = pl + ph * DS_STEP * qpitch + q;
 #pragma unroll
@@ -851,7 +852,7 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
         int qp = (cols + sf - 1) / sf + 1;
         qp |= 1;
         const size_t lds_s = ((size_t)sf * DS_STEP * qp + (size_t)ring * (DS_COLS + 1) + 2 * (size_t)k) * 4;
-        const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * 4 && lds_s <= 64 * 1024;
+        const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * DS_SB && lds_s <= 64 * 1024;
         // measured: configs[4] (sf 8, k 45: 109 KB tile window, one workgroup per CU) 1.88 -> 1.05 ms; configs[1] (sf 4, k 17: 24 KB)
         // 111 -> 135 us — the streaming kernel pays ~1 us of barriers and LDS round trips per 8 rows, the tile kernel only loses where its
         // window crowds the CU
