@@ -86,7 +86,28 @@ struct BnArgs {
     long long npg;                    // elements per channel and group: (B/groups) * H * W
     int nsplit;
     int chunks;                       // bn_apply: blocks per (image, channel group) plane
+    // bn_apply<0, .., FIN>: the affine is derived here from the mode-0 sums (what bn_finalize_kernel would have left in scale / shift)
+    const double* fin_sums;           // [groups][C][2]
+    float eps, momentum;
+    const float* beta;
+    float *o_mean, *o_rstd, *o_scale, *o_shift, *run_mean, *run_var;
 };
+
+// mean, rstd, scale, shift of channel c in group g from the mode-0 sums — bn_finalize_kernel's arithmetic, shared with the fused form
+struct BnStat { float mu, r, sc, sh; double var; };
+__device__ __forceinline__ BnStat bn_stat(const double* sums, long long gc, double n, float eps, float gm, float bt) {
+    const double s = sums[gc * 2], ss = sums[gc * 2 + 1];
+    const double mu = s / n;
+    double var = ss / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    BnStat o;
+    o.r = (float)(1.0 / sqrt(var + (double)eps));
+    o.mu = (float)mu;
+    o.sc = gm * o.r;
+    o.sh = bt - gm * o.r * (float)mu;
+    o.var = var;
+    return o;
+}
 
 // raw 16-byte vectors of one pixel (hi [+ lo]) and their decoding: loads are issued for several pixels before the first is decoded
 struct Raw8 { uint4 h, l; };
@@ -209,8 +230,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
 // Block = (image, channel group, chunk of U x 256 pixels): the 8 channels' per-channel constants (affine, statistics, the backward sums and their
 // double -> float conversions: ~60 loads and a dozen fp64 operations) are formed ONCE per thread and serve its U pixels, whose loads are all
 // issued before the first result is computed.  (One pixel per thread re-derived them for every 16-byte vector: the kernels ran at 3 TB/s.)
-template <int MODE, bool S2D, int U>
+// FIN (MODE 0): no bn_finalize launch in front of this one — eight threads of every block derive their group's affine for the block's 8
+// channels from the sums (fp64, bn_stat) and hand it to the others through LDS; the first block of each channel group also stores mean /
+// rstd / scale / shift of ALL groups for the backward passes and moves the running statistics, group after group, as bn_finalize_kernel does.
+template <int MODE, bool S2D, int U, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
+    static_assert(!FIN || MODE == 0, "the fused finalize belongs to the forward");
     int t = blockIdx.x;
     const int chunk = t % a.chunks;
     t /= a.chunks;
@@ -220,28 +245,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
     float sc[8], sh[8], mu[8], rs[8], k1[8], s1[8], s2[8], t1[8], t2[8], q[8];
     bool okc[8];
     const double inv_n = 1.0 / (double)a.npg;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = cg * 8 + e;
-        const bool ok = c < a.C;
-        okc[e] = ok;
-        const long long gc = (long long)g * a.C + (ok ? c : 0);
-        sc[e] = (ok && a.scale) ? a.scale[gc] : 1.f;
-        sh[e] = (ok && a.shift) ? a.shift[gc] : 0.f;
-        mu[e] = rs[e] = k1[e] = s1[e] = s2[e] = t1[e] = t2[e] = q[e] = 0.f;
-        if (MODE >= 1 && !a.const_stats) {
-            mu[e] = a.mean[gc];
-            rs[e] = a.rstd[gc];
-            k1[e] = (a.gamma ? a.gamma[ok ? c : 0] : 1.f) * rs[e];
-            s1[e] = (float)(a.s2[gc * 2] * inv_n);                      // E[dyb], E[dyb*xh]
-            s2[e] = (float)(a.s2[gc * 2 + 1] * inv_n);
-            if (MODE == 2) {
-                t1[e] = (float)(a.s3[gc * 3] * inv_n);
-                t2[e] = (float)(a.s3[gc * 3 + 1] * inv_n);
-                q[e] = (float)(a.s3[gc * 3 + 2] * inv_n) - t1[e] * s1[e] - t2[e] * s2[e];
-            }
-        }
-    }
+    // the pixels' loads go out first: the per-channel constants (and, FIN, the statistics' fp64 arithmetic and its barrier) are formed under them
     Raw8 ry[U], rd[U], ru[U];
     int ys[U], xs[U];
     bool live[U];
@@ -255,6 +259,59 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
         ry[i] = ldraw(a.y, voff<false>(a.y, b, cg, ys[i], xs[i]));
         if (MODE >= 1) rd[i] = ldraw(a.dz, voff<S2D>(a.dz, b, cg, ys[i], xs[i]));
         if (MODE == 2) ru[i] = ldraw(a.u, voff<false>(a.u, b, cg, ys[i], xs[i]));
+    }
+    __shared__ float fin[FIN ? 16 : 1];
+    if constexpr (FIN) {
+        const int c = cg * 8 + (int)threadIdx.x;
+        if (threadIdx.x < 8 && c < a.C) {
+            const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+            const double n = (double)a.npg;
+            const BnStat me = bn_stat(a.fin_sums, (long long)g * a.C + c, n, a.eps, gm, bt);
+            fin[threadIdx.x] = me.sc;
+            fin[8 + threadIdx.x] = me.sh;
+            if (b == 0 && chunk == 0) {
+                float rm = a.run_mean ? a.run_mean[c] : 0.f, rv = a.run_var ? a.run_var[c] : 0.f;
+                for (int gg = 0; gg < a.groups; ++gg) {
+                    const BnStat o = bn_stat(a.fin_sums, (long long)gg * a.C + c, n, a.eps, gm, bt);
+                    a.o_mean[gg * a.C + c] = o.mu;
+                    a.o_rstd[gg * a.C + c] = o.r;
+                    a.o_scale[gg * a.C + c] = o.sc;
+                    a.o_shift[gg * a.C + c] = o.sh;
+                    rm = (1.f - a.momentum) * rm + a.momentum * o.mu;
+                    rv = (1.f - a.momentum) * rv + a.momentum * (float)(n > 1.0 ? o.var * n / (n - 1.0) : o.var);
+                }
+                if (a.run_mean) a.run_mean[c] = rm;
+                if (a.run_var) a.run_var[c] = rv;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cg * 8 + e;
+        const bool ok = c < a.C;
+        okc[e] = ok;
+        const long long gc = (long long)g * a.C + (ok ? c : 0);
+        if constexpr (FIN) {
+            sc[e] = ok ? fin[e] : 1.f;
+            sh[e] = ok ? fin[8 + e] : 0.f;
+        } else {
+            sc[e] = (ok && a.scale) ? a.scale[gc] : 1.f;
+            sh[e] = (ok && a.shift) ? a.shift[gc] : 0.f;
+        }
+        mu[e] = rs[e] = k1[e] = s1[e] = s2[e] = t1[e] = t2[e] = q[e] = 0.f;
+        if (MODE >= 1 && !a.const_stats) {
+            mu[e] = a.mean[gc];
+            rs[e] = a.rstd[gc];
+            k1[e] = (a.gamma ? a.gamma[ok ? c : 0] : 1.f) * rs[e];
+            s1[e] = (float)(a.s2[gc * 2] * inv_n);                      // E[dyb], E[dyb*xh]
+            s2[e] = (float)(a.s2[gc * 2 + 1] * inv_n);
+            if (MODE == 2) {
+                t1[e] = (float)(a.s3[gc * 3] * inv_n);
+                t2[e] = (float)(a.s3[gc * 3 + 1] * inv_n);
+                q[e] = (float)(a.s3[gc * 3 + 2] * inv_n) - t1[e] * s1[e] - t2[e] * s2[e];
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < U; ++i) {
@@ -302,18 +359,13 @@ __global__ void bn_finalize_kernel(const double* sums, int groups, int C, double
     if (c >= C) return;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < groups; ++g) {
-        const double s = sums[((long long)g * C + c) * 2], ss = sums[((long long)g * C + c) * 2 + 1];
-        const double mu = s / n;
-        double var = ss / n - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)eps));
-        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-        mean[g * C + c] = (float)mu;
-        rstd[g * C + c] = r;
-        scale[g * C + c] = gm * r;
-        shift[g * C + c] = bt - gm * r * (float)mu;
-        rm = (1.f - momentum) * rm + momentum * (float)mu;
-        rv = (1.f - momentum) * rv + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+        const BnStat o = bn_stat(sums, (long long)g * C + c, n, eps, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+        mean[g * C + c] = o.mu;
+        rstd[g * C + c] = o.r;
+        scale[g * C + c] = o.sc;
+        shift[g * C + c] = o.sh;
+        rm = (1.f - momentum) * rm + momentum * o.mu;
+        rv = (1.f - momentum) * rv + momentum * (float)(n > 1.0 ? o.var * n / (n - 1.0) : o.var);
     }
     if (running_mean) running_mean[c] = rm;
     if (running_var) running_var[c] = rv;
@@ -413,6 +465,33 @@ extern "C" int esr_bn_apply(const esr_bn_desc* d, int mode, esr_stream_t stream)
     if (mode == 0) { if (u == 4) ESR_LAUNCH3(bn_apply_kernel, 0, s2d, 4, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 0, s2d, 1, grid, a); }
     else if (mode == 1) { if (u == 4) ESR_LAUNCH3(bn_apply_kernel, 1, s2d, 4, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 1, s2d, 1, grid, a); }
     else { if (u == 2) ESR_LAUNCH3(bn_apply_kernel, 2, s2d, 2, grid, a); else ESR_LAUNCH3(bn_apply_kernel, 2, s2d, 1, grid, a); }
+    return ESR_OK;
+}
+
+extern "C" int esr_bn_finalize_apply(const esr_bn_desc* d, const esr_cmd_bn_finalize* f, esr_stream_t stream) {
+    BnArgs a{};
+    const int rc = fill_common(a, d);
+    if (rc != ESR_OK) return rc;
+    if (!f || !f->sums || !f->mean || !f->rstd || !f->scale || !f->shift || f->groups != d->groups || f->C != d->C || d->const_stats) return ESR_E_ARG;
+    if (f->n_per_group != a.npg) return ESR_E_ARG;
+    const bool s2d = d->s2d != 0;
+    if (!s2d_view_ok(a.out0, a, s2d)) return ESR_E_ARG;
+    a.fin_sums = f->sums; a.eps = f->eps; a.momentum = f->momentum; a.gamma = f->gamma; a.beta = f->beta;
+    a.o_mean = f->mean; a.o_rstd = f->rstd; a.o_scale = f->scale; a.o_shift = f->shift; a.run_mean = f->running_mean; a.run_var = f->running_var;
+    const long long hw = (long long)a.H * a.W;
+    const int u = hw >= 1024 ? 4 : 1;
+    a.chunks = (int)((hw + 256 * u - 1) / (256 * u));
+    const long long grid = (long long)a.B * a.ncg * a.chunks;
+    if (grid > 0x7FFFFFFFll) return ESR_E_UNSUPPORTED;
+    ESR_CLEAR_ERR();
+    if (u == 4) {
+        if (s2d) hipLaunchKernelGGL((bn_apply_kernel<0, true, 4, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<0, false, 4, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        if (s2d) hipLaunchKernelGGL((bn_apply_kernel<0, true, 1, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<0, false, 1, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
 

@@ -46,6 +46,7 @@ extern "C" int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t str
                 const esr_cmd_bn_param_grads& a = c.u.bn_param_grads;
                 rc = esr_bn_param_grads(a.sums2, a.sums3, a.rstd, a.groups, a.C, a.n_per_group, a.dgamma, a.dbeta, a.g_gamma, stream);
             } break;
+            case ESR_OP_BN_FINALIZE_APPLY: rc = esr_bn_finalize_apply(&c.u.bn_finalize_apply.d, &c.u.bn_finalize_apply.f, stream); break;
             default: rc = ESR_E_ARG;
         }
         if (rc != ESR_OK) {

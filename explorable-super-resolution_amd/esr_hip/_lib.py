@@ -62,7 +62,8 @@ class AdamTensor(C.Structure):
 
 # ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
 OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
-    OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS = range(1, 17)
+    OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS, \
+    OP_BN_FINALIZE_APPLY = range(1, 18)
 
 
 class CmdPackNchw(C.Structure):
@@ -119,6 +120,10 @@ class CmdBnFinalize(C.Structure):
                 ('running_mean', C.c_void_p), ('running_var', C.c_void_p)]
 
 
+class CmdBnFinalizeApply(C.Structure):
+    _fields_ = [('d', BnDesc), ('f', CmdBnFinalize)]
+
+
 class CmdBnParamGrads(C.Structure):
     _fields_ = [('sums2', C.c_void_p), ('sums3', C.c_void_p), ('rstd', C.c_void_p), ('groups', C.c_int32), ('C', C.c_int32), ('n_per_group', C.c_int64),
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('g_gamma', C.c_void_p)]
@@ -128,7 +133,7 @@ class CmdUnion(C.Union):
     _fields_ = [('conv', Conv3x3Desc), ('pack_nchw', CmdPackNchw), ('unpack_grad_nchw', CmdUnpackGradNchw), ('act_combine', CmdActCombine),
                 ('pixel_unshuffle', CmdPixelUnshuffle), ('grad_absmax', CmdGradAbsmax), ('grad_scale', CmdGradScale),
                 ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero), ('unpack_nchw', CmdUnpackNchw),
-                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads)]
+                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads), ('bn_finalize_apply', CmdBnFinalizeApply)]
 
 
 class Cmd(C.Structure):
@@ -139,12 +144,13 @@ class Cmd(C.Structure):
 CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW: 'unpack_grad_nchw', OP_ACT_COMBINE: 'act_combine',
               OP_PIXEL_UNSHUFFLE: 'pixel_unshuffle', OP_GRAD_ABSMAX: 'grad_absmax', OP_GRAD_SCALE: 'grad_scale',
               OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero', OP_UNPACK_NCHW: 'unpack_nchw',
-              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads'}
+              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads', OP_BN_FINALIZE_APPLY: 'bn_finalize_apply'}
 
 
 _SIGS = {
     'esr_bn_reduce': (C.c_int, [C.POINTER(BnDesc), C.c_int, C.c_void_p, C.c_void_p]),
     'esr_bn_apply': (C.c_int, [C.POINTER(BnDesc), C.c_int, C.c_void_p]),
+    'esr_bn_finalize_apply': (C.c_int, [C.POINTER(BnDesc), C.POINTER(CmdBnFinalize), C.c_void_p]),
     'esr_bn_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'esr_bn_param_grads': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -137,6 +137,8 @@ STACK_MAX = 8       # feature maps up to this height are stacked (0: never)
 # 32-128 chunks each) over 2-8 workgroup sets (esr_conv3x3_desc.k_split_ws); 0: never
 SPLITK = True
 SPLITK_MAX_FLOATS = 16 << 20
+# forward of a training-mode BatchNorm block: bn_finalize folded into the normalise + activate launch (esr_bn_finalize_apply); False: two launches
+FUSE_FINALIZE = True
 
 
 class _Layer:
@@ -750,12 +752,18 @@ def _fwd_pass(eng, x, training, groups=1):
             A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, k_split_ws=bs.ksw, **kw)
             st = bs.stats(eng, i, training)
             if L.bn is not None and training:
+                # statistics, then ONE launch that turns the sums into the affine (and the stored / running statistics) and applies it
                 bn = L.bn
                 _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False, groups=G), 0, bs.ptr(i, 'sums'))
                 track = bn.track_running_stats and bn.running_mean is not None
-                rec.emit(_lib.OP_BN_FINALIZE, _lib.CmdBnFinalize(bs.ptr(i, 'sums'), G, L.cout, bs.Bg * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                                                                 st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
-                                                                 bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None))
+                fin = _lib.CmdBnFinalize(bs.ptr(i, 'sums'), G, L.cout, bs.Bg * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                         st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
+                                         bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None)
+                if FUSE_FINALIZE:
+                    rec.emit(_lib.OP_BN_FINALIZE_APPLY, _lib.CmdBnFinalizeApply(_desc(L, B, y, st, bs.s2d[i], out0=z, groups=G), fin))
+                    t = z
+                    continue
+                rec.emit(_lib.OP_BN_FINALIZE, fin)
             _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], out0=z, groups=G), 0)
             t = z
         rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, bs.feat_shape[1], feat.data_ptr()), ('dst',))

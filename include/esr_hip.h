@@ -409,7 +409,8 @@ int esr_bn_param_grads(const double* sums2, const double* sums3, const float* rs
 enum {
     ESR_OP_CONV3X3 = 1, ESR_OP_PACK_NCHW = 2, ESR_OP_UNPACK_GRAD_NCHW = 3, ESR_OP_ACT_COMBINE = 4, ESR_OP_PIXEL_UNSHUFFLE = 5,
     ESR_OP_GRAD_ABSMAX = 6, ESR_OP_GRAD_SCALE = 7, ESR_OP_WGRAD_BATCH_RUN = 8, ESR_OP_PACK_BATCH_RUN = 9, ESR_OP_ZERO = 10,
-    ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16
+    ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16,
+    ESR_OP_BN_FINALIZE_APPLY = 17
 };
 typedef struct { const float* src; int64_t src_batch_stride; int32_t B, C, h, w, c0, nc, pad, down; esr_act_view dst; } esr_cmd_pack_nchw;
 typedef struct { esr_act_view G; float* dst; int64_t dst_batch_stride; int32_t B, C, h, w, c0, nc, pad, down, accumulate; } esr_cmd_unpack_grad_nchw;
@@ -427,6 +428,12 @@ typedef struct { const double* sums; int32_t groups, C; int64_t n_per_group; flo
                  float* mean; float* rstd; float* scale; float* shift; float* running_mean; float* running_var; } esr_cmd_bn_finalize;
 typedef struct { const double* sums2; const double* sums3; const float* rstd; int32_t groups, C; int64_t n_per_group; float* dgamma; float* dbeta;
                  float* g_gamma; } esr_cmd_bn_param_grads;
+/* esr_bn_finalize(f...) and esr_bn_apply(d, 0) as ONE launch: the normalise + activate kernel derives its affine from the mode-0 sums itself
+ * (same fp64 arithmetic) and its first block per channel group stores mean / rstd / scale / shift and moves the running statistics.  d->scale,
+ * d->shift, d->mean, d->rstd are not read (f's are written); f->groups, f->C, f->n_per_group must agree with d.  Nine launches fewer per
+ * forward of Discriminator_VGG_128 (codes/models/modules/architecture.py:446-508). */
+typedef struct { esr_bn_desc d; esr_cmd_bn_finalize f; } esr_cmd_bn_finalize_apply;
+int esr_bn_finalize_apply(const esr_bn_desc* d, const esr_cmd_bn_finalize* f, esr_stream_t stream);
 typedef struct {
     int32_t op;              /* ESR_OP_* */
     int32_t reserved;
@@ -446,6 +453,7 @@ typedef struct {
         esr_cmd_bn bn;
         esr_cmd_bn_finalize bn_finalize;
         esr_cmd_bn_param_grads bn_param_grads;
+        esr_cmd_bn_finalize_apply bn_finalize_apply;
     } u;
 } esr_cmd;
 int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);

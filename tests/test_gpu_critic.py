@@ -460,3 +460,32 @@ def test_grouped_call_equals_separate_calls(monkeypatch, splitk):
                 continue                      # analytically zero (conv bias in front of BatchNorm)
             tol = 5e-2 if splitk else 2e-3
         assert rel(v, u) < tol, (name, rel(v, u))
+
+
+def test_finalize_folded_into_the_normalise_launch_equals_the_separate_launch(monkeypatch):
+    """esr_bn_finalize_apply (the forward's default: statistics -> ONE launch that derives the affine, stores mean / rstd / scale / shift,
+    moves the running statistics and normalises) against esr_bn_finalize followed by esr_bn_apply: same fp64 arithmetic on the same sums
+    (the sums themselves are fp64 atomics: their order may move the last bit of a double), for a grouped call of three batches."""
+    from esr_hip import critic as K
+    netD = make_D(64)
+    xs = [seeded_uniform((4, 3, 64, 64), 41 + i).cuda() for i in range(3)]
+    bns = [m for m in netD.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    params = list(netD.parameters())
+
+    def run(fused):
+        monkeypatch.setattr(K, 'FUSE_FINALIZE', fused)
+        eng = K.CriticEngine(netD, 'split')
+        for m in bns:
+            m.reset_running_stats()
+        for p in params:
+            p.grad = None
+        outs = K.critic_forward_group(eng, xs)
+        (outs[0].mean() - 2 * outs[1].mean() + outs[2].square().mean()).backward()
+        return [o.detach().clone() for o in outs] + [p.grad.clone() for p in params] + [m.running_mean.clone() for m in bns] + [m.running_var.clone() for m in bns]
+    a, b = run(False), run(True)
+    assert all(int(m.num_batches_tracked) == 3 for m in bns)
+    scale = max(float(g.norm()) for g in a[3:3 + len(params)])
+    for i, (u, v) in enumerate(zip(a, b)):
+        if max(float(u.norm()), float(v.norm())) < 1e-6 * scale:
+            continue
+        assert rel(v, u) < 1e-6, (i, rel(v, u))
