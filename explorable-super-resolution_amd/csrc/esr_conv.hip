@@ -842,35 +842,53 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int dim0, int d
     if (npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
 }
 
-// many weight tensors in one launch: block b packs entry map[b].x, elements map[b].y*256 .. (a training step re-packs every layer)
+// many weight tensors in one launch (a training step re-packs every layer after the optimiser's update): block b packs tile map[b].y of entry
+// map[b].x — one (K chunk, M tile) = 32 output x 16 input channels x 9 taps.  The tile's 4608 source floats are read ONCE, as the 32 (16 in the
+// transposed pack) contiguous runs of 144 (288) floats they are in [M][K][3][3], into LDS; then every thread assembles the 16-byte vectors of
+// the pack (lane = output channel x K half, 8 input channels each) from there.  (One thread per output vector gathering its 8 floats 36 bytes apart
+// from global memory — every tap another thread, another block — fetched each 32-byte sector eight times: 171 us per configs[2] generator, 0.8 TB/s.)
 struct PackEntry {
     const float* w; const int* kmap; const int* mmap; uint4* out;
     int dim0, dim1, ncg_in, mtiles, transposed, npl, f16, total; float scale;
 };
-__global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ table, const int2* __restrict__ map) {
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackEntry* __restrict__ table, const int2* __restrict__ map) {
+    constexpr int PITCH = 16 * 9 + 1;                     // floats per output-channel row of the staged tile: odd, so the 32 rows fall into 32 banks
+    __shared__ float tile[32 * PITCH];
+    __shared__ int kch_s[16], mch_s[32];
     const int2 m = map[blockIdx.x];
     const PackEntry e = table[m.x];
-    const int idx = m.y * 256 + threadIdx.x;
-    if (idx >= e.total) return;
-    const int lane = idx & 63;
-    const int mt = (idx >> 6) % e.mtiles;
-    const int ks = (idx >> 6) / e.mtiles;
-    const int cp = ks / 9, t = ks % 9;
-    const int cg = 2 * cp + (lane >> 5);
-    const int mch = e.mmap[mt * 32 + (lane & 31)];
-    uint32_t hi[8], lo[8];
+    const int cp = m.y / e.mtiles, mt = m.y % e.mtiles;
+    if (threadIdx.x < 16) {
+        const int cg = 2 * cp + (threadIdx.x >> 3);
+        kch_s[threadIdx.x] = cg < e.ncg_in ? e.kmap[cg * 8 + (threadIdx.x & 7)] : -1;
+    } else if (threadIdx.x >= 32 && threadIdx.x < 64) mch_s[threadIdx.x - 32] = e.mmap[mt * 32 + (threadIdx.x - 32)];
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int kch = cg < e.ncg_in ? e.kmap[cg * 8 + c] : -1;
+    for (int j = 0; j < 18; ++j) {
+        const int f = j * 256 + threadIdx.x;              // walks the source runs: [32 rows][16 x 9] plain, [16 rows][32 x 9] transposed
+        int mr, kc, t;
+        if (e.transposed) { kc = f / 288; const int c = f - kc * 288; mr = c / 9; t = 8 - (c - mr * 9); }
+        else { mr = f / 144; const int c = f - mr * 144; kc = c / 9; t = c - kc * 9; }
+        const int kch = kch_s[kc], mch = mch_s[mr];
         float v = 0.f;
-        if (kch >= 0 && mch >= 0)
-            v = e.transposed ? e.w[((long long)kch * e.dim1 + mch) * 9 + (8 - t)] : e.w[((long long)mch * e.dim1 + kch) * 9 + t];
-        if (e.f16) { hi[c] = f2h(v * e.scale); lo[c] = f2h(v * e.scale - h2f(hi[c])); }
-        else split_bf16(v * e.scale, hi[c], lo[c]);
+        if (kch >= 0 && mch >= 0) v = e.transposed ? e.w[((long long)kch * e.dim1 + mch) * 9 + (8 - t)] : e.w[((long long)mch * e.dim1 + kch) * 9 + t];
+        tile[mr * PITCH + kc * 9 + t] = v;
     }
-    uint4* o = e.out + ((size_t)(ks * e.mtiles + mt) * e.npl) * 64 + lane;
-    o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-    if (e.npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    __syncthreads();
+    for (int v = threadIdx.x; v < 9 * 64; v += 256) {
+        const int t = v >> 6, lane = v & 63;
+        const float* src = tile + (lane & 31) * PITCH + (lane >> 5) * 72 + t;
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float x = src[c * 9];
+            if (e.f16) { hi[c] = f2h(x * e.scale); lo[c] = f2h(x * e.scale - h2f(hi[c])); }
+            else split_bf16(x * e.scale, hi[c], lo[c]);
+        }
+        uint4* o = e.out + ((size_t)((cp * 9 + t) * e.mtiles + mt) * e.npl) * 64 + lane;
+        o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+        if (e.npl == 2) o[64] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
 }
 
 struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
@@ -1075,8 +1093,7 @@ static int64_t pack_batch_blocks(const esr_pack_desc* descs, int n) {
     int64_t nb = 0;
     for (int i = 0; i < n; ++i) {
         if (!descs[i].w || !descs[i].kmap || !descs[i].mmap || !descs[i].wpack || descs[i].ncg_in <= 0 || descs[i].mtiles <= 0) return ESR_E_ARG;
-        const int64_t total = (int64_t)((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
-        nb += (total + 255) / 256;
+        nb += (int64_t)((descs[i].ncg_in + 1) / 2) * descs[i].mtiles;             // one block per (K chunk, M tile)
     }
     return nb;
 }
@@ -1102,7 +1119,7 @@ extern "C" int64_t esr_pack_batch_upload(const esr_pack_desc* descs, int n, void
         e.dim0 = descs[i].cout_w; e.dim1 = descs[i].cin_w; e.ncg_in = descs[i].ncg_in; e.mtiles = descs[i].mtiles;
         e.transposed = descs[i].transposed; e.npl = (descs[i].split == 1 || descs[i].split == 3) ? 2 : 1; e.f16 = descs[i].split >= 2 ? 1 : 0; e.scale = descs[i].scale;
         e.total = ((descs[i].ncg_in + 1) / 2) * 9 * descs[i].mtiles * 64;
-        for (int j = 0; j < (e.total + 255) / 256; ++j) map[(size_t)b++] = make_int2(i, j);
+        for (int j = 0; j < ((descs[i].ncg_in + 1) / 2) * descs[i].mtiles; ++j) map[(size_t)b++] = make_int2(i, j);
     }
     const size_t tb = ((size_t)n * sizeof(PackEntry) + 255) / 256 * 256;
     hipStream_t s = (hipStream_t)stream;

@@ -206,3 +206,30 @@ def test_small_launch_output_slices_are_bit_identical_to_the_64_channel_form(pre
     y1, dx1, dw1 = run(0)
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
     assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
+
+
+@pytest.mark.parametrize('split', [True, False, 'f16x2', 'f16x3'])
+def test_batched_weight_pack_is_bit_identical_to_the_single_tensor_pack(split):
+    """esr_pack_batch_run (one launch for every pack of a step: each (K chunk, M tile) staged through LDS) against esr_pack_conv_weights (one
+    thread per output vector) on the pack kinds the engines make: forward packs with a latent group / ragged channel counts / permuted rows
+    (pixel-shuffle convs), data-gradient packs over a channel slice, the latent slice and permuted K rows, 1 and 2 M tiles, 1..6 K chunks."""
+    from esr_hip import act as A
+    torch.manual_seed(3)
+    dev = 'cuda'
+    w = lambda co, ci: torch.randn(co, ci, 3, 3, device=dev) * (1 + torch.arange(co, device=dev).view(-1, 1, 1, 1) * 0.01)
+    perm = [int(i) for i in torch.randperm(64)]
+    kinds = [dict(weight=w(32, 64), lat=0), dict(weight=w(64, 192), lat=0), dict(weight=w(64, 4), lat=1), dict(weight=w(32, 163), lat=3),
+             dict(weight=w(3, 64), lat=0), dict(weight=w(64, 64), lat=0, rows=perm),
+             dict(weight=w(32, 160), lat=0, transposed=True, m_slice=(64, 128)), dict(weight=w(64, 67), lat=3, transposed=True, m_slice='latent'),
+             dict(weight=w(64, 67), lat=3, transposed=True, m_slice=(0, 64)), dict(weight=w(64, 32), lat=0, transposed=True, rows=perm),
+             dict(weight=w(3, 64), lat=0, transposed=True)]
+    single = [A.PackedConv(k['weight'], None, k['lat'], split=split, transposed=k.get('transposed', False), m_slice=k.get('m_slice'), rows=k.get('rows')) for k in kinds]
+    want = [pk.get().wpack.clone() for pk in single]
+    batch = [A.PackedConv(k['weight'], None, k['lat'], split=split, transposed=k.get('transposed', False), m_slice=k.get('m_slice'), rows=k.get('rows')) for k in kinds]
+    for pk in batch:
+        pk.prepare()
+        pk.wpack.fill_(0x5A)
+    A.PackBatch().run(batch)
+    torch.cuda.synchronize()
+    for i, (pk, ref) in enumerate(zip(batch, want)):
+        assert torch.equal(pk.wpack, ref), (i, kinds[i]['weight'].shape, int((pk.wpack != ref).sum()))
