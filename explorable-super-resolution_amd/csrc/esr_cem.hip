@@ -987,6 +987,63 @@ __global__ void cem_adjoint_kernel(const float* __restrict__ dy, int hq, int wq,
     dx[idx] = accumulate ? dx[idx] + acc : acc;
 }
 
+// The same adjoint for rank-one taps (taps = tv (x) th: the bicubic kernels and their inv_hTh — every filter of the shipped configs): the 2-D tables
+// factor into per-axis tables T[ry][rx][a][b] = Tv[ry][a] * Th[rx][b] ([3][k] each: prefix / plain / suffix), so the gather is two 1-D passes,
+// horizontal (dy [hq][wq] -> tmp [hq][wn]) then vertical (tmp -> dx [hn][wn]): k_y + k_x products per unknown instead of k_y * k_x (the 27 x 27
+// inv_hTh filter: 54 instead of 729), every read of the vertical pass coalesced along x.  One thread per output; AXIS 0: along x, 1: along y.
+// out = (base ? base : 0) + alpha * sum  (the projection's backward folds  dfull - D^T(de)  into the last pass).
+template <int AXIS>
+__global__ void cem_adjoint_1d_kernel(const float* __restrict__ src, int hs, int ws, int sq, int oq, int N, const float* __restrict__ tab, int k,
+                                      int n_out, int sn, int on, const float* __restrict__ base, float alpha, float* __restrict__ dst, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // AXIS 0: dst [bc][hs][n_out], the sum runs along a source row;  AXIS 1: dst [bc][n_out][ws], the sum runs down a source column
+    const int wo = AXIS == 0 ? n_out : ws, ho = AXIS == 0 ? hs : n_out;
+    const int x = (int)(idx % wo);
+    long long t = idx / wo;
+    const int y = (int)(t % ho);
+    const long long bc = t / ho;
+    const int n = AXIS == 0 ? x : y, nq = AXIS == 0 ? ws : hs;
+    const int p = k / 2;
+    const int f = n * sn + on;                                   // frame position of this unknown
+    const int r = f == 0 ? 0 : (f == N - 1 ? 2 : 1);
+    const float* T = tab + r * k;
+    int lo = f + p - (k - 1) - oq, hi = f + p - oq;              // m(q) = q*sq + oq in [f+p-(k-1), f+p]; first / last frame position: everything clamped onto it
+    if (r == 0) lo = -(1 << 28);
+    if (r == 2) hi = (1 << 28);
+    int q0 = lo <= 0 ? 0 : (lo + sq - 1) / sq;
+    int q1 = hi < 0 ? -1 : hi / sq;
+    if (q1 > nq - 1) q1 = nq - 1;
+    const float* sp = src + bc * hs * (long long)ws + (AXIS == 0 ? (long long)y * ws : (long long)x);
+    const long long stride = AXIS == 0 ? 1 : ws;
+    float acc = 0.f;
+    for (int q = q0; q <= q1; ++q) {
+        const int m = q * sq + oq;
+        int a;
+        if (r == 1) a = f - m + p;
+        else if (r == 0) { a = p - m; a = a > k - 1 ? k - 1 : a; }
+        else { a = N - 1 - m + p; a = a < 0 ? 0 : a; }
+        if (a < 0 || a >= k) continue;
+        acc = fmaf(T[a], sp[q * stride], acc);
+    }
+    dst[idx] = (base ? base[idx] : 0.f) + alpha * acc;
+}
+
+// tabs_v / tabs_h: [3][k] prefix / plain / suffix sums of the vertical / horizontal factor; tmp: B*C*hq*wn floats of scratch
+extern "C" int esr_cem_adjoint_sep(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs_v, const float* tabs_h,
+                                   int k, int hn, int wn, int sn, int on, float* tmp, const float* base, float alpha, float* dx, esr_stream_t stream) {
+    if (!dy || !tabs_v || !tabs_h || !tmp || !dx || B <= 0 || C <= 0 || hq <= 0 || wq <= 0 || hn <= 0 || wn <= 0 || sq < 1 || sn < 1 || k < 1 || !(k & 1)) return ESR_E_ARG;
+    if ((hn - 1) * sn + on >= Ny || (wn - 1) * sn + on >= Nx || (hq - 1) * sq + oq >= Ny || (wq - 1) * sq + oq >= Nx) return ESR_E_ARG;
+    const long long t1 = (long long)B * C * hq * wn, t2 = (long long)B * C * hn * wn;
+    ESR_CLEAR_ERR();
+    hipLaunchKernelGGL(cem_adjoint_1d_kernel<0>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, hq, wq, sq, oq, Nx, tabs_h, k, wn, sn, on,
+                       (const float*)nullptr, 1.f, tmp, t1);
+    hipLaunchKernelGGL(cem_adjoint_1d_kernel<1>, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, hq, wn, sq, oq, Ny, tabs_v, k,
+                       hn, sn, on, base, alpha, dx, t2);
+    ESR_CHECK_LAUNCH();
+    return ESR_OK;
+}
+
 extern "C" int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
                                int hn, int wn, int sn, int on, float* dx, int accumulate, esr_stream_t stream) {
     if (!dy || !tabs || !dx || B <= 0 || C <= 0 || hq <= 0 || wq <= 0 || hn <= 0 || wn <= 0 || sq < 1 || sn < 1 || k < 1 || !(k & 1)) return ESR_E_ARG;

@@ -181,6 +181,8 @@ _SIGS = {
                                        C.c_int, C.c_int, C.c_void_p]),
     'esr_cem_adjoint': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'esr_cem_adjoint_sep': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'esr_conv3x3_wgrad': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'esr_conv3x3_wgrad_workspace_floats': (C.c_int64, [C.POINTER(WgradDesc)]),
     'esr_conv3x3_wgrad_batch_workspace_bytes': (C.c_int64, [C.POINTER(WgradDesc), C.c_int]),

@@ -72,21 +72,38 @@ def tap_tables(taps):
     return torch.stack(out).to(torch.float32).contiguous()
 
 
+def tap_tables_1d(t):
+    """[3][k] prefix / plain / suffix sums of one 1-D factor of rank-one taps (esr_cem_adjoint_sep)."""
+    t = t.detach().to(torch.float64)
+    return torch.stack([torch.cumsum(t, 0), t, torch.flip(torch.cumsum(torch.flip(t, [0]), 0), [0])]).to(torch.float32).contiguous()
+
+
+class AdjointTables:
+    """What the adjoint of one CEM filter reads: the 2-D cumulative tables and, for rank-one taps (cem_ops._sep: the separable kernels'
+    factors), the per-axis ones."""
+
+    def __init__(self, taps):
+        self.full = tap_tables(taps)
+        self.k = taps.shape[-1]
+        sep = cem_ops._sep(taps, self.full.device) if self.full.is_cuda else None
+        self.v, self.h = (tap_tables_1d(sep[0]), tap_tables_1d(sep[1])) if sep is not None else (None, None)
+
+
 def _tabs_for(taps):
     """The adjoint's cumulative tap tables, cached next to the taps' device copy ON the tensor that owns the storage (the frozen
     Filter_OP.weight; see cem_ops._taps_entry — a cache keyed on data pointers would go stale when the allocator recycles an address)."""
     owner = taps._base if taps._base is not None else taps
-    key = ('tabs', owner._version, tuple(taps.shape), taps.storage_offset(), str(taps.device))
+    key = ('tabs', owner._version, tuple(taps.shape), taps.storage_offset(), str(taps.device), cem_ops.USE_SEPARABLE)
     cache = getattr(owner, '_esr_taps', None)
     if cache is None:
         cache = {}
         try:
             owner._esr_taps = cache
         except Exception:
-            return tap_tables(taps)
+            return AdjointTables(taps)
     hit = cache.get(key)
     if hit is None:
-        hit = cache[key] = tap_tables(taps)
+        hit = cache[key] = AdjointTables(taps)
     return hit
 
 
@@ -144,7 +161,7 @@ class _CemProject(torch.autograd.Function):
         dlr = _pad_adjoint(de, lr_pad) if ctx.needs_input_grad[0] else None
         dg = None
         if ctx.needs_input_grad[1]:
-            dg = dfull - cem_ops.adjoint_raw(de, td, 'downscale', sf, pre, gshape)   # g enters directly and through -D
+            dg = cem_ops.adjoint_raw(de, td, 'downscale', sf, pre, gshape, base=dfull, alpha=-1.0)   # g enters directly and through -D
         return dlr, dg, None, None, None, None, None, None, None
 
 

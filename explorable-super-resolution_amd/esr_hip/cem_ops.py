@@ -132,11 +132,12 @@ def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0, out=
     return (out, out2) if mode == 3 else out
 
 
-def adjoint_raw(dy, tabs, kind, sf, pre, in_shape):
-    """Transpose of one CEM filter: dy (the op's output gradient) -> gradient w.r.t. the op's input of shape `in_shape`."""
+def adjoint_raw(dy, tabs, kind, sf, pre, in_shape, base=None, alpha=1.0):
+    """Transpose of one CEM filter: dy (the op's output gradient) -> base + alpha * (gradient w.r.t. the op's input of shape `in_shape`).
+    tabs: autograd.AdjointTables — rank-one taps run the two 1-D passes (esr_cem_adjoint_sep), anything else the 2-D gather."""
     dy = _prep(dy, 'gradient')
     B, Cc = in_shape[0], in_shape[1]
-    k = tabs.shape[-1]
+    k = tabs.k
     dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
     hq, wq = dy.shape[2], dy.shape[3]
     hn, wn = in_shape[2], in_shape[3]
@@ -147,8 +148,18 @@ def adjoint_raw(dy, tabs, kind, sf, pre, in_shape):
     else:                        # upscale: frame = HR (the output); unknowns = LR samples at sf*n+pre
         args = (1, 0, hq, wq, sf, pre)
     sq, oq, Ny, Nx, sn, on = args
-    check(_lib.lib.esr_cem_adjoint(dy.data_ptr(), B, Cc, hq, wq, sq, oq, Ny, Nx, tabs.data_ptr(), k, hn, wn, sn, on, dx.data_ptr(), 0,
+    if base is not None:
+        base = _prep(base, 'gradient')
+        assert tuple(base.shape) == tuple(in_shape)
+    if tabs.v is not None:
+        tmp = torch.empty(B * Cc * hq * wn, dtype=torch.float32, device=dy.device)
+        check(_lib.lib.esr_cem_adjoint_sep(dy.data_ptr(), B, Cc, hq, wq, sq, oq, Ny, Nx, tabs.v.data_ptr(), tabs.h.data_ptr(), k, hn, wn, sn, on, tmp.data_ptr(),
+                                           base.data_ptr() if base is not None else None, float(alpha), dx.data_ptr(), stream_ptr()), 'esr_cem_adjoint_sep')
+        return dx
+    check(_lib.lib.esr_cem_adjoint(dy.data_ptr(), B, Cc, hq, wq, sq, oq, Ny, Nx, tabs.full.data_ptr(), k, hn, wn, sn, on, dx.data_ptr(), 0,
                                    stream_ptr()), 'esr_cem_adjoint')
+    if base is not None or alpha != 1.0:
+        dx = dx * alpha if base is None else torch.add(base, dx, alpha=alpha)
     return dx
 
 

@@ -262,6 +262,10 @@ int esr_grad_scale(const esr_act_view* src, const esr_act_view* dst, int B, cons
  * tabs: device fp32 [3][3][k][k] prefix/plain/suffix tap tables (esr_hip/cem_ops.py builds them). */
 int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs, int k,
                     int hn, int wn, int sn, int on, float* dx, int accumulate, esr_stream_t stream);
+/* The same adjoint for rank-one taps (= outer(tv, th): the bicubic kernels and their inv_hTh): two 1-D passes through `tmp` (B*C*hq*wn floats).
+ * tabs_v / tabs_h: device fp32 [3][k] prefix / plain / suffix sums of the vertical / horizontal factor.  dx = (base ? base : 0) + alpha * adjoint. */
+int esr_cem_adjoint_sep(const float* dy, int B, int C, int hq, int wq, int sq, int oq, int Ny, int Nx, const float* tabs_v, const float* tabs_h, int k,
+                        int hn, int wn, int sn, int on, float* tmp, const float* base, float alpha, float* dx, esr_stream_t stream);
 
 /* ---- conv3x3 weight / bias gradient (autograd of nn.Conv2d, block.py:141-142) ----
  *   dw[co][lat+ci][dy][dx] += alpha * sum_{b,y,x} dy[b,co,y,x] * x[b,ci,(y+dy-1)/up,(x+dx-1)/up]     (zero padded)

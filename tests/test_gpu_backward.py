@@ -65,6 +65,34 @@ def test_cem_filter_adjoints_match_oracle_autograd(sf, kernel, bound):
         assert rel_l2(xg.grad.cpu().numpy(), xc.grad.numpy()) < 1e-5, op
 
 
+@pytest.mark.parametrize('sf', [2, 4, 8])
+def test_separable_cem_adjoints_match_the_2d_gather(sf, monkeypatch):
+    """esr_cem_adjoint_sep (two 1-D passes over per-axis prefix / plain / suffix tables; rank-one taps) against esr_cem_adjoint (k x k gather) for the
+    three filters, including the first / last frame rows and columns (where the replicate padding's folded taps are the cumulative entries) and the
+    projection's fused  dfull - D^T(de)."""
+    from esr_hip import cem_ops, autograd as AG
+    net = _cem(sf).WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    h, w = 13, 9
+    cases = [('downscale', net.DownscaleOP, (2, 3, h * sf, w * sf)), ('lr_filter', net.Conv_LR_with_Inv_hTh_OP, (2, 3, h, w)), ('upscale', net.Upscale_OP, (2, 3, h, w))]
+    for kind, op, in_shape in cases:
+        taps = op.taps()
+        x = seeded_uniform(in_shape, 5, -1, 1).to(DEV)
+        with torch.no_grad():
+            y = op(x)
+        dy = seeded_uniform(tuple(y.shape), 6, -1, 1).to(DEV)
+        base = seeded_uniform(in_shape, 7, -1, 1).to(DEV)
+        got = []
+        for use in (True, False):
+            monkeypatch.setattr(cem_ops, 'USE_SEPARABLE', use)
+            tabs = AG._tabs_for(taps)
+            assert (tabs.v is not None) == use
+            got.append((cem_ops.adjoint_raw(dy, tabs, kind, op.sf, op.pre_stride, in_shape),
+                        cem_ops.adjoint_raw(dy, tabs, kind, op.sf, op.pre_stride, in_shape, base=base, alpha=-1.0)))
+        for a, b in zip(*got):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, (kind, sf)
+        assert rel_l2((base - got[0][0]).cpu().numpy(), got[0][1].cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize('eval_mode', [False, True])
 def test_cem_projection_backward_matches_oracle(eval_mode):
     sf = 4
