@@ -772,13 +772,19 @@ __global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_w
 // Many layers in one launch (the whole backward pass of a generator): workgroup b serves table[map[b].x] as (group map[b].y,
 // slice map[b].z).  With hundreds of layers there are enough (layer, input tile, output tile) triples to fill the chip without
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
-template <int NPL, int NST, int FMT, bool S2D = false>
-__global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
+// SIDE: the same kernel for a launch that runs on a SECOND stream under another stream's kernels (the backward's data-gradient chain: ~350 small
+// launches of one workgroup per CU that leave most of every CU idle).  Its waves are made to hold more than half of a SIMD's register file (the
+// clobber pins the accumulator registers up to a180: ~300 registers per wave), so the hardware can never place a second one on a SIMD: ONE such
+// workgroup per CU, whatever LDS is free — the other stream's workgroups (<= 160 registers, <= 80 KB of LDS next to this one's 80) always find
+// room on every CU instead of queueing behind two weight-gradient workgroups that live for a millisecond.
+template <int NPL, int NST, int FMT, bool S2D = false, bool SIDE = false>
+__global__ __launch_bounds__(256, SIDE ? 1 : ((NST == 1 || NPL == 1) ? 2 : 1)) void conv3x3_wgrad_batch_kernel(const WgradArgs* __restrict__ table, const int4* __restrict__ map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int4 m = map[blockIdx.x];
     if (m.x < 0) return;                                         // padding of the XCD-aware order (uniform)
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
+    if constexpr (SIDE) asm volatile("" ::: "a180");
     wgrad_dispatch<NPL, NST, FMT, S2D>(a, group, slice, smem);
 }
 
@@ -1079,7 +1085,14 @@ static int batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int
     return ESR_OK;
 }
 
+static int wgrad_batch_launch(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream, bool side);
 extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
+    return wgrad_batch_launch(workspace, plan, stream, false);
+}
+extern "C" int esr_conv3x3_wgrad_batch_run_side(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
+    return wgrad_batch_launch(workspace, plan, stream, true);
+}
+static int wgrad_batch_launch(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream, bool side) {
     if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = plan->f16 != 0, split = plan->split != 0;
@@ -1090,6 +1103,8 @@ extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgra
     if (plan->s2d && !f16)        // some layers are space-to-depth embedded stride-2 convs: the variant that skips their zero blocks
         k = split ? (nst == 2 ? conv3x3_wgrad_batch_kernel<2, 2, 0, true> : conv3x3_wgrad_batch_kernel<2, 1, 0, true>)
                   : (nst == 2 ? conv3x3_wgrad_batch_kernel<1, 2, 0, true> : conv3x3_wgrad_batch_kernel<1, 1, 0, true>);
+    if (side && !split && !plan->s2d)          // one-plane operands only: the hi+lo and space-to-depth forms run as they are
+        k = f16 ? conv3x3_wgrad_batch_kernel<1, 2, 1, false, true> : conv3x3_wgrad_batch_kernel<1, 2, 0, false, true>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // k varies per call: no caching
     ESR_CLEAR_ERR();
     hipLaunchKernelGGL(k, dim3((unsigned)plan->nwg), dim3(256), wgrad_lds(split ? 2 : 1, nst), s, (const WgradArgs*)workspace,

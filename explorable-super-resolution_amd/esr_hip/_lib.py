@@ -192,6 +192,7 @@ _SIGS = {
     'esr_conv3x3_wgrad_batch_part_workspace_bytes': (C.c_int64, [C.POINTER(WgradDesc), C.c_int, C.c_int64]),
     'esr_conv3x3_wgrad_batch_part_upload': (C.c_int, [C.POINTER(WgradDesc), C.c_int, C.c_void_p, C.c_int64, C.POINTER(WgradBatchPlan), C.c_int64, C.c_void_p]),
     'esr_conv3x3_wgrad_batch_run': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_void_p]),
+    'esr_conv3x3_wgrad_batch_run_side': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_void_p]),
     'esr_conv3x3_wgrad_batch_rebase': (C.c_int, [C.c_void_p, C.POINTER(WgradBatchPlan), C.c_int64, C.c_void_p]),
     'esr_soft_hist_slabs': (C.c_int64, [C.c_int64]),
     'esr_soft_hist_fwd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -63,6 +63,23 @@ class Recorder:
     def host(self, fn):
         self.items.append(('host', fn))
 
+    def position(self):
+        """Where the next command will go: (item index, command index inside that item) — insert_host() takes it back."""
+        if self.items and self.items[-1][0] == 'cmds':
+            return (len(self.items) - 1, len(self.items[-1][1]))
+        return (len(self.items), 0)
+
+    def insert_host(self, pos, fn):
+        """host(fn) at an EARLIER position() of the sequence (the segment it falls into is split).  Insert from the last position to the first:
+        an insertion moves everything behind it."""
+        k, j = pos
+        if k >= len(self.items) or self.items[k][0] != 'cmds':
+            self.items.insert(k, ('host', fn))
+            return
+        cmds = self.items[k][1]
+        parts = ([('cmds', cmds[:j])] if j else []) + [('host', fn)] + ([('cmds', cmds[j:])] if j < len(cmds) else [])
+        self.items[k:k + 1] = parts
+
     def _external_of(self, ptr):
         for name, base, nbytes in self.ext:
             if ptr is not None and base <= ptr < base + max(nbytes, 1):

@@ -73,6 +73,13 @@ class RRDBEngine:
         # behind the last one (it makes the compute stream wait for the collectives and scales the sums).  None (the default, and always for a
         # one-process job): ONE launch, nothing exchanged here.
         self.wgrad_exchange = None
+        # Weight gradients UNDER the data-gradient chain (recorded backward passes, one-plane gradient formats): the layers are cut, in the order
+        # their dy become final, into this many groups; every group but the last is launched on a second stream as soon as the main stream has
+        # produced its last dy (esr_conv3x3_wgrad_batch_run_side: one workgroup per CU, so the chain's small launches keep finding room on every
+        # CU), the last one behind the chain on the main stream, which then waits for the second.  Same slicing as the one launch: bit-identical
+        # gradients.  0: one launch behind the chain.
+        self.wgrad_overlap = WGRAD_OVERLAP
+        self._side = None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
@@ -518,7 +525,7 @@ class RRDBEngine:
         ext = {'dg': dg}
         if dx is not None:
             ext['dx'] = dx
-        key = self._plan_key('bwd', tuple(x_shape), pad, bool(need_dx), bool(need_dw), None if self.wgrad_exchange is None else int(self.wgrad_exchange.bucket_bytes))
+        key = self._plan_key('bwd', tuple(x_shape), pad, bool(need_dx), bool(need_dw), None if self.wgrad_exchange is None else int(self.wgrad_exchange.bucket_bytes), str(self.wgrad_overlap or 0))
         entry = bufs['_plans'].get(key)
         if entry is None:
             wg = WGrad(self, need_dw, B)
@@ -757,6 +764,10 @@ def _pow2_scale(t, exp):
     return torch.ldexp(torch.ones((), dtype=torch.float32, device=t.device), exp - e)
 
 
+# RRDBEngine.wgrad_overlap of new engines (see there); 0 = one weight-gradient launch behind the data-gradient chain
+WGRAD_OVERLAP = 3
+
+
 class WGrad:
     """Weight / bias gradient collection.  Layers are only RECORDED while the data-gradient pass walks the network; result() runs
     them all in one batched launch (esr_conv3x3_wgrad_batch), which is why every gradient / activation buffer a record refers to
@@ -772,7 +783,7 @@ class WGrad:
         self.grads = {} if enabled else None
         self.mods = {name: c for name, c, _ in engine._convs()} if enabled else None
         self.lats = {name: lat for name, _, lat in engine._convs()} if enabled else None
-        self.descs, self.keep, self.permuted, self.desc_off = [], [], [], []
+        self.descs, self.keep, self.permuted, self.desc_off, self.ready = [], [], [], [], []
         if enabled:
             # one zeroed flat buffer per backward pass, handed out as views (a fresh one every time: the views become .grad tensors)
             self.offsets, n = {}, 0
@@ -801,6 +812,8 @@ class WGrad:
         d, dw, db = A.wgrad_desc(dy, x_main, x_lat, self.lats[name], c.weight.shape, self.B, H, W, alpha, upsample, c.weight.device, out=out)
         self.descs.append(d)
         self.desc_off.append(o)
+        rec = A._rec()
+        self.ready.append(rec.position() if rec is not None else None)      # (the launch that wrote dy is already in the list)
         self.keep.extend(keep)
         if rows is not None:
             dw, db = final
@@ -849,6 +862,11 @@ class WGrad:
                 self._flat_ptr = self.flat.data_ptr()
                 self._cur_flat = self.flat
                 self._tables = []                 # [(descriptor array, workspace, plan)] one per group
+                if self._overlap_groups(rec, dev):
+                    rec.keep.extend(self.keep)
+                    self._n, self._dev = self.flat.numel(), dev
+                    grads, self.descs, self.keep, self.flat, self.grads, self.ready = self.grads, [], [], None, None, []
+                    return grads
                 for gi, (o0, o1, idx) in enumerate(groups):
                     if idx:
                         arr = (_lib.WgradDesc * len(idx))(*[self.descs[i] for i in idx])
@@ -883,6 +901,43 @@ class WGrad:
                 self.flat[o:o + n].div_(g)
             self.descs, self.keep = [], []
         return self.grads
+
+    def _overlap_groups(self, rec, dev):
+        """engine.wgrad_overlap: the recorded launches as groups in readiness order — all but the last on the engine's second stream, each
+        enqueued (a host step of the list) right behind the main-stream launch that completed its last dy; the last group and the join at the
+        end of the list.  False: not applicable here (exchange attached, permuted / rescaled gradients, too few layers, hi+lo gradients)."""
+        eng = self.engine
+        fr = eng.wgrad_overlap if isinstance(eng.wgrad_overlap, (tuple, list)) else None      # (experiments: the groups' shares of the layers)
+        G = len(fr) if fr else int(eng.wgrad_overlap or 0)
+        if G < 2 or eng.wgrad_exchange is not None or self.permuted or self.scaled or len(self.descs) < 4 * G or eng._bwd_split is True:
+            return False
+        if eng._side is None:
+            eng._side = torch.cuda.Stream(device=dev)
+        side = eng._side
+        unit = A.wgrad_batch_unit(self.descs)          # every group slices its layers' pixel sums as the one launch would
+        n = len(self.descs)
+        bounds = [n * g // G for g in range(G + 1)] if not fr else [0] + [min(n, int(round(n * sum(fr[:g + 1]) / sum(fr)))) for g in range(G)]
+        hooks = []
+        for g in range(G):
+            idx = range(bounds[g], bounds[g + 1])
+            arr = (_lib.WgradDesc * len(idx))(*[self.descs[i] for i in idx])
+            ws, plan = A.wgrad_batch_upload(arr, dev, unit)
+            self._tables.append((arr, ws, plan))
+            rec.keep.append(ws)
+            if g + 1 < G:
+                def launch(ctx, ws=ws, plan=plan):
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    side.wait_event(ev)
+                    _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_run_side(ws.data_ptr(), C.byref(plan), side.cuda_stream), 'esr_conv3x3_wgrad_batch_run_side')
+                # behind the launch that wrote the group's last dy = where the NEXT layer was recorded
+                hooks.append((self.ready[bounds[g + 1]], launch))
+            else:
+                rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(ws.data_ptr(), plan))
+        rec.host(lambda ctx: torch.cuda.current_stream().wait_stream(side))
+        for pos, fn in reversed(hooks):                # (positions grow with the layer order: last first)
+            rec.insert_host(pos, fn)
+        return True
 
     def _exchange(self, gi, o0, o1, last):
         ex = self.engine.wgrad_exchange

@@ -309,6 +309,11 @@ typedef struct { int64_t nwg, table_bytes; int32_t n, max_red, split, f16, s2d, 
 int esr_conv3x3_wgrad_batch_upload(const esr_wgrad_desc* descs, int n, void* workspace, int64_t workspace_bytes, esr_wgrad_batch_plan* plan,
                                    esr_stream_t stream);
 int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
+/* The same launch for a SECOND stream that runs under another stream's kernels (the generator backward: weight gradients of the layers whose
+ * data gradients are done, while the data-gradient chain — small launches that leave most of every CU idle — goes on): one-plane operand sets run an
+ * instantiation whose waves hold more than half of a SIMD's registers, i.e. ONE workgroup per CU, so that the other stream's workgroups always find
+ * room; the results are those of _run.  hi+lo / space-to-depth sets: identical to _run. */
+int esr_conv3x3_wgrad_batch_run_side(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream);
 /* A backward pass's layers as SEVERAL launches (one per gradient bucket of a data-parallel job, so that each bucket's all-reduce starts behind its
  * launch and overlaps the launches that follow — torch.distributed over RCCL; the reference's nn.DataParallel reduces after the whole backward,
  * codes/models/SRRaGAN_model.py:418-499): _unit returns the slicing granule the ONE-launch form would use for the whole set; passing it to

@@ -68,6 +68,35 @@ def test_replayed_training_pass_is_bit_identical_to_direct_launches(precision):
     assert kinds == ['bwd', 'fwd'], kinds                   # one list per pass kind, recorded on the first step and replayed on the other two
 
 
+@pytest.mark.parametrize('groups', [2, 3, 5])
+def test_weight_gradients_under_the_data_gradient_chain_are_bit_identical(groups):
+    """RRDBEngine.wgrad_overlap: the recorded backward launches the weight gradients of the layers whose dy are final on a second stream
+    (esr_conv3x3_wgrad_batch_run_side) while the data-gradient chain goes on, and joins at the end.  Same slicing as the single launch:
+    every gradient bit-identical, on the recording step and on replays with new tensors; the gradients are consumed on the main stream right
+    behind backward() (a missing join would read them early)."""
+    def run(g):
+        net = make_net(nb=3, precision='bf16')
+        net.engine.wgrad_overlap = g
+        outs = []
+        for i in range(4):
+            x = inputs(4, 3, 4, 20, 16, 180 + i).requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            (y * seeded_uniform(tuple(y.shape), 190 + i).cuda()).sum().backward()
+            total = torch.stack([p.grad.double().abs().sum() for p in net.parameters()]).sum()       # main stream, no synchronisation in between
+            outs.append((x.grad.clone(), [p.grad.clone() for p in net.parameters()], total.clone()))
+            del y
+        return net, outs
+    _, ref = run(0)
+    net, got = run(groups)
+    plans = [v for b in net.engine._bufs.values() for k, v in b['_plans'].items() if k[0] == 'bwd']
+    assert len(plans) == 1 and sum(1 for it in plans[0][0].items if callable(it)) == groups          # groups - 1 side launches + the join
+    for (dx0, dw0, t0), (dx1, dw1, t1) in zip(ref, got):
+        assert torch.equal(dx0, dx1) and torch.equal(t0, t1)
+        assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
+
+
 def test_replay_follows_weight_updates_and_gradient_accumulation():
     """The lists point at the weight PACKS, which are refreshed before every replay; .grad accumulation over two backward passes must add
     into the first pass's gradients (each pass gets its own flat dW buffer)."""
