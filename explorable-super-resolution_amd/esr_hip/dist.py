@@ -162,10 +162,13 @@ class EarlyBucketReducer:
     already happened in this step, and falls back to the late, bucketed exchange otherwise (gradient accumulation, pixel-shuffle layers, a
     backward that did not run on the engine): same sums, same division, bit-identical gradients either way."""
 
-    # OFF by default: cutting the one weight-gradient launch into three costs 1.7 ms of a 25.6 ms configs[2] step at one rank (each part ends in
-    # its own half-empty round of workgroups; profiles/r05_c3_exchange_ab.log) — more than the ~1 ms of all-reduce it can hide at 8 GPUs by the
-    # estimate of DESIGN section 6.  Switch it on (train.early_gradient_exchange, bench.py --early-exchange) where a measured scaling run shows the
-    # exposed exchange to be the larger number.
+    # OFF by default.  With the two-stream backward (RRDBEngine.wgrad_overlap: the bf16 / f16 one-plane gradient formats) the groups ARE the buckets
+    # and the exchange costs +0.1-0.25 ms of a 25.2 ms configs[2] step at one rank under a launcher (profiles/r05_c3_exchange_ab.log, second block;
+    # a one-rank RCCL group blocks the host inside every collective call until the stream it waits for has caught up, which is why the calls are
+    # made at the end of the recorded pass) — against ~1 ms of all-reduce it can hide at 8 GPUs by the estimate of DESIGN section 6.  Where the
+    # backward is ONE stream (hi+lo gradients, pixel-shuffle layers) the engine cuts the weight-gradient launch into one launch per bucket instead,
+    # which costs 1.4-1.7 ms at one rank (each part ends in its own half-empty round of workgroups).  It has never run on more than one GPU: switch it
+    # on (train.early_gradient_exchange, bench.py --early-exchange) where a measured scaling run shows the exposed exchange to be the larger number.
     ENABLED = False
 
     def __init__(self, params, bucket_mb=32.0):

@@ -79,7 +79,7 @@ class RRDBEngine:
         # CU), the last one behind the chain on the main stream, which then waits for the second.  Same slicing as the one launch: bit-identical
         # gradients.  0: one launch behind the chain.
         self.wgrad_overlap = WGRAD_OVERLAP
-        self._side = None
+        self._side, self._xs = None, None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
     def set_precision(self, precision):
@@ -905,19 +905,41 @@ class WGrad:
     def _overlap_groups(self, rec, dev):
         """engine.wgrad_overlap: the recorded launches as groups in readiness order — all but the last on the engine's second stream, each
         enqueued (a host step of the list) right behind the main-stream launch that completed its last dy; the last group and the join at the
-        end of the list.  False: not applicable here (exchange attached, permuted / rescaled gradients, too few layers, hi+lo gradients)."""
+        end of the list.  With an exchange attached (engine.wgrad_exchange) the groups are its buckets: each group's stretch of the flat buffer
+        is handed to exchange.start() on the stream that computes it — the collective waits for that launch only and runs under everything that
+        follows — and exchange.finish() comes behind the join.  False: not applicable here (permuted / rescaled gradients, too few layers, hi+lo
+        gradients)."""
         eng = self.engine
         fr = eng.wgrad_overlap if isinstance(eng.wgrad_overlap, (tuple, list)) else None      # (experiments: the groups' shares of the layers)
         G = len(fr) if fr else int(eng.wgrad_overlap or 0)
-        if G < 2 or eng.wgrad_exchange is not None or self.permuted or self.scaled or len(self.descs) < 4 * G or eng._bwd_split is True:
+        if G < 2 or self.permuted or self.scaled or len(self.descs) < 4 * G or eng._bwd_split is True:
             return False
         if eng._side is None:
             eng._side = torch.cuda.Stream(device=dev)
-        side = eng._side
+        side, ex = eng._side, eng.wgrad_exchange
         unit = A.wgrad_batch_unit(self.descs)          # every group slices its layers' pixel sums as the one launch would
         n = len(self.descs)
         bounds = [n * g // G for g in range(G + 1)] if not fr else [0] + [min(n, int(round(n * sum(fr[:g + 1]) / sum(fr)))) for g in range(G)]
-        hooks = []
+        # the groups' stretches of the flat buffer: the backward meets the layers in (roughly) the reverse of the buffer's order, so a group is
+        # a contiguous run of it; the runs are stretched over layers without a recorded gradient so that every element belongs to one group
+        names = list(self.mods)
+        ends = {self.offsets[nm]: (self.offsets[names[k + 1]] if k + 1 < len(names) else self.flat.numel()) for k, nm in enumerate(names)}
+        spans = [(min(self.desc_off[i] for i in range(bounds[g], bounds[g + 1])), max(ends[self.desc_off[i]] for i in range(bounds[g], bounds[g + 1]))) for g in range(G)]
+        order = sorted(range(G), key=lambda g: spans[g][0])
+        disjoint = all(spans[order[k]][1] <= spans[order[k + 1]][0] for k in range(G - 1))
+        if ex is not None and not disjoint:
+            return False                               # (an exotic layer order: the bucketed launches of result() serve the exchange)
+        cover = {}
+        for k, g in enumerate(order):
+            cover[g] = (0 if k == 0 else spans[order[k - 1]][1], self.flat.numel() if k + 1 == G else spans[g][1])
+
+        def exchange(g, last=False):
+            if ex is not None and self._cur_flat is not None:
+                ex.start(g, self._cur_flat[cover[g][0]:cover[g][1]])
+                if last:
+                    ex.finish()
+                    self._cur_flat = None
+        hooks, done = [], {}
         for g in range(G):
             idx = range(bounds[g], bounds[g + 1])
             arr = (_lib.WgradDesc * len(idx))(*[self.descs[i] for i in idx])
@@ -925,16 +947,34 @@ class WGrad:
             self._tables.append((arr, ws, plan))
             rec.keep.append(ws)
             if g + 1 < G:
-                def launch(ctx, ws=ws, plan=plan):
+                def launch(ctx, ws=ws, plan=plan, g=g):
                     ev = torch.cuda.Event()
                     ev.record()
                     side.wait_event(ev)
                     _lib.check(_lib.lib.esr_conv3x3_wgrad_batch_run_side(ws.data_ptr(), C.byref(plan), side.cuda_stream), 'esr_conv3x3_wgrad_batch_run_side')
+                    if ex is not None:
+                        done[g] = torch.cuda.Event()
+                        done[g].record(side)
                 # behind the launch that wrote the group's last dy = where the NEXT layer was recorded
                 hooks.append((self.ready[bounds[g + 1]], launch))
             else:
                 rec.emit(_lib.OP_WGRAD_BATCH_RUN, _lib.CmdWgradBatchRun(ws.data_ptr(), plan))
-        rec.host(lambda ctx: torch.cuda.current_stream().wait_stream(side))
+
+        def join(ctx):
+            # The collectives are issued HERE, when the host has enqueued the whole pass (it runs milliseconds ahead of the GPU), not between the
+            # segments of the chain: a collective call may block the host until the stream it waits for has caught up (a one-rank RCCL group does:
+            # 2.0-2.7 ms per call with the group's launch still running — profiles/r05_c3_exchange_ab.log), and the chain's 12 us launches must
+            # not wait for the host.  Each one still waits only for its own group's launch (the event recorded behind it on the second stream).
+            if ex is not None:
+                if eng._xs is None:
+                    eng._xs = torch.cuda.Stream(device=dev)
+                for g in range(G - 1):
+                    eng._xs.wait_event(done.pop(g))
+                    with torch.cuda.stream(eng._xs):
+                        exchange(g)
+            torch.cuda.current_stream().wait_stream(side)
+            exchange(G - 1, last=True)
+        rec.host(join)
         for pos, fn in reversed(hooks):                # (positions grow with the layer order: last first)
             rec.insert_host(pos, fn)
         return True

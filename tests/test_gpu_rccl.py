@@ -42,7 +42,7 @@ def _digest(tensors):
     return h.hexdigest()
 
 
-def _generator_steps(shard=None, bucket_kb=None):
+def _generator_steps(shard=None, bucket_kb=None, precision=None, early=False):
     """Two SRRaGANModel generator steps (RRDB-2 + CEM, L1): digests of the gradients after the all-reduce and of the weights after Adam."""
     _paths()
     import models
@@ -52,6 +52,10 @@ def _generator_steps(shard=None, bucket_kb=None):
     opt['gpu_ids'] = [0]
     torch.manual_seed(D.rank())                  # rank-dependent initial weights: the constructor's broadcast makes them rank 0's
     m = models.create_model(opt)
+    if precision is not None:
+        m.netG.generated_image_model.set_precision(precision)
+    if early:
+        m.grad_reducer.ENABLED = True
     if bucket_kb is not None:                    # small buckets: the backward's weight-gradient launch is cut into several, each followed by its all-reduce
         m.grad_reducer.bucket_bytes = bucket_kb * 1024
         m.grad_reducer.ENABLED = True             # (off by default: train.early_gradient_exchange)
@@ -109,7 +113,7 @@ def _worker(rank, world, port, what, q):
         rows = D.gather_scalars(t[:3])
         info['gather_rows'] = rows.cpu().tolist()
         info['mean_scalar'] = D.all_reduce_mean_scalar(2.5 + rank, torch.device('cuda'))
-        res = _generator_steps() if what == 'g' else (_generator_steps(bucket_kb=256) if what == 'g_small' else _gan_steps())
+        res = _generator_steps() if what == 'g' else (_generator_steps(bucket_kb=256) if what == 'g_small' else (_generator_steps(precision='bf16', early=True) if what == 'g_overlap' else _gan_steps()))
         q.put((rank, info, res))
         dist.barrier()
         dist.destroy_process_group()
@@ -154,6 +158,20 @@ def test_bucketed_weight_gradient_launches_with_early_all_reduce_are_bit_identic
     (_, info, got), = _spawn(1, 'g_small')
     assert info['backend'] == 'nccl'
     assert got['early'] >= 3, got                # exchanged from inside the backward, in several buckets
+    assert got['grads'] == ref['grads'] and got['weights'] == ref['weights'], (got, ref)
+
+
+def test_two_stream_backward_exchanges_its_groups_as_they_finish_bit_identically():
+    """The bf16 generator's recorded backward launches its weight gradients in RRDBEngine.wgrad_overlap groups, two of them on the second stream under
+    the data-gradient chain; with the early exchange switched on every group's stretch of the flat gradient buffer is all-reduced (in place, RCCL)
+    behind its own launch on the stream that computed it, and the main stream joins at the end: gradients and weights after three steps are those of
+    the plain process (no process group, exchange off) bit for bit."""
+    ref = _generator_steps(shard=(0, 4), precision='bf16')
+    assert ref['early'] == 0
+    torch.cuda.synchronize()
+    (_, info, got), = _spawn(1, 'g_overlap')
+    assert info['backend'] == 'nccl'
+    assert got['early'] == 3, got                # = the engine's groups
     assert got['grads'] == ref['grads'] and got['weights'] == ref['weights'], (got, ref)
 
 
