@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256, (NST == 1 || NPL == 1) ? 2 : 1) void conv3x3_w
 // splitting the pixel sum, so each workgroup streams ALL tiles of its layer and owns its 32x32x9 block of dW.
 // SIDE: the same kernel for a launch that runs on a SECOND stream under another stream's kernels (the backward's data-gradient chain: ~350 small
 // launches of one workgroup per CU that leave most of every CU idle).  Its waves are made to hold more than half of a SIMD's register file (the
-// clobber pins the accumulator registers up to a180: ~300 registers per wave), so the hardware can never place a second one on a SIMD: ONE such
+// clobber pins the accumulator registers up to a196: 273 registers per wave, allocated as 280), so the hardware can never place a second one on a SIMD: ONE such
 // workgroup per CU, whatever LDS is free — the other stream's workgroups (<= 160 registers, <= 80 KB of LDS next to this one's 80) always find
 // room on every CU instead of queueing behind two weight-gradient workgroups that live for a millisecond.
 template <int NPL, int NST, int FMT, bool S2D = false, bool SIDE = false>
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256, SIDE ? 1 : ((NST == 1 || NPL == 1) ? 2 : 1)) v
     if (m.x < 0) return;                                         // padding of the XCD-aware order (uniform)
     const int e = __builtin_amdgcn_readfirstlane(m.x), group = __builtin_amdgcn_readfirstlane(m.y), slice = __builtin_amdgcn_readfirstlane(m.z);
     const WgradArgs a = table[e];
-    if constexpr (SIDE) asm volatile("" ::: "a180");
+    if constexpr (SIDE) asm volatile("" ::: "a196");          // 76 VGPRs + 197 AGPRs = 273 > 256 (a180 is the least that caps: 257; a210 measures the same)
     wgrad_dispatch<NPL, NST, FMT, S2D>(a, group, slice, smem);
 }
 
