@@ -347,3 +347,29 @@ def test_filter_loss_matches_reference(code):
         np.testing.assert_allclose(loss.detach().numpy(), g['%s/call%d' % (code, call)], rtol=1e-5, atol=1e-7)
     loss.sum().backward()
     np.testing.assert_allclose(sr.grad.numpy(), g[code + '/dSR'], rtol=1e-4, atol=1e-8)
+
+
+def test_recorder_inserts_host_steps_at_earlier_positions():
+    """act.Recorder.position() / insert_host(): the two-stream backward places its side-stream launches where a group's last dy was written, after
+    the whole pass has been recorded — the segment a position falls into is split, positions at a segment boundary or behind a host step insert
+    without splitting, and inserting last-to-first keeps the earlier positions valid."""
+    import torch
+    from esr_hip import act as A
+    rec = A.Recorder({'x': torch.zeros(4)})
+    pos = [rec.position()]
+    for i in range(5):
+        rec.emit(100 + i, None)
+        pos.append(rec.position())
+    rec.host('h0')
+    pos.append(rec.position())
+    for i in range(3):
+        rec.emit(200 + i, None)
+        pos.append(rec.position())
+    assert pos == [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (2, 0), (2, 1), (2, 2), (2, 3)]
+    for p, name in reversed([(pos[0], 'a'), (pos[2], 'b'), (pos[5], 'c'), (pos[6], 'd'), (pos[8], 'e'), (pos[9], 'f')]):
+        rec.insert_host(p, name)
+    flat = []
+    for kind, payload in rec.items:
+        flat += [payload] if kind == 'host' else [op for op, _, _ in payload]
+    assert flat == ['a', 100, 101, 'b', 102, 103, 104, 'c', 'h0', 'd', 200, 201, 'e', 202, 'f'], flat
+    assert all(kind == 'host' or payload for kind, payload in rec.items)        # no empty segments
