@@ -373,3 +373,19 @@ def test_recorder_inserts_host_steps_at_earlier_positions():
         flat += [payload] if kind == 'host' else [op for op, _, _ in payload]
     assert flat == ['a', 100, 101, 'b', 102, 103, 104, 'c', 'h0', 'd', 200, 201, 'e', 202, 'f'], flat
     assert all(kind == 'host' or payload for kind, payload in rec.items)        # no empty segments
+
+
+def test_adjoint_tables_of_rank_one_taps_factor_per_axis():
+    """esr_cem_adjoint_sep's premise (esr_hip/autograd.py): for taps = outer(tv, th) every one of the nine prefix / plain / suffix tables of the 2-D
+    adjoint is the outer product of the per-axis tables."""
+    import torch
+    from esr_hip import autograd as AG
+    g = torch.Generator().manual_seed(5)
+    tv, th = torch.rand(17, generator=g, dtype=torch.float64) - 0.3, torch.rand(17, generator=g, dtype=torch.float64) - 0.3
+    full = AG.tap_tables(torch.outer(tv, th).float())
+    v, h = AG.tap_tables_1d(tv.float()), AG.tap_tables_1d(th.float())
+    assert full.shape == (3, 3, 17, 17) and v.shape == h.shape == (3, 17)
+    for ry in range(3):
+        for rx in range(3):
+            ref = torch.outer(v[ry].double(), h[rx].double())
+            assert float((full[ry, rx].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
