@@ -535,6 +535,7 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     flop_g = 3 * 32 * 52 * 52 * 2 * 18316944 * (B / 32)        # fwd + dgrad + wgrad of G (lat 3), SURVEY §8(d)
     # layer-granular bytes of the same three passes (49,268 + 15,728 elements per LR pixel for RRDB-23 x4 lat 3), at the bytes
     # per element the precision stores (one 16-bit plane, or hi + lo)
+    eng_g = getattr(model.netG.generated_image_model, 'engine', None)
     bytes_g = 3 * B * 52 * 52 * (49268 + 15728) * (4 if precision in ('split', 'mixed') else 2)
     return {'metric': 'LR crops/sec (RRDB-23 x4 lat 3 G + Discriminator_VGG_128 WGAN-GP step, 32 x 52x52 per GPU)', 'value': world * B * args.steps / dt, 'unit': 'LR crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -545,6 +546,8 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
             'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank],
             'gradient_exchange': ('inside the backward, %d buckets' % model.grad_reducer.early_buckets) if model.grad_reducer.early_buckets else
                                  ('after the backward, %d buckets' % len(model.grad_reducer.buckets) if dist is not None else 'none (one process)'),
+            'generator_backward': ('weight gradients in %d groups, %d of them on a second stream under the data-gradient chain' % (eng_g.wgrad_overlap, eng_g.wgrad_overlap - 1))
+                                  if (eng_g is not None and isinstance(eng_g.wgrad_overlap, int) and eng_g.wgrad_overlap >= 2 and precision != 'split') else 'one weight-gradient launch behind the data-gradient chain',
             'phases_ms': split_ms, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
             'roofline': {'bound': 'mfma', 'kernel': 'generator convs (forward + data gradient + weight gradient)', 'achieved': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 1e12,
                          'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 2.5e15, 'traffic': None,
