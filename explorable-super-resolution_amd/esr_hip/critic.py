@@ -798,6 +798,15 @@ class _WgradSet:
         self.ws = torch.empty(int(need), dtype=torch.uint8, device=bs.dev)
         self.plan = None
         self._first = flat
+        # the embedded stride-2 layers' 4x4 gradients are gathered out of their 3x3 x 4 cin blocks by ONE index launch for all of them
+        idx, self.gather, off, g0 = [], {}, 0, 0
+        for (L, _, _), n in zip(pairs, self.sizes):
+            if L.strided:
+                idx.append(L.E_index + off)
+                self.gather[L.index] = (g0, g0 + L.E_index.numel())
+                g0 += L.E_index.numel()
+            off += n
+        self.gather_idx = torch.cat(idx) if idx else None
 
     def run(self):
         """-> {layer index: (dW in the parameter's shape, db)}"""
@@ -812,10 +821,11 @@ class _WgradSet:
             self.flat_ptr += delta
         check(_lib.lib.esr_conv3x3_wgrad_batch_run(self.ws.data_ptr(), C.byref(self.plan), A.stream_ptr()), 'esr_conv3x3_wgrad_batch_run')
         out, off = {}, 0
+        picked = flat[self.gather_idx] if self.gather_idx is not None else None
         for (L, _, _), n in zip(self.pairs, self.sizes):
             nw = L.cout * L.cin_e * 9
             dw, db = flat[off:off + nw], flat[off + nw:off + n]
-            dw = dw[L.E_index].view(L.cout, L.cin, 4, 4) if L.strided else dw.view(L.cout, L.cin_e, 3, 3)
+            dw = picked[self.gather[L.index][0]:self.gather[L.index][1]].view(L.cout, L.cin, 4, 4) if L.strided else dw.view(L.cout, L.cin_e, 3, 3)
             out[L.index] = (dw, db)
             off += n
         return out
