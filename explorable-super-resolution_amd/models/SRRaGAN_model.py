@@ -144,7 +144,10 @@ class SRRaGANModel(BaseModel):
             if self.optimalZ_loss_type is not None:
                 from Z_optimization import Z_optimizer
                 if self.optimalZ_loss_type not in ('l1', 'l2'):
-                    raise NotImplementedError("train.optimalZ_loss_type = %r: 'l1' or 'l2' ('hist' needs SoftHistogramLoss)" % self.optimalZ_loss_type)
+                    # ('hist' cannot be constructed in the reference either: its trainer builds Z_optimizer(objective='hist') without a desired image,
+                    # and SoftHistogramLoss(desired_hist_image=None, patch_size=1) takes len() of it — codes/Z_optimization.py:72, :538-541)
+                    raise NotImplementedError("train.optimalZ_loss_type = %r: 'l1' or 'l2' (the reference's 'hist' fails at construction: "
+                                              "SoftHistogramLoss without a desired image)" % self.optimalZ_loss_type)
                 self.l_g_optimalZ_w = train_opt['optimalZ_loss_weight']
                 z_side = int(opt['datasets']['train']['patch_size'] / (opt['scale'] / self.Z_size_factor))
                 self.Z_optimizer = Z_optimizer(objective=self.optimalZ_loss_type, Z_size=2 * [z_side], model=self, Z_range=1, max_iters=10, initial_LR=1,
