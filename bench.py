@@ -479,7 +479,7 @@ def extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks):
         try:
             r = fn(a, dev, rank, world, dist, sync, max_over_ranks)
             r = {k: r[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'phases_ms', 'roofline',
-                                   'cem_consistency_rmse_interior', 'peak_memory_GB') if k in r} | {'workload': r['config']['workload']}
+                                   'cem_consistency_rmse_interior', 'peak_memory_GB', 'generator_backward') if k in r} | {'workload': r['config']['workload']}
         except Exception as e:                      # noqa: BLE001 — the headline line must survive whatever an appended block does
             r = {'error': '%s: %s' % (type(e).__name__, e)}
         r['wall_s'] = time.perf_counter() - t0
