@@ -906,8 +906,8 @@ class WGrad:
         """engine.wgrad_overlap: the recorded launches as groups in readiness order — all but the last on the engine's second stream, each
         enqueued (a host step of the list) right behind the main-stream launch that completed its last dy; the last group and the join at the
         end of the list.  With an exchange attached (engine.wgrad_exchange) the groups are its buckets: each group's stretch of the flat buffer
-        is handed to exchange.start() on the stream that computes it — the collective waits for that launch only and runs under everything that
-        follows — and exchange.finish() comes behind the join.  False: not applicable here (permuted / rescaled gradients, too few layers, hi+lo
+        is handed to exchange.start() behind an event recorded after its own launch — the collective waits for that launch only and runs under
+        everything that follows — and exchange.finish() comes behind the join.  False: not applicable here (permuted / rescaled gradients, too few layers, hi+lo
         gradients)."""
         eng = self.engine
         fr = eng.wgrad_overlap if isinstance(eng.wgrad_overlap, (tuple, list)) else None      # (experiments: the groups' shares of the layers)
