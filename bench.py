@@ -42,6 +42,10 @@ HBM_PEAK = 8.0e12
 N_CONV_LAUNCHES = 3 + NB * 15 + 2 + 1                              # 351
 MFMA_TERMS = {'split': 3, 'f16x2': 2, 'mixed': 1.16}              # bf16/f16 MFMA instructions issued per product, network average
 
+# what the `traffic: null` of the c3 / c4 / c5 roofline blocks means: HBM counters need rocprofv3 passes, which this process cannot take of itself
+TRAFFIC_NOT_COLLECTED = ('not collected by this run (PMC counters need separate rocprofv3 --pmc passes: tools/pmc_workload.sh %s); committed '
+                         'summaries of such passes, where taken: profiles/*_pmc*.json')
+
 DTYPE = {'split': 'bf16x3 (bf16 hi+lo operands = 16 significand bits per operand in every product, three MFMAs, f32 accumulate)',
          'mixed': 'f16 (residual stream stored as hi+lo planes, hi+lo main-path weights, one-plane dense-block products, f32 accumulate)',
          'f16x2': 'f16x2', 'bf16': 'bf16', 'f16': 'f16'}
@@ -164,8 +168,11 @@ def kernel_set_id():
     every summary they write; this file prints a static PMC field only when the stamp equals the current sources'."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('esr_conv.hip', 'esr_cem.hip', 'esr_common.h'):
-        with open(os.path.join(ROOT, 'explorable-super-resolution_amd', 'csrc', f), 'rb') as fh:
+    for f in ('esr_conv.hip', 'esr_conv_dev.h', 'esr_chain.hip', 'esr_cem.hip', 'esr_common.h'):
+        path = os.path.join(ROOT, 'explorable-super-resolution_amd', 'csrc', f)
+        if not os.path.exists(path):
+            continue
+        with open(path, 'rb') as fh:
             h.update(f.encode() + b'\0' + fh.read())
     return h.hexdigest()[:16]
 
@@ -326,8 +333,10 @@ def main(argv=None):
         out = run_c5(args, dev, rank, world, dist, sync, max_over_ranks)
     else:
         out = run_c2(args, dev, rank, world, dist, sync, max_over_ranks)
-        if world == 1 and args.batch == BATCH and not args.no_extra_workloads:
-            out['extra_workloads'] = extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks)
+        if args.batch == BATCH and not args.no_extra_workloads:
+            extra = extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks)      # every rank takes part (barriers, collectives)
+            if rank == 0:
+                out['extra_workloads'] = extra
     infos = rank_info()
     if rank == 0:
         out['ranks'] = infos
@@ -461,28 +470,35 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
 
 
 def extra_workloads(args, dev, rank, world, dist, sync, max_over_ranks):
-    """Single-GPU default run only, AFTER the headline's timed region and its alt-precision / CPU-baseline legs: a short run (3 warm-up + 5
-    steps) of configs[2] (`--workload c3`: G+D training step at the per-GPU shape, bf16) and of configs[4] (`--workload c5`: x8 inference, f16,
-    blurry_cubic_2.0 CEM kernel), each through the same function its own `--workload` run uses — so the line the driver records carries
-    driver-observed numbers for the configs the headline does not time.  Nothing here touches a headline key; a failure is recorded as
-    {'error': ...} for that block instead of costing the line."""
+    """The default run only, AFTER the headline's timed region and its alt-precision / CPU-baseline legs, each block through the same function
+    its own `--workload` run uses — so the line the driver records carries driver-observed numbers for the configs the headline does not time.
+    N = 1: a short run (3 warm-up + 5 steps) of configs[2] (`c3`: G+D training step at the per-GPU shape, bf16), of configs[4] (`c5`: x8
+    inference, f16, blurry_cubic_2.0 CEM kernel) and (1 warm-up + 2 timed iterations) of configs[3] (`c4`: the Z search, 64 samples of 512x512,
+    'split').  N > 1: configs[2] only — the one workload with data-path collectives — with its communication diagnosis (`comm`: the step with the
+    gradient exchange after the backward, from inside it, and with no exchange at all; run_c3), so that the first multi-GPU record answers what
+    the exchange costs and which form to default to.  Nothing here touches a headline key; a failure is recorded as {'error': ...} for that
+    block instead of costing the line (ranks fail together or not at all: the blocks' collectives are symmetric)."""
     import copy
     import gc
     import torch
     res = {}
-    for name, fn in (('c3', run_c3), ('c5', run_c5)):
+    blocks = (('c3', run_c3, 5, 3), ('c5', run_c5, 5, 3), ('c4', run_c4, 2, 1)) if world == 1 else (('c3', run_c3, 5, 3),)
+    for name, fn, steps, warmup in blocks:
         a = copy.copy(args)
-        a.workload, a.steps, a.warmup, a.precision = name, 5, 3, None
+        a.workload, a.steps, a.warmup, a.precision, a.comm_diag = name, steps, warmup, None, world > 1
         gc.collect()
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
         try:
             r = fn(a, dev, rank, world, dist, sync, max_over_ranks)
-            r = {k: r[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'phases_ms', 'roofline',
-                                   'cem_consistency_rmse_interior', 'peak_memory_GB', 'generator_backward') if k in r} | {'workload': r['config']['workload']}
+            if r is not None:
+                r = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'dtype', 'phases_ms', 'roofline',
+                                       'cem_consistency_rmse_interior', 'peak_memory_GB', 'generator_backward', 'gradient_exchange', 'comm',
+                                       'seconds_for_200_iterations', 'activation_stash') if k in r} | {'workload': r['config']['workload']}
         except Exception as e:                      # noqa: BLE001 — the headline line must survive whatever an appended block does
             r = {'error': '%s: %s' % (type(e).__name__, e)}
-        r['wall_s'] = time.perf_counter() - t0
+        if r is not None:
+            r['wall_s'] = time.perf_counter() - t0
         res[name] = r
     return res
 
@@ -528,10 +544,55 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
     for _ in range(nphase):
         model.feed_data(data); model.optimize_parameters()
     sync()
+    timing_kept = dict(model.timing)
+    comm = None
+    if getattr(args, 'comm_diag', False) and dist is not None:
+        # What the gradient exchange costs and which form to default to, answered by ONE record: the same step (a) with
+        # the exchange after the backward (the timed region above), (b) started from inside the backward (EarlyBucketReducer), (c) with no
+        # exchange at all — the ranks' replicas then drift apart, which is why this comes last, on a model nobody uses afterwards.
+        # exposed_comm_ms = (a) - (c): the part of the collectives that the step's own work does not hide.
+        model.timing = None
+
+        def arm(nsteps=5, nwarm=2):
+            for _ in range(nwarm):
+                model.feed_data(data); model.optimize_parameters()
+            sync()
+            t = time.perf_counter()
+            for _ in range(nsteps):
+                model.feed_data(data); model.optimize_parameters()
+            sync()
+            return max_over_ranks(time.perf_counter() - t)[0] / nsteps * 1e3
+        late_ms = dt / args.steps * 1e3
+        was = model.grad_reducer.ENABLED
+        model.grad_reducer.ENABLED = not was
+        other_ms = arm()
+        other_buckets = model.grad_reducer.early_buckets
+        model.grad_reducer.ENABLED = was
+        early_ms, after_ms = (late_ms, other_ms) if was else (other_ms, late_ms)
+        real_G, real_D = model.grad_reducer, getattr(model, 'grad_reducer_D', None)
+
+        class NoExchange:                          # what SRRaGANModel asks of a reducer (see _G_backward), doing nothing
+            ENABLED, params, buckets, early_buckets, in_place = False, [], [], 0, 0
+
+            def __call__(self):
+                pass
+        model.grad_reducer = NoExchange()
+        if real_D is not None:
+            model.grad_reducer_D = NoExchange()
+        none_ms = arm()
+        model.grad_reducer, model.grad_reducer_D = real_G, real_D
+        comm = {'ms_per_step_exchange_after_backward': after_ms, 'ms_per_step_exchange_inside_backward': early_ms, 'ms_per_step_no_exchange': none_ms,
+                'exposed_comm_ms': (early_ms if was else after_ms) - none_ms, 'exposed_comm_ms_after_backward': after_ms - none_ms,
+                'exposed_comm_ms_inside_backward': early_ms - none_ms, 'early_buckets': other_buckets if not was else model.grad_reducer.early_buckets,
+                'timed_region_used': 'inside the backward' if was else 'after the backward',
+                'G_gradient_bytes': int(sum(p.numel() * 4 for p in real_G.params)), 'D_gradient_bytes': int(sum(p.numel() * 4 for p in real_D.params)) if real_D is not None else 0,
+                'backend': dist.get_backend(), 'steps_per_arm': 5,
+                'note': 'same model, same data, arms back to back: (the timed region), the other exchange form (2 warm-up + 5 steps), no exchange '
+                        '(2 + 5; replicas drift: diagnosis only).  exposed_comm_ms = timed form minus no exchange'}
     if rank != 0:
         return None
     log = model.get_current_log()
-    split_ms = {k: v / nphase for k, v in getattr(model, 'timing', {}).items()}
+    split_ms = {k: v / nphase for k, v in (getattr(model, 'timing', None) or timing_kept).items()}
     flop_g = 3 * 32 * 52 * 52 * 2 * 18316944 * (B / 32)        # fwd + dgrad + wgrad of G (lat 3), SURVEY §8(d)
     # layer-granular bytes of the same three passes (49,268 + 15,728 elements per LR pixel for RRDB-23 x4 lat 3), at the bytes
     # per element the precision stores (one 16-bit plane, or hi + lo)
@@ -548,9 +609,10 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
                                  ('after the backward, %d buckets' % len(model.grad_reducer.buckets) if dist is not None else 'none (one process)'),
             'generator_backward': ('weight gradients in %d groups, %d of them on a second stream under the data-gradient chain' % (eng_g.wgrad_overlap, eng_g.wgrad_overlap - 1))
                                   if (eng_g is not None and isinstance(eng_g.wgrad_overlap, int) and eng_g.wgrad_overlap >= 2 and precision != 'split') else 'one weight-gradient launch behind the data-gradient chain',
-            'phases_ms': split_ms, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
+            'phases_ms': split_ms, 'comm': comm, 'losses': {k: float(v) for k, v in log.items() if isinstance(v, (int, float))},
             'roofline': {'bound': 'mfma', 'kernel': 'generator convs (forward + data gradient + weight gradient)', 'achieved': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 1e12,
                          'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': MFMA_TERMS.get(precision, 1) * flop_g / (dt / args.steps) / 2.5e15, 'traffic': None,
+                         'traffic_source': TRAFFIC_NOT_COLLECTED % 'c3',
                          'generator_algorithmic_bytes_per_step': bytes_g, 'generator_hbm_frac_of_step': bytes_g / (dt / args.steps) / 8.0e12,
                          'note': 'MFMA issue rate (and, beside it, the layer-granular HBM bytes) of the generator over the WHOLE step time: D, optimizers '
                                  'and all-reduce are in the denominator; per-owner GPU time of a step: profiles/*_c3_*_step_kernels.csv'}}
@@ -610,6 +672,7 @@ def run_c4(args, dev, rank, world, dist, sync, max_over_ranks):
             'peak_memory_GB': peak, 'activation_stash': net.engine.stash,
             'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_tile_kernel (forward and data gradient of the frozen generator)', 'achieved': terms * flop / t_it / 1e12 / world,
                          'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': terms * flop / t_it / 2.5e15 / world, 'traffic': None,
+                         'traffic_source': TRAFFIC_NOT_COLLECTED % 'c4',
                          'fp32_equiv_tflops': flop / t_it / 1e12 / world, 'algorithmic_bytes_per_iteration': algo_bytes,
                          'hbm_frac': algo_bytes / t_it / HBM_PEAK / world,
                          'note': 'MFMA issue rate over the WHOLE iteration (CEM, objective, Adam and the host in the denominator); per GPU'}}
@@ -673,7 +736,8 @@ def run_c5(args, dev, rank, world, dist, sync, max_over_ranks):
             'world_size_seen': world, 'ms_per_step_per_rank': [p / args.steps * 1e3 for p in per_rank], 'cem_consistency_rmse_interior': cons,
             'cem_kernel_sizes': [int(cem.ds_kernel.shape[0]), int(cem.inv_hTh.shape[0])], 'peak_memory_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_tile_kernel (%d launches per forward)' % n_launch, 'achieved': algo / (conv_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9,
-                         'unit': 'GB/s', 'frac': algo / (conv_ms * 1e-3) / HBM_PEAK, 'traffic': None, 'algorithmic_bytes_per_forward_per_gpu': algo,
+                         'unit': 'GB/s', 'frac': algo / (conv_ms * 1e-3) / HBM_PEAK, 'traffic': None, 'traffic_source': TRAFFIC_NOT_COLLECTED % 'c5',
+                         'algorithmic_bytes_per_forward_per_gpu': algo,
                          'generator_ms_per_step': conv_ms, 'avg_launch_ms': conv_ms / n_launch,
                          'mfma_issue_frac': terms * flop / (conv_ms * 1e-3) / 2.5e15,
                          'note': 'layer-granular bytes at the element size the precision stores (SURVEY 8(d): 313,356 B per LR pixel in fp32, half in fp16); rank 0'}}

@@ -1092,6 +1092,13 @@ extern "C" int esr_conv3x3_wgrad_batch_run(const void* workspace, const esr_wgra
 extern "C" int esr_conv3x3_wgrad_batch_run_side(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream) {
     return wgrad_batch_launch(workspace, plan, stream, true);
 }
+extern "C" int esr_conv3x3_wgrad_side_occupancy(int f16) {
+    void (*k)(const WgradArgs*, const int4*) = f16 ? conv3x3_wgrad_batch_kernel<1, 2, 1, false, true> : conv3x3_wgrad_batch_kernel<1, 2, 0, false, true>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return ESR_E_LAUNCH; }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k, 256, wgrad_lds(1, 2)) != hipSuccess) { (void)hipGetLastError(); return ESR_E_LAUNCH; }
+    return nb;
+}
 static int wgrad_batch_launch(const void* workspace, const esr_wgrad_batch_plan* plan, esr_stream_t stream, bool side) {
     if (!workspace || !plan || plan->n <= 0 || plan->nwg <= 0) return ESR_E_ARG;
     hipStream_t s = (hipStream_t)stream;

@@ -79,6 +79,9 @@ class RRDBEngine:
         # CU), the last one behind the chain on the main stream, which then waits for the second.  Same slicing as the one launch: bit-identical
         # gradients.  0: one launch behind the chain.
         self.wgrad_overlap = WGRAD_OVERLAP
+        # the four 32-channel convs of a dense block (forward, and the mirrored data-gradient ones) handed to the library as ONE esr_conv3x3_chain
+        # call: fused into one launch by halo recompute where the launch is small, separate launches otherwise — bit-identical (act.chain)
+        self.fuse_chains = FUSE_CHAINS
         self._side, self._xs = None, None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
@@ -122,9 +125,15 @@ class RRDBEngine:
         at what has already arrived on the host (no synchronisation: what the next forward does by itself); wait=True waits for the last
         forward's flag first — call it where a result is consumed (RRDBNet.forward callers that hand images on, bench.py after its timed loop)."""
         ev = self._watch_ev
-        if self._watch is None or ev is None or torch.cuda.is_current_stream_capturing():
+        if self._watch is None or torch.cuda.is_current_stream_capturing():
             return
-        if wait:
+        if ev is None:
+            # no copy is on its way: nothing ran since the last check — or what ran was a HIP-graph replay / a pass recorded into somebody else's
+            # launch list (_post_range does not post from inside those).  wait=True reads the device word itself (one synchronising 4-byte copy)
+            if not wait:
+                return
+            self._watch_host.copy_(self._watch.flag)
+        elif wait:
             ev.synchronize()
         elif not ev.query():
             return
@@ -384,7 +393,7 @@ class RRDBEngine:
     def _plan_key(self, kind, *what):
         # a forward list points into the forward packs only: creating the data-gradient packs later (first backward) leaves it valid
         packs = self._pack_gen[0] if kind == 'fwd' else tuple(self._pack_gen)
-        return (kind,) + what + (self.split, self._ptr_epoch, packs)
+        return (kind,) + what + (self.split, self._ptr_epoch, packs, bool(self.fuse_chains and A.CHAINS))
 
     @A.one_stream
     def run_forward(self, x, pad=0, keep=False):
@@ -468,10 +477,11 @@ class RRDBEngine:
             rrdb_in = buf_of(3 * r)
             for k in range(3):
                 buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
-                for i in range(4):
-                    o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
-                    conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
+                with A.chain(self.fuse_chains):      # the four growing convs: one launch at the small launch sizes (esr_conv3x3_chain)
+                    for i in range(4):
+                        o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
+                        conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
+                             out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
@@ -699,11 +709,15 @@ class RRDBEngine:
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
                 if need_dw:
                     wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
-                for c in (3, 2, 1, 0):
-                    g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
-                    conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
-                         mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
-                    if need_dw:
+                with A.chain(self.fuse_chains):          # the mirrored dense block: one launch at the small launch sizes (esr_conv3x3_chain)
+                    for c in (3, 2, 1, 0):
+                        g0 = 8 + 4 * (3 - c)             # dy of conv c goes right behind the gradients it is computed from
+                        conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
+                             mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
+                # (recorded behind the chain: a weight gradient's place in a launch list — where its dy is final — is behind the launch that wrote it)
+                if need_dw:
+                    for c in (3, 2, 1, 0):
+                        g0 = 8 + 4 * (3 - c)
                         wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
@@ -766,6 +780,26 @@ def _pow2_scale(t, exp):
 
 # RRDBEngine.wgrad_overlap of new engines (see there); 0 = one weight-gradient launch behind the data-gradient chain
 WGRAD_OVERLAP = 3
+
+# RRDBEngine.fuse_chains of new engines
+FUSE_CHAINS = True
+
+_SIDE_CAPPED = {}
+
+
+def _side_kernel_capped(f16):
+    """Does the weight-gradient instantiation of the second stream hold its CU alone (esr_conv3x3_wgrad_side_occupancy == 1)?  That is what lets the
+    data-gradient chain's small launches always find room next to it; it rests on the register allocator honouring a clobber, i.e. on the
+    toolchain that built the library — asked once per process, and a build where it does not hold keeps the one-stream backward (with a warning:
+    the two-stream form would then SLOW the chain down)."""
+    if f16 not in _SIDE_CAPPED:
+        occ = _lib.lib.esr_conv3x3_wgrad_side_occupancy(1 if f16 else 0)
+        _SIDE_CAPPED[f16] = occ == 1
+        if occ != 1:
+            import warnings
+            warnings.warn('libesr_hip: the side-stream weight-gradient kernel reports %d resident workgroups per CU (expected 1): '
+                          'wgrad_overlap is ignored, the backward runs on one stream' % occ)
+    return _SIDE_CAPPED[f16]
 
 
 class WGrad:
@@ -856,11 +890,14 @@ class WGrad:
             groups = self._groups()
             # several launches slice every layer's pixel sum exactly as the one launch over all layers would (bit-identical gradients)
             unit = A.wgrad_batch_unit(self.descs) if len(groups) > 1 else 0
-            ex = None if self.permuted else self.engine.wgrad_exchange      # (pixel-shuffle layers' gradients are un-permuted after the launch: exchanged by the caller)
+            # (pixel-shuffle layers' gradients are un-permuted after the launch, 'mixed' gradients are still multiplied by this RANK's power-of-two
+            # scales until the loop at the end of this function: both are exchanged by the caller, after the backward — summing scaled buffers
+            # across ranks and dividing by the local scale would give every rank different, wrong gradients)
+            ex = None if (self.permuted or self.scaled) else self.engine.wgrad_exchange
             if rec is not None:
                 # recorded pass: the descriptor tables go to the device now, their launches into the list; rebind() serves the replays
                 self._flat_ptr = self.flat.data_ptr()
-                self._cur_flat = self.flat
+                self._cur_flat = self.flat if ex is not None else None      # (only an exchange slices it; without one nothing here outlives the step)
                 self._tables = []                 # [(descriptor array, workspace, plan)] one per group
                 if self._overlap_groups(rec, dev):
                     rec.keep.extend(self.keep)
@@ -881,7 +918,7 @@ class WGrad:
                 self._n, self._dev = self.flat.numel(), dev
                 grads, self.descs, self.keep, self.flat, self.grads = self.grads, [], [], None, None      # hold no reference to a step's gradients
                 return grads
-            self._cur_flat = self.flat
+            self._cur_flat = self.flat if ex is not None else None
             for gi, (o0, o1, idx) in enumerate(groups):
                 if idx:
                     A.conv3x3_wgrad_batch([self.descs[i] for i in idx], dev, cache=self.engine._wgb, unit=unit)
@@ -914,6 +951,8 @@ class WGrad:
         G = len(fr) if fr else int(eng.wgrad_overlap or 0)
         if G < 2 or self.permuted or self.scaled or len(self.descs) < 4 * G or eng._bwd_split is True:
             return False
+        if not _side_kernel_capped(eng._bwd_split in ('mixed', 'f16')):
+            return False                               # (this build's side instantiation is not one workgroup per CU: the one-stream backward)
         if eng._side is None:
             eng._side = torch.cuda.Stream(device=dev)
         side, ex = eng._side, eng.wgrad_exchange
@@ -994,7 +1033,9 @@ class WGrad:
         if not self.enabled:
             return None
         flat = torch.zeros(self._n, dtype=torch.float32, device=self._dev)
-        self._cur_flat = flat                 # what the recorded exchange hooks slice (WGrad._exchange)
+        # what the recorded exchange hooks slice (WGrad._exchange) — and only then: a plan that kept the previous step's 67 MB buffer alive would
+        # keep the allocator from handing the same block back, i.e. re-base every table every step
+        self._cur_flat = flat if self.engine.wgrad_exchange is not None else None
         delta = flat.data_ptr() - self._flat_ptr
         if delta:             # the tables' dW / db pointers move with the buffer: patched on the device (no host copy, stream-ordered)
             for arr, ws, plan in self._tables:

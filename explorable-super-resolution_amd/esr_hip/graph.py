@@ -54,3 +54,10 @@ class GraphedForward:
         entry['x'].copy_(x)
         entry['graph'].replay()
         return entry['y']
+
+    def check_range(self):
+        """fp16 precisions: raise EsrError if a replayed forward stored saturated activations (RRDBEngine.check_range; a replay cannot post the
+        range word to the host by itself, so this reads it from the device — call it where an image is handed on)."""
+        for m in self.module.modules():
+            if hasattr(m, 'invalidate_packs') and hasattr(m, 'check_range'):
+                m.check_range(wait=True)

@@ -411,59 +411,53 @@ def test_pixelshuffle_generator_matches_oracle(sf, lat, prec):
 
 
 # ---- the sign-flip statement, tested: with the activation pattern the GPU forward actually took, the HIP backward is the exact adjoint
+# (precision, flip-candidate distance / layer rms, flip share, dx bar, per-parameter bar).  'split' is held to the north star's plain 1e-3;
+# 'mixed' (fp16 hi planes and one MFMA per product inside the dense blocks, power-of-two gradient scaling) to its own arithmetic: the bars are
+# ~5x what it measures with the pattern forced (round 6: flip candidates within 1.0e-3 of the rms, 27 of 589,824 activations; dx 4.4e-5; weight
+# gradients median 4.7e-4, worst 6.9e-4 — 1.15e-3 in the smoke's RRDB-1 under the CEM) — far under the 1e-2 / 1e-1 its flip-inclusive tests above
+# have to allow, and split measures dx 1.2e-5, weight gradients <= 2.2e-5
+PATTERN_BARS = {'split': (1e-4, 1e-5, 1e-3, 1e-3), 'mixed': (5e-3, 3e-4, 3e-4, 4e-3)}
+
+
+@pytest.mark.parametrize('precision', ['split', 'mixed'])
 @pytest.mark.parametrize('nb,sf,lat', [(1, 4, 0), (2, 4, 3)])
-def test_gradients_meet_the_bar_under_the_gpu_activation_pattern(nb, sf, lat):
+def test_gradients_meet_the_bar_under_the_gpu_activation_pattern(nb, sf, lat, precision):
     """A LeakyReLU network is piecewise linear: its gradient is a function of the activation PATTERN (which side of zero every
     pre-activation fell on).  Two correct forwards that differ by rounding can disagree on the pattern at pre-activations within rounding
     distance of zero, and then their gradients differ by O(1e-3) in those activations' receptive fields — that is why the comparisons with
-    the reference's golden gradients above use a robust metric.  Here the claim is checked piece by piece against an fp64 run of the oracle:
+    the reference's golden gradients above use a robust metric.  Here the claim is checked piece by piece against an fp64 run of the oracle
+    (oracle/pattern.py):
       (1) the pattern the HIP forward took (sign of its STORED activations) differs from the fp64 pattern only where the fp64
-          pre-activation is within 1e-4 of the layer's rms from zero (the flip candidates), at a handful of elements;
+          pre-activation is within rounding distance of zero (the flip candidates), at a handful of elements;
       (2) with THAT pattern forced on the fp64 oracle, input, latent and every parameter gradient agree with the HIP backward to the
-          1e-3 bar of the north star, per tensor, in plain relative L2 — no robust metric, no masking."""
-    from esr_hip import act as A
+          bar of the precision (PATTERN_BARS: 'split' the 1e-3 of the north star), per tensor, in plain relative L2 — no robust metric, no
+          masking.  A drift of the kind the round-5 smoke showed for 'mixed' (6.4e-3 -> 9.2e-3 between two builds) is now either flips
+          (this test unchanged) or arithmetic (this test fails)."""
+    from oracle import pattern as PT
+    near, share, dx_bar, dw_bar = PATTERN_BARS[precision]
     net = _rrdb(nb, sf, lat).to(DEV)
+    net.set_precision(precision)
     eng = net.engine
     x = _f4_input(nb, sf, lat)
     g, bufs = eng.run_forward(x.to(DEV), pad=0, keep=True)
     cot = seeded_uniform(tuple(g.shape), 141 + nb + sf + lat, -1.0, 1.0)
     dx, grads = eng.run_backward(tuple(x.shape), 0, bufs, cot.to(DEV), need_dx=True, need_dw=True)
-    # stored activations of the LeakyReLU layers in the oracle's call order: RDB convs 0-3 of every RDB, the upconvs, HR_conv0
-    stored = []
-    for j in range(3 * nb):
-        for i in range(4):
-            stored.append(bufs['rdb'][j].to_nchw(32, cg0=8 + 4 * i).cpu())
-    stored += [b.to_nchw(64).cpu() for b in bufs['ups']] + [bufs['hr0'].to_nchw(64).cpu()]
+    stored = PT.stored_lrelu_outputs(bufs, nb)
     sd64 = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
     x64 = x.double()
-    # fp64 forward, true LeakyReLU: the pre-activations
-    pre = []
-    orig = ro._lrelu
-    try:
-        ro._lrelu = lambda y: (pre.append(y.detach()), orig(y))[1]
-        with torch.no_grad():
-            ro.rrdb_forward(sd64, x64, nb, sf, lat)
-        assert len(pre) == len(stored)
-        flips = 0
-        for p64, s in zip(pre, stored):
-            assert p64.shape == s.shape
-            differ = (p64 > 0) != (s > 0)
-            flips += int(differ.sum())
-            if differ.any():     # every disagreement is a flip candidate: a pre-activation within rounding distance of zero
-                assert float(p64[differ].abs().max()) < 1e-4 * float(p64.pow(2).mean().sqrt()), float(p64[differ].abs().max())
-        assert flips <= 1e-5 * sum(s.numel() for s in stored) + 5, flips
-        # fp64 forward + backward with the GPU's pattern forced
-        it = iter(stored)
-        ro._lrelu = lambda y: torch.where(next(it) > 0, y, 0.2 * y)
-        params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
-        xg = x64.clone().requires_grad_(True)
+    with PT.capture_preactivations() as pre, torch.no_grad():
+        ro.rrdb_forward(sd64, x64, nb, sf, lat)
+    flips, worst_pre = PT.pattern_flips(pre, stored)
+    total = sum(s.numel() for s in stored)
+    assert worst_pre < near, worst_pre           # every disagreement is a flip candidate: a pre-activation within rounding distance of zero
+    assert flips <= share * total + 5, flips
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    xg = x64.clone().requires_grad_(True)
+    with PT.forced_pattern(stored):
         (ro.rrdb_forward(params, xg, nb, sf, lat) * cot.double()).sum().backward()
-    finally:
-        ro._lrelu = orig
-    assert rel_l2(dx.cpu().numpy(), xg.grad.numpy()) < 1e-3, rel_l2(dx.cpu().numpy(), xg.grad.numpy())
-    worst = 0.0
-    for k, p in net.named_parameters():
-        e = rel_l2(grads[p].cpu().numpy(), params[k].grad.numpy())
-        worst = max(worst, e)
-        assert e < 1e-3, (k, e)
-    print('flips %d of %d activations; dx rel_l2 %.2e; worst parameter-gradient rel_l2 %.2e' % (flips, sum(s.numel() for s in stored), rel_l2(dx.cpu().numpy(), xg.grad.numpy()), worst))
+    e_dx = rel_l2(dx.cpu().numpy(), xg.grad.numpy())
+    errs = sorted((rel_l2(grads[p].cpu().numpy(), params[k].grad.numpy()), k) for k, p in net.named_parameters())
+    print('%s nb %d lat %d: flips %d of %d activations (largest |pre| / rms among them %.1e); dx rel_l2 %.2e; parameter-gradient rel_l2 median %.2e worst %.2e (%s)' % (
+        precision, nb, lat, flips, total, worst_pre, e_dx, errs[len(errs) // 2][0], errs[-1][0], errs[-1][1]))
+    assert e_dx < dx_bar, e_dx
+    assert errs[-1][0] < dw_bar, errs[-1]

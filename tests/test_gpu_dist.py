@@ -32,7 +32,7 @@ def _batch(world):
     return seeded_uniform((n, 3, 24, 28), 301), seeded_uniform((n, 3, 96, 112), 302)
 
 
-def _step(seed, lr, hr):
+def _step(seed, lr, hr, precision=None, early=False):
     """One SRRaGANModel generator step (two calls: without a discriminator the first one is idle, as in the reference) on the given shard."""
     _paths()
     import models
@@ -41,6 +41,10 @@ def _step(seed, lr, hr):
     opt['gpu_ids'] = [0]
     torch.manual_seed(seed)                      # rank-dependent initial weights: the constructor's broadcast has to make them rank 0's
     m = models.create_model(opt)
+    if precision is not None:
+        m.netG.generated_image_model.set_precision(precision)
+    if early:
+        m.grad_reducer.ENABLED = True
     for _ in range(2):
         m.feed_data({'LR': lr, 'HR': hr})
         m.optimize_parameters()
@@ -51,7 +55,7 @@ def _step(seed, lr, hr):
     return m, names, grads, weights
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision=None, early=False):
     try:
         _paths()
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
@@ -60,11 +64,11 @@ def _worker(rank, world, port, q):
         D.init_from_env(backend='gloo')
         lr, hr = _batch(world)
         lo, hi = D.shard_range(lr.size(0))
-        m, names, grads, weights = _step(rank, lr[lo:hi], hr[lo:hi])
+        m, names, grads, weights = _step(rank, lr[lo:hi], hr[lo:hi], precision, early)
         pick = [names[0], names[len(names) // 2], names[-2]]
         q.put((rank, (lo, hi), {k: grads[k] for k in pick}, {k: weights[k] for k in pick},
                float(sum(float(np.abs(g).sum()) for g in grads.values())), int(m.grad_reducer.in_place), len(m.grad_reducer.buckets),
-               float(m.get_current_log()['l_g_pix'])))
+               float(m.get_current_log()['l_g_pix']), int(m.grad_reducer.early_buckets)))
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -87,7 +91,7 @@ def test_two_ranks_on_one_gpu_average_the_generator_gradients_in_place():
     [p.join(timeout=120) for p in procs]
     for r in res:
         assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
-    (_, sh0, g0, w0, n0, inplace0, nb0, l0), (_, sh1, g1, w1, n1, inplace1, nb1, l1) = res
+    (_, sh0, g0, w0, n0, inplace0, nb0, l0, _), (_, sh1, g1, w1, n1, inplace1, nb1, l1, _) = res
     assert sh0 == (0, PER_RANK) and sh1 == (PER_RANK, 2 * PER_RANK)
     assert inplace0 == nb0 >= 1 and inplace1 == nb1          # every bucket was reduced in place on the flat weight-gradient buffer
     assert n0 == n1
@@ -102,6 +106,38 @@ def test_two_ranks_on_one_gpu_average_the_generator_gradients_in_place():
             # fp32-class 1e-3 of the weight-gradient tests
             assert rel_l2(g0[k], ref) < 1e-3, (k, rel_l2(g0[k], ref))
     assert l0 != l1                                            # the ranks really saw different shards
+
+
+def _two_ranks(precision, early):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, precision, early)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
+    return res
+
+
+@pytest.mark.parametrize('precision', ['mixed', 'bf16'])
+def test_early_exchange_on_two_ranks_with_different_shards_equals_the_exchange_after_the_backward(precision):
+    """'mixed' back-propagates under power-of-two gradient scales that every RANK derives from its own gradients; a flat dW
+    buffer that is all-reduced before those scales are undone mixes differently scaled sums and then divides by the local scale — different,
+    wrong gradients on every rank, invisible at world size 1.  The engine therefore leaves scaled (and permuted) gradient sets to the exchange
+    after the backward.  Two ranks, different shards: with train.early_gradient_exchange switched on both ranks must end with the gradients
+    and weights of the late exchange, bit for bit — for 'mixed' through the late path (no early bucket), for 'bf16' through the two-stream
+    backward's groups (three early buckets; a two-rank sum does not depend on how the buffer is cut)."""
+    late, early = _two_ranks(precision, False), _two_ranks(precision, True)
+    for r in range(2):
+        for k in late[r][2]:
+            assert np.array_equal(late[r][2][k], early[r][2][k]) and np.array_equal(late[r][3][k], early[r][3][k]), (precision, r, k)
+    for k in early[0][2]:
+        assert np.array_equal(early[0][2][k], early[1][2][k]) and np.array_equal(early[0][3][k], early[1][3][k]), k       # the replicas stay replicas
+    assert early[0][7] != early[1][7]                          # different shards (different pixel losses)
+    assert [r[8] for r in late] == [0, 0]
+    assert [r[8] for r in early] == ([0, 0] if precision == 'mixed' else [3, 3]), [r[8] for r in early]
 
 
 def _run_bench(extra, timeout):
@@ -136,6 +172,27 @@ def test_bench_training_step_workload_on_two_ranks():
     assert set(d['phases_ms']) >= {'G_forward', 'D_step', 'G_losses_and_backward', 'G_allreduce_and_Adam'}
     assert all(np.isfinite(v) for v in d['losses'].values()), d['losses']
     assert abs(d['value'] - 2 * 32 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+
+
+def test_bench_default_line_on_two_ranks_carries_the_training_step_with_its_communication_diagnosis():
+    """the first N > 1 record has to answer the communication questions by itself.  `bench.py --gpus 2` (default workload)
+    appends `extra_workloads.c3` — the only workload with data-path collectives — with a `comm` block: the step with the gradient exchange
+    after the backward, from inside it, and without any exchange, and the exposed communication time derived from them; the ranks' backend is
+    in `ranks`.  The headline keys are those of the N = 1 line."""
+    d = _run_bench(['--no-cpu-baseline', '--no-alt-precision'], 1800)
+    assert d['n_gpus'] == 2 and d['world_size_seen'] == 2 and d['config']['workload'].startswith('configs[1]')
+    assert abs(d['value'] - 2 * 32 * 512 * 512 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    assert all(r['backend'] == 'gloo' for r in d['ranks']) and len(d['ranks']) == 2
+    c3 = d['extra_workloads']['c3']
+    assert 'error' not in c3, c3
+    assert set(d['extra_workloads']) == {'c3'}                  # the single-GPU blocks (c5, c4) are not repeated per N
+    assert c3['n_gpus'] == 2 and 'G_allreduce_and_Adam' in c3['phases_ms']
+    comm = c3['comm']
+    for k in ('ms_per_step_exchange_after_backward', 'ms_per_step_exchange_inside_backward', 'ms_per_step_no_exchange', 'exposed_comm_ms'):
+        assert np.isfinite(comm[k]), (k, comm)
+    assert comm['ms_per_step_exchange_after_backward'] > 0 and comm['ms_per_step_exchange_inside_backward'] > 0 and comm['ms_per_step_no_exchange'] > 0
+    assert comm['early_buckets'] >= 1 and comm['G_gradient_bytes'] > 60e6 and comm['backend'] == 'gloo'
+    assert abs(comm['exposed_comm_ms'] - (comm['ms_per_step_exchange_after_backward'] - comm['ms_per_step_no_exchange'])) < 1e-9
 
 
 def _zsearch(D, batch):

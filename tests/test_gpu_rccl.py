@@ -113,7 +113,8 @@ def _worker(rank, world, port, what, q):
         rows = D.gather_scalars(t[:3])
         info['gather_rows'] = rows.cpu().tolist()
         info['mean_scalar'] = D.all_reduce_mean_scalar(2.5 + rank, torch.device('cuda'))
-        res = _generator_steps() if what == 'g' else (_generator_steps(bucket_kb=256) if what == 'g_small' else (_generator_steps(precision='bf16', early=True) if what == 'g_overlap' else _gan_steps()))
+        res = {'g': _generator_steps, 'g_small': lambda: _generator_steps(bucket_kb=256), 'g_overlap': lambda: _generator_steps(precision='bf16', early=True),
+               'g_bf16': lambda: _generator_steps(precision='bf16'), 'gan': _gan_steps}[what]()
         q.put((rank, info, res))
         dist.barrier()
         dist.destroy_process_group()
@@ -228,6 +229,27 @@ def test_two_gpus_over_rccl_average_the_generator_gradients_in_place():
     assert g0['l_g_pix'] != g1['l_g_pix']                                           # they saw different shards
     ref = _generator_steps(shard=(0, 4))                                            # one process on the whole batch: the mean of the shards' gradients
     assert abs(g0['gsum'] - ref['gsum']) < 2e-3 * ref['gsum'], (g0['gsum'], ref['gsum'])
+
+
+@needs2
+def test_two_gpus_two_stream_backward_with_early_exchange_equals_the_exchange_after_the_backward():
+    """The early gradient exchange of the two-stream backward (three groups all-reduced behind their own launches on RCCL's stream, the main
+    stream joining at the end) on two REAL ranks with different shards: gradients and weights after three steps are those of the same job with
+    the exchange after the backward, bit for bit, and the two replicas agree."""
+    late, early = _spawn(2, 'g_bf16'), _spawn(2, 'g_overlap')
+    assert all(r[1]['backend'] == 'nccl' for r in late + early)
+    assert [r[2]['early'] for r in early] == [3, 3] and [r[2]['early'] for r in late] == [0, 0]
+    assert early[0][2]['grads'] == early[1][2]['grads'] == late[0][2]['grads'] == late[1][2]['grads']
+    assert early[0][2]['weights'] == early[1][2]['weights'] == late[0][2]['weights']
+    assert early[0][2]['l_g_pix'] != early[1][2]['l_g_pix']
+
+
+@needs2
+def test_bench_default_line_on_two_gpus_carries_the_communication_diagnosis():
+    d = _bench_under_launcher(2, ['--no-cpu-baseline', '--no-alt-precision'], 1800)
+    comm = d['extra_workloads']['c3']['comm']
+    assert comm['backend'] == 'nccl' and comm['early_buckets'] == 3
+    assert all(np.isfinite(comm[k]) and comm[k] > 0 for k in ('ms_per_step_exchange_after_backward', 'ms_per_step_exchange_inside_backward', 'ms_per_step_no_exchange'))
 
 
 @needs2
