@@ -168,7 +168,7 @@ def kernel_set_id():
     every summary they write; this file prints a static PMC field only when the stamp equals the current sources'."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('esr_conv.hip', 'esr_conv_dev.h', 'esr_chain.hip', 'esr_cem.hip', 'esr_common.h'):
+    for f in ('esr_conv.hip', 'esr_cem.hip', 'esr_common.h'):
         path = os.path.join(ROOT, 'explorable-super-resolution_amd', 'csrc', f)
         if not os.path.exists(path):
             continue

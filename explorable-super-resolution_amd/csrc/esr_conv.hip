@@ -23,9 +23,617 @@
 //   epilogue       compile-time specialised (EPI bits): bias, LeakyReLU, alpha*y + beta1*r1 + beta2*r2, act' mask
 //                  (data-gradient use), re-split to hi/lo via v_cvt_pk_bf16_f32, pairs of channel groups exchanged with
 //                  v_permlane32_swap so that every lane stores one full 16-byte pixel vector
-#include "esr_conv_dev.h"
+#include "esr_common.h"
+#include <type_traits>
+#include <vector>
 
 namespace {
+
+constexpr int NW = 4;          // waves per workgroup
+constexpr int NTHREADS = 64 * NW;
+constexpr int MAXS_BASE = 3;   // activation DMA slots (64 pixel vectors) per wave per plane: NPIX_L <= MAXS*NW*64
+// Resident workgroups per CU the single-stage kernels are built (registers) and tiled (LDS) for, per M-tile count.  Measured on MI355X
+// (RRDB-23 forward, ms): MT1/MT2 3/2: 76.7, 2/2: 72.9, 1/2: 74.6, 2/1: 85.4, 1/1: 85.5.  The chip is power-limited under this kernel
+// (DESIGN.md): beyond the overlap that reaches the power cap, more resident waves cost clock.
+constexpr int WGS_MT1 = 2, WGS_MT2 = 2;
+// 32-pixel column tiles per wave (R) and activation DMA slots per wave per plane (MAXS), per M-tile count: a workgroup tile holds up to
+// NW*R*32 flattened pixels.  (R = 6 for the 32-channel kernels — half the weight copies per pixel, less halo — was measured in rounds 3 and 5:
+// no gain at configs[1] / configs[4], -10 % at configs[2]; profiles/r05_r6_tiles_ab.log.  Experiment variants of this file are patches or
+// sed-edited scratch copies built to a side library, never switches in here.)
+constexpr int r_of(int mt) { return 3; }
+constexpr int maxs_of(int mt) { return r_of(mt) > 3 ? MAXS_BASE + 1 : MAXS_BASE; }
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// epilogue feature bits (template parameter EPI)
+constexpr int EPI_RES1 = 1, EPI_RES2 = 2, EPI_MASK = 4, EPI_NCHW = 8, EPI_OUT2 = 16;
+// residual 1 is a channel-group slice of the conv's own input (RDB conv5: out = 0.2*conv + x, block.py:235): it is added to the
+// accumulators from the LDS copy the K loop stages anyway, so the epilogue has no residual loads at all
+constexpr int EPI_RESIN = 32;
+// pixel-shuffle store (esr_conv3x3_desc.pixel_shuffle): its own instantiations, so that the plain store carries none of its index arithmetic
+constexpr int EPI_PS = 64;
+
+struct ConvArgs {
+    // ---- what the prologue decodes before it can issue the first copy (one kernarg batch): the tile space, the tile geometry and the
+    // divisions by launch constants turned into multiplications on the host (esr_conv3x3: magic numbers, the waves' copy shares)
+    int tiles_x, tiles_y, ntiles;
+    int xcd_q, xcd_r;               // ntiles = 8 * xcd_q + xcd_r: XCD x sweeps xcd_q (+1 if x < xcd_r) consecutive tiles
+    unsigned m_tx, m_ty;            // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y); 0 when the divisor is 1 ...
+    unsigned i_tx, i_ty;            // ... and then these are 1: n / d = umulhi(n, m) + n * i, no branch
+    int TH, TW, P, NPIX_T, NPIX_L, nslots;      // nslots = 1-KiB copy slots (64 pixel vectors) per plane, the last one partial
+    unsigned m_P, m_ups;            // ceil(2^20 / P), ceil(2^16 / ups)
+    int H, W, Win_p, ups;           // output interior; padded input row pitch (W_in + 2); input upsample factor
+    unsigned share[NW];             // per wave: activation slots | first weight fragment << 8 | weight fragments << 16 (dma_share)
+    int ncp, lo_chunks, reverse, B; // chunks [0, lo_chunks) carry a lo activation plane, later ones are hi-only (PARTLO kernels); reverse: walk the tile space backwards (cache-reuse hint)
+    DView in0, in1;
+    const uint4* wpack;
+    // where chunk cp's / tap t's fragments sit in the pack: normally 9 * MT * NPW and MT * NPW fragments apart.  A 64-channel layer of a SMALL
+    // launch is run as two 32-channel slices by the MT = 1 kernel out of the same [chunk][tap][M tile][plane] pack: slice s starts s * NPW
+    // fragments in and its taps are 2 * NPW fragments apart
+    long long wchunk;               // 16-byte vectors between the fragments of consecutive chunks
+    long long wslice;               // 16-byte vectors between the weight fragments of consecutive output slices (0: no slices)
+    int wtap;                       // fragments between consecutive taps
+    int nslices;                    // output slices of this launch (blockIdx.y): cout / 64 when cout > 64; 2 for a 64-channel layer run as two 32-channel halves
+    // ---- epilogue
+    const float* zero_bias;
+    int bias_stride;                // 1, or 0 when `bias` is the zero block (output slices step through a real bias only)
+    const float* bias;              // never NULL in the kernel: a launch without a bias points at the library's zero block (zero_bias())
+    int cout, ncg_out;              // output channels of one slice, and their groups
+    float act_slope, alpha, beta1, beta2;
+    DView res1, res2, out, out2, mask;
+    float* out_nchw;
+    int mask_cg0, mask_cg1;
+    float mask_slope;
+    int resin_g0;                   // EPI_RESIN: index (in the concatenated in0|in1 group order) of the residual's first group
+    float resin_scale;              // beta1 / alpha
+    int ps, ps_rg0;                 // pixel-shuffle store: factor r (0 = plain) and the first row group of this launch (esr_hip.h)
+    // split K (esr_conv3x3_desc.k_split_ws): blockIdx.z = which run of `ncp` chunks (kz_groups channel groups) of the input this workgroup
+    // contracts; its fp32 partial sums go to slab z of the workspace ([B][nchw_ctot][H][W] each, EPI_NCHW store), bias in slab 0 only
+    int ksplit, kz_groups;
+    long long kz_slab;              // floats between two slabs
+    int nchw_ctot;                  // channels of the fp32 NCHW destination (== cout unless the launch covers output slices)
+    int stages_hint;                // esr_conv3x3_desc.lds_stages
+    unsigned* range_flag;           // esr_conv3x3_desc.range_flag / range_tag (fp16 formats)
+    unsigned range_tag;
+#ifdef ESR_TRACE
+    unsigned long long* trace;   // debug build only: per-workgroup phase timestamps (128 slots each)
+#endif
+};
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+    if (FMT) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two floats -> packed 16-bit pair of format FMT (round to nearest even); low half = first argument
+template <int FMT>
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi);
+
+// two floats -> packed bf16x2 (round to nearest even); low half = first argument
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t cvt_pk<0>(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t cvt_pk<1>(float lo, float hi) { return f2h(lo) | (f2h(hi) << 16); }
+
+// Asynchronous global -> LDS copy, 16 bytes per lane: LDS destination = (wave-uniform) lds_dst + lane*16; the source is a uniform base
+// (SGPR pair) + a per-lane 32-bit byte offset: no 64-bit per-lane address arithmetic per copy (the offsets of a tile's slots are computed once
+// per tile, the bases once per chunk).
+// Issued through inline asm on purpose: hipcc treats the builtin form as a pending LDS write and drains vmcnt(0) in front of
+// every later ds_read, which would serialise the copy of step s+1 with the MFMAs of step s.  Hidden from the compiler, the
+// copy is ordered by hand: wait_vm_upto() + barrier before the first read of a stage (see the step loop).
+// M0 (the DMA's LDS base) is not preserved by hipcc across statements and no other instruction of this kernel reads it.
+__device__ __forceinline__ void glds16s(const uint4* sbase, unsigned voff, unsigned lds_dst) {
+    // (readfirstlane: the destination is wave-uniform by construction, but the compiler cannot always prove it and M0 takes a scalar)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+// n / d for a launch constant d: m = ceil(2^32 / d) from the host, exact while n * d < 2^32 (tile indices: n < 2^22, d < 2^10); d = 1 comes
+// as m = 0, i = 1 (2^32 does not fit): branch-free, so that nothing in the prologue keeps the kernel-argument loads from being batched
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned i) { return __umulhi(n, m) + n * i; }
+
+// base pointer (hi or lo) of input channel group g for image b; groups past the end alias group 0 of in1
+// (their packed weights are zero, the data only has to be finite)
+__device__ __forceinline__ const uint4* in_plane(const ConvArgs& a, int g, int b, bool lo) {
+    if (g < a.in0.ncg) return (lo ? a.in0.lo : a.in0.hi) + b * a.in0.bs + g * a.in0.cs;
+    int g1 = g - a.in0.ncg;
+    if (g1 >= a.in1.ncg) g1 = 0;
+    return (lo ? a.in1.lo : a.in1.hi) + b * a.in1.bs + g1 * a.in1.cs;
+}
+
+// The activation copies of a tile: up to MAXS slots (64 pixel vectors = 1 KiB each) per wave and plane.  soff = the lane's source BYTE offset
+// inside a plane (~0: a lane past the tile's last pixel vector, copies nothing); slot = the LDS slot it fills (uniform).  Pixels of the
+// flattened tile that lie outside the padded image read the plane's (0,0) border vector, which is zero.
+template <int MAXS>
+struct FetchState {
+    unsigned soff[MAXS];
+    int slot[MAXS];
+};
+
+// Flattened-tile pixel p -> (row, column) with the pitch division as a multiplication (m_P = ceil(2^20 / P): exact for p * P < 2^20, and
+// p < 1024, P <= 386), nearest-upsample source coordinate (c - 1 + ups) / ups the same way (m_ups = ceil(2^16 / ups): exact for
+// coordinates < 2^15, checked by the host; ups = 1: the identity).
+template <int MAXS>
+__device__ __forceinline__ FetchState<MAXS> setup_tile(const ConvArgs& a, int x0, int y0, int wave, int lane) {
+    FetchState<MAXS> f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        // (a slot index past the tile re-fetches this wave's first slot; dma_chunk never issues it: the wave's share says how many it owns)
+        f.slot[s] = (wave + s * NW) < a.nslots ? wave + s * NW : wave;
+        const unsigned p = (unsigned)f.slot[s] * 64 + lane;
+        const unsigned rr = __umul24(p, a.m_P) >> 20, cc = p - rr * a.P;
+        const unsigned Yp = y0 + rr, Xp = x0 + cc;
+        const bool inb = (p < (unsigned)a.NPIX_T) && (Yp < (unsigned)a.H + 2) && (Xp < (unsigned)a.W + 2);
+        const unsigned sy = __umul24(Yp + a.ups - 1, a.m_ups) >> 16, sx = __umul24(Xp + a.ups - 1, a.m_ups) >> 16;
+        // (the pad of the last slot is not copied: it would land in the next plane.  Rounding the planes up to whole slots instead — no
+        // per-lane predicate at all — measured +2.6 % on the configs[1] forward: 7 % more bytes into LDS under the power cap)
+        f.soff[s] = p >= (unsigned)a.NPIX_L ? ~0u : (inb ? (sy * a.Win_p + sx) * 16 : 0);
+    }
+    return f;
+}
+
+// source bases of one step: the 2*NPL input planes (group-major, hi|lo) of chunk cp in image b, and the chunk's weight fragments
+template <int NPL>
+struct Bases {
+    const uint4* p[2 * NPL];
+    const uint4* w;
+    int wtap;
+};
+template <int NPL, int MT, int NPW>
+__device__ __forceinline__ Bases<NPL> make_bases(const ConvArgs& a, int cp, int b) {
+    Bases<NPL> r;
+#pragma unroll
+    for (int i = 0; i < 2 * NPL; ++i) r.p[i] = in_plane(a, 2 * cp + i / NPL, b, (i % NPL) == 1);
+    r.w = a.wpack + (size_t)cp * a.wchunk;                     // uniform: the lane's 16 bytes are the copy's per-lane offset
+    r.wtap = a.wtap;
+    return r;
+}
+
+// Which copies of a chunk this wave issues.  A chunk is 2*NPL activation planes x `nslots` 1-KiB slots plus NWI 1-KiB weight fragments; wave w
+// owns the slots w, w + NW, ... (setup_tile) and a contiguous range of weight fragments sized so that every wave issues the same number of
+// copies (+-1): a 1-KiB global_load_lds occupies its in-order wave for 90-150 cycles (profiles/microbench/ingest_paths.hip), the barrier
+// behind the copies waits for the slowest wave, and nothing is fetched twice.  Computed on the HOST per launch (dma_share_host; the kernel
+// reads its wave's packed word from the kernel arguments).
+struct DmaShare {
+    int nsl;                   // activation slots of this wave
+    int w0, wc;                // its weight fragments [w0, w0 + wc)
+};
+__device__ __forceinline__ DmaShare unpack_share(unsigned w) { return DmaShare{(int)(w & 0xFF), (int)((w >> 8) & 0xFF), (int)(w >> 16)}; }
+// number of copies dma_chunk() issues (for the counted waits of the two-stage kernels)
+// TMODE != 0 (tap-masked kernels): only the 4 * MT * NPW fragments of the chunk's live taps are copied, wave k those of the k-th live tap
+// (per M tile: its own k-th live tap) — MT * NPW copies per wave whatever the chunk's tap set is
+template <int NPL, int MT = 1, int NPW = 1, int TMODE = 0>
+__device__ __forceinline__ int dma_count(const DmaShare& d, bool xlo) { return (xlo ? 2 * NPL : 2) * d.nsl + (TMODE != 0 ? MT * NPW : d.wc); }
+
+// tsel (TMODE 1: the chunk's tap-set index (cp >> 1) & 3; TMODE 2: parity of the output slice): the live taps of an embedded stride-2 conv are
+// the 2x2 block of taps at (r0, c0): S2D_FWD[q] -> (1 - (q >> 1), 1 - (q & 1)), S2D_FLIP[q] -> (q >> 1, q & 1) with q = 2 * parity + m.  The dead
+// taps' fragments (5 of 9: zeros in the pack) are neither copied nor read — on the 512-channel layers the weight copies ARE the launch.
+template <int NPL, int MT, int NPW, int TMODE = 0>
+__device__ __forceinline__ void dma_chunk(const FetchState<maxs_of(MT)>& f, const Bases<NPL>& bs, const DmaShare& d, unsigned stage, int plane_bytes, bool xlo,
+                                          int tsel = 0, int wave = 0) {
+    constexpr int MAXS = maxs_of(MT);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s >= d.nsl) break;                          // wave-uniform
+        const unsigned dst = stage + (unsigned)f.slot[s] * 1024;
+        if (f.soff[s] != ~0u) {                         // per lane; one predicate per slot, not per copy
+#pragma unroll
+            for (int cgpl = 0; cgpl < 2 * NPL; ++cgpl) {
+                if (!xlo && (cgpl % NPL) == 1) continue;    // this chunk's groups have no lo plane
+                glds16s(bs.p[cgpl], f.soff[s], dst + cgpl * plane_bytes);
+            }
+        }
+    }
+    const unsigned vlane = (unsigned)(threadIdx.x & 63) * 16;
+    if constexpr (TMODE == 0 && MT == 1) {
+        // (the pack may be a wider layer's: fragment j = tap * NPW + plane sits (tap * wtap + plane) fragments in — ConvArgs.wtap)
+        for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + ((j / NPW) * bs.wtap + j % NPW) * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+    } else if constexpr (TMODE == 0) {
+        for (int j = d.w0; j < d.w0 + d.wc; ++j) glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+    } else {
+        static_assert(TMODE == 0 || NW == 4, "one live tap per wave");
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r0 = TMODE == 1 ? 1 - (tsel >> 1) : tsel, c0 = TMODE == 1 ? 1 - (tsel & 1) : m;
+            const int tap = (r0 + (wave >> 1)) * 3 + c0 + (wave & 1);
+#pragma unroll
+            for (int pl = 0; pl < NPW; ++pl) {
+                const int j = (tap * MT + m) * NPW + pl;
+                glds16s(bs.w + j * 64, vlane, stage + 2 * NPL * plane_bytes + j * 1024);
+            }
+        }
+    }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  MAXN = the largest count the calling kernel can ask
+// for (its waves' copy shares are bounded by the tile format): the cases above it are not compiled.
+template <int MAXN>
+__device__ __forceinline__ void wait_vm_upto(int n) {
+#define ESR_VMC(k) case k: if constexpr (k <= MAXN) { asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break; }
+    switch (n) {
+        ESR_VMC(1) ESR_VMC(2) ESR_VMC(3) ESR_VMC(4) ESR_VMC(5) ESR_VMC(6) ESR_VMC(7) ESR_VMC(8) ESR_VMC(9) ESR_VMC(10) ESR_VMC(11) ESR_VMC(12)
+        ESR_VMC(13) ESR_VMC(14) ESR_VMC(15) ESR_VMC(16) ESR_VMC(17) ESR_VMC(18) ESR_VMC(19) ESR_VMC(20) ESR_VMC(21) ESR_VMC(22) ESR_VMC(23)
+        ESR_VMC(24) ESR_VMC(25) ESR_VMC(26) ESR_VMC(27) ESR_VMC(28) ESR_VMC(29) ESR_VMC(30) ESR_VMC(31) ESR_VMC(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;       // 0, or more than the cases cover: wait for everything (always safe)
+    }
+#undef ESR_VMC
+}
+
+// Residual / mask operand of one PAIR of channel groups (cg0, cg0+1) at this lane's pixel, read the way the output is stored:
+// lanes 0-31 load the full 16-byte pixel vector of group cg0, lanes 32-63 that of group cg0+1 (one coalesced b128 load per
+// plane, uniform per-image base + 32-bit lane offset); res_unpack() then exchanges halves (v_permlane32_swap) into the accumulator
+// arrangement: this lane's 4 channels (4*half .. 4*half+3) of both groups.
+struct ResRaw { uint4 h, l; };
+__device__ __forceinline__ void swap_halves(const uint4& x, uint32_t (&d)[2][2]) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(x.x, x.z, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(x.y, x.w, false, false);
+    d[0][0] = s0[0]; d[0][1] = s1[0]; d[1][0] = s0[1]; d[1][1] = s1[1];
+}
+template <int FMT>
+__device__ __forceinline__ void res_unpack(const ResRaw& q, bool has_lo, f32x2 (&rv)[2][2]) {
+    uint32_t d[2][2];
+    swap_halves(q.h, d);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rv[k][j] = f32x2{e2f<FMT>(d[k][j] & 0xFFFF), e2f<FMT>(d[k][j] >> 16)};
+    if (has_lo) {
+        swap_halves(q.l, d);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rv[k][j] += f32x2{e2f<FMT>(d[k][j] & 0xFFFF), e2f<FMT>(d[k][j] >> 16)};
+    }
+}
+
+// EPI_RESIN: the two input groups of chunk cp are in the LDS stage right now; if they belong to the residual slice, add this lane's 4
+// channels of the centre-tap pixel (exactly hi + lo, in fp32) to the matching accumulator rows.
+template <int NPL, int MT, int R, int FMT>
+__device__ __forceinline__ void resin_accumulate(f32x16 (&acc)[MT][R], const ConvArgs& a, const unsigned char* stage, int cp, bool xlo, int P,
+                                                 int plane_bytes, int wave, int lane) {
+#pragma unroll
+    for (int sgrp = 0; sgrp < 2; ++sgrp) {
+        const int og = 2 * cp + sgrp - a.resin_g0;              // output group fed by this input group (uniform)
+        if (og < 0 || og * 8 >= a.cout) continue;
+        float x[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned char* const pr = stage + sgrp * NPL * plane_bytes + ((wave + r * NW) * 32 + (lane & 31) + P + 1) * 16 + (lane >> 5) * 8;
+            const uint2 h = *(const uint2*)pr;
+            x[r][0] = e2f<FMT>(h.x & 0xFFFF); x[r][1] = e2f<FMT>(h.x >> 16); x[r][2] = e2f<FMT>(h.y & 0xFFFF); x[r][3] = e2f<FMT>(h.y >> 16);
+            if (NPL == 2 && xlo) {
+                const uint2 l = *(const uint2*)(pr + plane_bytes);
+                x[r][0] += e2f<FMT>(l.x & 0xFFFF); x[r][1] += e2f<FMT>(l.x >> 16); x[r][2] += e2f<FMT>(l.y & 0xFFFF); x[r][3] += e2f<FMT>(l.y >> 16);
+            }
+        }
+        // (uniform switch with the row group as a compile-time constant per case: accumulator rows are register indices — an if-chain over an
+        // unrolled index gets re-rolled into a run-time index, which sends the whole accumulator array to scratch)
+        auto add = [&](auto MG) {
+            constexpr int mg = decltype(MG)::value;
+            if constexpr (mg < MT * 4) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mg / 4][r][(mg % 4) * 4 + i] = fmaf(a.resin_scale, x[r][i], acc[mg / 4][r][(mg % 4) * 4 + i]);
+            }
+        };
+        switch (og) {
+            case 0: add(std::integral_constant<int, 0>{}); break;
+            case 1: add(std::integral_constant<int, 1>{}); break;
+            case 2: add(std::integral_constant<int, 2>{}); break;
+            case 3: add(std::integral_constant<int, 3>{}); break;
+            case 4: add(std::integral_constant<int, 4>{}); break;
+            case 5: add(std::integral_constant<int, 5>{}); break;
+            case 6: add(std::integral_constant<int, 6>{}); break;
+            default: add(std::integral_constant<int, 7>{}); break;
+        }
+    }
+}
+
+// The MFMAs of one chunk (2 channel groups x 9 taps) out of one LDS stage, with the fragment reads of tap t+1 interleaved between the
+// MFMAs of tap t (sched_barrier-pinned).  XLO: the chunk's activations have a lo plane.  Terms per product, in issue order:
+// Wlo*Xhi (if the weights have a lo plane), Whi*Xlo (if XLO), Whi*Xhi.
+// TM0 / TM1 (compile time): 9-bit masks of the taps whose weights are not structurally zero for M tile 0 / 1 of this chunk; the unrolled
+// loops below drop the dead MFMAs and the fragment reads nobody needs (no run-time branches: those cost more than the MFMAs they save)
+template <int NPL, int MT, int R, int NPW, int FMT, bool XLO, int NTERM_CAP, int TM0 = 0x1FF, int TM1 = 0x1FF>
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[MT][R], const unsigned char* sa, const unsigned char* sb, int P, int plane_bytes) {
+    constexpr int TMU = TM0 | (MT == 2 ? TM1 : 0);      // taps any M tile needs: the activation fragments to read
+#define ESR_TAP_LIVE(t, m) ((((m) == 0 ? TM0 : TM1) >> (t)) & 1)
+    constexpr int NPB = XLO ? NPL : 1;                                   // activation planes read
+    constexpr int NT_FULL = 1 + (NPW == 2 ? 1 : 0) + (NPB == 2 ? 1 : 0);
+    constexpr int NTERM = NT_FULL < NTERM_CAP ? NT_FULL : NTERM_CAP;      // NTERM_CAP < 3 only in ablation builds
+    constexpr int NM = MT * R * NTERM;
+    constexpr int NLA = MT * NPW, NLB = R * NPB, NL = NLA + NLB;
+    constexpr int NSLOT = NM > NL ? NM : NL;
+    uint4 fa[2][MT][NPW], fb[2][R][NPB];
+    // read order inside a tap: [A plane of the first term x MT, B hi x R, then the other A plane x MT (if any), B lo x R (if any)] — what
+    // the first MFMAs of the next tap need comes first
+    auto load_frag = [&](int t, int k, int buf) {
+        const int tapoff = ((t / 3) * P + (t % 3)) * 16;
+        if (!((TMU >> t) & 1)) return;               // nobody multiplies this tap
+        if (k < MT) {
+            const int pl = NPW == 2 ? 1 : 0;
+            if (ESR_TAP_LIVE(t, k)) fa[buf][k][pl] = *(const uint4*)(sa + ((t * MT + k) * NPW + pl) * 1024);
+        } else if (k < MT + R) {
+            fb[buf][k - MT][0] = *(const uint4*)(sb + (k - MT) * NW * 512 + tapoff);
+        } else if (NPW == 2 && k < 2 * MT + R) {
+            const int idx = k - MT - R;
+            if (ESR_TAP_LIVE(t, idx)) fa[buf][idx][0] = *(const uint4*)(sa + ((t * MT + idx) * NPW) * 1024);
+        } else {
+            const int idx = k - (NPW == 2 ? 2 * MT + R : MT + R);
+            fb[buf][idx][NPB - 1] = *(const uint4*)(sb + idx * NW * 512 + tapoff + (NPB - 1) * plane_bytes);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load_frag(0, k, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int cb = t & 1;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NM) {
+                // the NTERM terms are the LAST NTERM entries of [Wlo*Xhi (needs NPW == 2), Whi*Xlo (needs XLO), Whi*Xhi]
+                const int ti = i / (MT * R), rem = i % (MT * R), r = rem % R, m = rem / R;
+                constexpr int has0 = NPW == 2 ? 1 : 0, has1 = NPB == 2 ? 1 : 0;
+                const int skip = NT_FULL - NTERM;                             // ablation: drop leading terms
+                const int idx = ti + skip;                                    // index into the present-term list
+                const int term = (idx < has0) ? 0 : ((idx < has0 + has1) ? 1 : 2);
+                const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+                if (!ESR_TAP_LIVE(t, m)) {
+                    // this tap's weights for M tile m are structurally zero (compile-time: t and m are unrolled constants)
+                } else acc[m][r] = mfma<FMT>(fa[cb][m][pa], fb[cb][r][pb], acc[m][r]);
+            }
+            if (t < 8 && i < NL) load_frag(t + 1, i, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+#undef ESR_TAP_LIVE
+
+// tap masks of the critic's stride-2 convs run as 3x3 convs over the space-to-depth input (esr_hip/critic.py): by parity s = 2 py + px of a
+// 32-channel tile, the non-zero taps of the embedded weight (bit 3 ty + tx) — and of its flipped / transposed form (data gradient)
+constexpr int S2D_FWD[4] = {432, 216, 54, 27}, S2D_FLIP[4] = {27, 54, 216, 432};
+
+// ---- epilogue.  D layout (32x32 MFMA): lane holds pixel column j = lane&31 and, for register i, output row (i&3) + 8*(i>>2) + 4*(lane>>5):
+// i>>2 selects the 8-channel group inside the 32-row tile, (i&3) + 4*(lane>>5) the channel inside the group -> 4 consecutive channels = 8 bytes
+// of bf16.  Two groups are paired through v_permlane32_swap so that every lane stores one full 16-byte pixel vector: lanes 0-31 group cg0's,
+// lanes 32-63 group cg0+1's (same pixel).
+//
+// What depends only on (tile, lane) is computed ONCE, in front of the K loop where a lone workgroup waits for its first copies anyway
+// (epi_coords): per column tile the lane's byte offset inside an activation plane and `lim` = how many output groups the lane may store
+// (0: its pixel is pitch padding or outside the image; ncg_out - half otherwise, so that one compare `cg0 < lim` covers both the pixel and
+// the existence of group cg0 + half).  KIND 1 (fp32 NCHW destination): poff = byte offset inside a channel plane, lim without the half
+// term (every lane stores its own 4 channels of both groups); KIND 2 (pixel-shuffle store): poff = Y << 16 | X.
+template <int R>
+struct EpiCoord {
+    int lim[R];
+    unsigned poff[R];
+};
+template <int R, int KIND>
+__device__ __forceinline__ EpiCoord<R> epi_coords(const ConvArgs& a, int x0, int y0, int wave, int lane) {
+    EpiCoord<R> e;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned q = (wave + r * NW) * 32 + (lane & 31);
+        const unsigned rr = __umul24(q, a.m_P) >> 20, cc = q - rr * a.P;
+        const unsigned Y = y0 + rr, X = x0 + cc;
+        const bool valid = (rr < (unsigned)a.TH) && (cc < (unsigned)a.TW) && (Y < (unsigned)a.H) && (X < (unsigned)a.W);
+        e.lim[r] = valid ? (KIND == 1 ? a.ncg_out : a.ncg_out - half) : 0;
+        if (KIND == 1) e.poff[r] = (__umul24(Y, a.W) + X) * 4;
+        else if (KIND == 2) e.poff[r] = (Y << 16) | X;
+        else e.poff[r] = valid ? (__umul24(Y + 1, a.W + 2) + X + 1) * 16 : 0;
+    }
+    return e;
+}
+
+template <int NPL, int MT, int R, int EPI, int FMT, bool PARTLO>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][R], const int b, const EpiCoord<R>& ec, const int lane) {
+    constexpr bool HAS_R1 = (EPI & EPI_RES1) != 0, HAS_R2 = (EPI & EPI_RES2) != 0, HAS_MK = (EPI & EPI_MASK) != 0;
+    constexpr bool NCHW = (EPI & EPI_NCHW) != 0, OUT2 = (EPI & EPI_OUT2) != 0, PS = (EPI & EPI_PS) != 0;
+    const int half = lane >> 5;
+    const long long bl = b;
+    const f32x2 slope2 = {a.act_slope, a.act_slope}, alpha2 = {a.alpha, a.alpha};
+    // per-image plane bases (uniform: SGPR pairs) and the half-wave's group stride (one VGPR per view): every access below is
+    // base + 32-bit lane offset (the host checked that a view's image fits 2^32 bytes)
+    const char *r1h = nullptr, *r1l = nullptr, *r2h = nullptr, *r2l = nullptr, *mkh = nullptr;
+    unsigned h1 = 0, h2 = 0, ho = 0, ho2 = 0;
+    if constexpr (HAS_R1) {
+        r1h = (const char*)(a.res1.hi + bl * a.res1.bs);
+        r1l = a.res1.lo ? (const char*)(a.res1.lo + bl * a.res1.bs) : nullptr;
+        h1 = half ? (unsigned)a.res1.cs * 16 : 0;
+    }
+    if constexpr (HAS_R2) {
+        r2h = (const char*)(a.res2.hi + bl * a.res2.bs);
+        r2l = a.res2.lo ? (const char*)(a.res2.lo + bl * a.res2.bs) : nullptr;
+        h2 = half ? (unsigned)a.res2.cs * 16 : 0;
+    }
+    if constexpr (HAS_MK) {
+        mkh = (const char*)(a.mask.hi + bl * a.mask.bs);
+    }
+    char *oh = nullptr, *ol = nullptr, *o2h = nullptr, *o2l = nullptr;
+    if constexpr (!NCHW) {
+        oh = (char*)(a.out.hi + bl * a.out.bs);
+        ol = (NPL == 2 && a.out.lo) ? (char*)(a.out.lo + bl * a.out.bs) : nullptr;
+        ho = half ? (unsigned)a.out.cs * 16 : 0;
+        if constexpr (OUT2) {
+            o2h = (char*)(a.out2.hi + bl * a.out2.bs);
+            o2l = (NPL == 2 && a.out2.lo) ? (char*)(a.out2.lo + bl * a.out2.bs) : nullptr;       // (a hi-only second destination: the mask stash)
+            ho2 = half ? (unsigned)a.out2.cs * 16 : 0;
+        }
+    }
+    // Residual / mask operands: 16-byte loads, all of a column tile's (or, where the registers allow, of the whole tile's) issued in one go
+    // before the math that uses them.  A lane without an output reads its view's first vector (always mapped) and drops it.
+    constexpr int OPREGS_R = MT * 2 * (((HAS_R1 ? 1 : 0) + (HAS_R2 ? 1 : 0)) * NPL + (HAS_MK ? 1 : 0)) * 4;
+    constexpr bool ALL_FIRST = OPREGS_R * R <= 96;
+    constexpr int RQ = ALL_FIRST ? R : 1;
+    ResRaw q1[HAS_R1 ? RQ : 1][MT * 2], q2[HAS_R2 ? RQ : 1][MT * 2];
+    uint4 qm[HAS_MK ? RQ : 1][MT * 2];
+    unsigned big = 0;              // fp16 range watch: bit 15 / 31 set once a stored half had magnitude >= 2^15 (exponent field >= 30, inf and NaN included)
+    auto issue = [&](const int r) {
+        const int rq = ALL_FIRST ? r : 0;
+#pragma unroll
+        for (int mp = 0; mp < MT * 2; ++mp) {
+            const int cg0 = mp * 2;
+            const bool ok = cg0 < ec.lim[r];
+            if constexpr (HAS_R1) {
+                const unsigned off = ok ? ec.poff[r] + h1 + cg0 * ((unsigned)a.res1.cs * 16) : 0;
+                q1[rq][mp].h = *(const uint4*)(r1h + off);
+                if (NPL == 2 && r1l) q1[rq][mp].l = *(const uint4*)(r1l + off);
+            }
+            if constexpr (HAS_R2) {
+                const unsigned off = ok ? ec.poff[r] + h2 + cg0 * ((unsigned)a.res2.cs * 16) : 0;
+                q2[rq][mp].h = *(const uint4*)(r2h + off);
+                if (NPL == 2 && r2l) q2[rq][mp].l = *(const uint4*)(r2l + off);
+            }
+            if constexpr (HAS_MK) {
+                const int cgm = cg0 + half - a.mask_cg0;                  // the lane's group inside the mask view
+                const bool okm = ok && cgm >= 0 && cg0 + half < a.mask_cg1;
+                const unsigned off = okm ? ec.poff[r] + (unsigned)cgm * ((unsigned)a.mask.cs * 16) : 0;
+                qm[rq][mp] = *(const uint4*)(mkh + off);
+            }
+        }
+    };
+    if constexpr (ALL_FIRST && (HAS_R1 || HAS_R2 || HAS_MK)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) issue(r);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if constexpr (!ALL_FIRST && (HAS_R1 || HAS_R2 || HAS_MK)) issue(r);
+        const int rq = ALL_FIRST ? r : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int cg0 = m * 4 + gp * 2;                  // this pair: output groups cg0, cg0+1
+                if (!(cg0 < ec.lim[r])) continue;                // per lane: pixel inside the image and group cg0 + half exists
+                f32x2 v[2][2];                                   // [group k][channel pair]: this lane's 4 channels of both groups
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // alpha * LeakyReLU(y) = max(alpha * y, alpha * slope * y) for alpha >= 0, 0 < slope <= 1 (checked by the host); the bias is
+                        // the accumulators' seed.  (Scaling first makes both operands of the max products: no canonicalising v_max x, x.)
+                        v[k][j] = f32x2{acc[m][r][(gp * 2 + k) * 4 + 2 * j], acc[m][r][(gp * 2 + k) * 4 + 2 * j + 1]} * alpha2;
+                        v[k][j] = __builtin_elementwise_max(v[k][j], v[k][j] * slope2);
+                    }
+                if constexpr (HAS_R1) {
+                    f32x2 rv[2][2];
+                    res_unpack<FMT>(q1[rq][m * 2 + gp], NPL == 2 && a.res1.lo != nullptr, rv);
+                    const f32x2 bb = {a.beta1, a.beta1};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) v[k][j] = __builtin_elementwise_fma(bb, rv[k][j], v[k][j]);
+                }
+                if constexpr (HAS_R2) {
+                    f32x2 rv[2][2];
+                    res_unpack<FMT>(q2[rq][m * 2 + gp], NPL == 2 && a.res2.lo != nullptr, rv);
+                    const f32x2 bb = {a.beta2, a.beta2};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) v[k][j] = __builtin_elementwise_fma(bb, rv[k][j], v[k][j]);
+                }
+                if constexpr (HAS_MK) {
+                    // LeakyReLU' from the stored post-activation value: its sign is the pre-activation's (slope > 0);
+                    // x <= 0 -> slope (torch: leaky_relu'(0) = slope).  16-bit elements, two per dword: the low one is positive iff
+                    // (int)(d << 16) > 0, the high one iff (int)d > 0xFFFF (sign clear, magnitude bits not all zero) — bf16 and f16 alike
+                    uint32_t d[2][2];
+                    swap_halves(qm[rq][m * 2 + gp], d);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int cg = cg0 + k;
+                        const float ms = (cg < a.mask_cg0 || cg >= a.mask_cg1) ? 1.f : a.mask_slope;      // uniform: groups outside the masked range keep their value
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x2 s = v[k][j] * f32x2{ms, ms};
+                            v[k][j].x = (int)(d[k][j] << 16) > 0 ? v[k][j].x : s.x;
+                            v[k][j].y = (int)d[k][j] > 0xFFFF ? v[k][j].y : s.y;
+                        }
+                    }
+                }
+                if constexpr (NCHW) {
+                    // fp32 [B][nchw_ctot][H][W]: this lane's 4 channels of both groups (no exchange)
+                    char* const ob = (char*)(a.out_nchw + bl * a.nchw_ctot * a.H * a.W);
+                    const unsigned hw4 = (unsigned)(a.H * a.W) * 4;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int ch0 = (cg0 + k) * 8 + half * 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ch0 + i < a.cout) *(float*)(ob + (ec.poff[r] + (unsigned)(ch0 + i) * hw4)) = v[k][i >> 1][i & 1];
+                    }
+                    continue;                                    // the fp32 NCHW destination replaces the act-layout one
+                }
+                // to 16-bit hi (+ lo = the rounding residue) elements (v_cvt_pk_bf16_f32 rounds to nearest even), 2 channels per dword.  Rows past
+                // cout need no masking: their weights and their bias seed are zero, so is whatever the residual buffers hold there.
+                uint32_t hi[2][2], lo[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t h = cvt_pk<FMT>(v[k][j].x, v[k][j].y);
+                        hi[k][j] = h;
+                        if constexpr (FMT == 1) big |= (h & 0x7FFF7FFFu) + 0x08000800u;      // 15-bit magnitude >= 0x7800 carries into the half's top bit
+                        lo[k][j] = 0;
+                        if (NPL == 2) lo[k][j] = cvt_pk<FMT>(v[k][j].x - e2f<FMT>(h & 0xFFFF), v[k][j].y - e2f<FMT>(h >> 16));
+                    }
+                // lanes 0-31 end up with group cg0's 8 channels, lanes 32-63 with group cg0+1's (same pixel)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(hi[0][0], hi[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(hi[0][1], hi[1][1], false, false);
+                const uint4 hv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                uint4 lv = hv;
+                if (NPL == 2) {
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
+                    lv = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                unsigned off;
+                if constexpr (PS) {
+                    // row group -> (output group, sub-position) of the r x r block at (Y, X)
+                    const int cgs = cg0 + half, rg = a.ps_rg0 + cgs, r2 = a.ps * a.ps, sp = rg % r2;
+                    const int Y = ec.poff[r] >> 16, X = ec.poff[r] & 0xFFFF;
+                    off = ((unsigned)(rg / r2) * (unsigned)a.out.cs + (unsigned)(a.ps * Y + sp / a.ps + 1) * (a.ps * a.W + 2) + (a.ps * X + sp % a.ps + 1)) * 16;
+                } else off = ec.poff[r] + ho + cg0 * ((unsigned)a.out.cs * 16);
+                *(uint4*)(oh + off) = hv;
+                if (NPL == 2 && (!PARTLO || ol)) *(uint4*)(ol + off) = lv;
+                if constexpr (OUT2) {
+                    const unsigned off2 = ec.poff[r] + ho2 + cg0 * ((unsigned)a.out2.cs * 16);
+                    *(uint4*)(o2h + off2) = hv;
+                    if (NPL == 2 && o2l) *(uint4*)(o2l + off2) = lv;
+                }
+            }
+        }
+    }
+    if constexpr (FMT == 1 && !NCHW) {
+        if (a.range_flag && (big & 0x80008000u)) atomicMin(a.range_flag, a.range_tag);      // (no lane gets here in a pass that stays in range)
+    }
+}
+
+// The accumulators' seed: the bias of this lane's 16 rows per M tile (esr_conv3x3_desc.bias: MT * 32 floats, zero beyond cout; the library's
+// zero block without a bias).  Scalar loads (the constant address space: s_load_dwordx8 per 8-channel block, on their own counter — the hand-counted vmcnt of the
+// copies is not involved), then one select per value on the half-wave.
+template <int MT>
+__device__ __forceinline__ void bias_seed(const float* bias, int half, float (&bz)[MT][16]) {
+    typedef const __attribute__((address_space(4))) float* cptr;
+    const cptr cb = (cptr)(uintptr_t)bias;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c0 = (m * 4 + j) * 8;
+                const float lo = cb[c0 + k], hi = cb[c0 + 4 + k];
+                bz[m][j * 4 + k] = half ? hi : lo;
+            }
+}
 
 // One output tile per workgroup.
 //   NST == 1: single LDS stage, 2 workgroups resident per CU: latency hiding comes from the co-resident workgroup instead of an
@@ -40,13 +648,8 @@ namespace {
 // Order of the prologue (round 5: a lone workgroup per CU pays every instruction in front of its first copy in full): tile decode and the
 // slots' source offsets (multiplications by host-made magic numbers, no division), the first chunk's copies — and only then, while those
 // are in flight, the bias seed of the accumulators and the epilogue's per-lane coordinates.
-// NTILE > 1 (single-stage kernels of LARGE launches with one MFMA per product, round 6): a workgroup runs up to NTILE consecutive tiles of its
-// XCD's sweep — kernel arguments, slice shifts and wave shares read once, the next tile's first chunk of copies issued in front of the current
-// tile's epilogue (the K loop's closing barrier has freed the stage), so its landing time hides behind the stores.  Same tiles, same
-// arithmetic per tile: bit-identical to NTILE = 1.
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0, int NTILE = 1>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_MT2)) void conv3x3_tile_kernel(const ConvArgs a_in) {
-    static_assert(NTILE == 1 || NST == 1, "several tiles per workgroup: the single-stage form only");
     // Output slices (cout > 64; esr_conv3x3_desc): blockIdx.y selects a 64-channel slice of the output — its own weight pack and bias, the
     // same staged input.  All workgroups of all slices are in flight together: a 512-channel layer on an 8x8 map is one launch of
     // 32 x 8 workgroups instead of eight launches of 32.  (Everything below is uniform: the shifts are scalar adds; slice 0 adds zero.)
@@ -88,24 +691,11 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // XCD-aware tile order: workgroup g runs on XCD g%8; each XCD sweeps a contiguous range of the tile space.  The grid is exactly ntiles
     // workgroups (XCD x owns xcd_q tiles, one more if x < xcd_r): no idle workgroup, no early exit — the prologue is branch-free
     const unsigned xcd = blockIdx.x & 7;
-    const unsigned xcd_first = xcd * a.xcd_q + (xcd < (unsigned)a.xcd_r ? xcd : (unsigned)a.xcd_r);      // first tile of this XCD's sweep
-    unsigned tile_f = xcd_first + (blockIdx.x >> 3), ntl = 1;
-    if constexpr (NTILE > 1) {
-        // (grid: 8 x ceil(longest sweep / NTILE) workgroups — the last workgroup of a sweep may get fewer tiles, or none)
-        const unsigned qx = a.xcd_q + (xcd < (unsigned)a.xcd_r ? 1u : 0u), j0 = (blockIdx.x >> 3) * NTILE;
-        if (j0 >= qx) return;
-        ntl = qx - j0 < (unsigned)NTILE ? qx - j0 : (unsigned)NTILE;
-        tile_f = xcd_first + j0;
-    }
-    // tile -> image b, tile origin (x0, y0): output interior coords == padded coords of the halo origin
-    struct TilePos { int b, x0, y0; };
-    auto decode = [&](const unsigned tf) {
-        const unsigned tile = a.reverse ? a.ntiles - 1 - tf : tf;
-        const unsigned trow = udiv_magic(tile, a.m_tx, a.i_tx);         // = image * tiles_y + tile row
-        const int bb = udiv_magic(trow, a.m_ty, a.i_ty);
-        return TilePos{bb, (int)(tile - trow * a.tiles_x) * a.TW, (int)(trow - bb * a.tiles_y) * a.TH};
-    };
-    TilePos tp = decode(tile_f);
+    const unsigned tile_f = xcd * a.xcd_q + (xcd < (unsigned)a.xcd_r ? xcd : (unsigned)a.xcd_r) + (blockIdx.x >> 3);
+    const unsigned tile = a.reverse ? a.ntiles - 1 - tile_f : tile_f;
+    const unsigned trow = udiv_magic(tile, a.m_tx, a.i_tx);         // = image * tiles_y + tile row
+    const int b = udiv_magic(trow, a.m_ty, a.i_ty);
+    const int x0 = (tile - trow * a.tiles_x) * a.TW, y0 = (trow - b * a.tiles_y) * a.TH;   // tile origin: output interior coords == padded coords of the halo origin
     const DmaShare share = unpack_share(a_in.share[wave]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 #ifdef ESR_TRACE
@@ -117,7 +707,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
 #else
 #define ESR_TR() do { } while (0)
 #endif
-    FetchState<MAXS> fs = setup_tile<MAXS>(a, tp.x0, tp.y0, wave, lane);
+    const FetchState<MAXS> fs = setup_tile<MAXS>(a, x0, y0, wave, lane);
     ESR_TR();                                    // (slot 3) tile decoded, slot offsets formed
     static_assert(TMODE != 2 || MT == 2, "M-tile tap masks come in pairs");
     const unsigned char* const sb0 = smem + (lane >> 5) * NPL * plane_bytes + (wave * 32 + (lane & 31)) * 16;
@@ -125,11 +715,10 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     constexpr int NTERM_CAP = 3;
     // which 2x2 block of taps chunk c's weights live in (dma_chunk)
     auto tsel_of = [&](const int c) { return TMODE == 1 ? ((c >> 1) & 3) : (TMODE == 2 ? (int)(blockIdx.y & 1) : 0); };
-    auto issue_for = [&](const FetchState<MAXS>& f, const int bb, const int c, const unsigned stage, const bool xlo) {
-        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, bb);
-        dma_chunk<NPL, MT, NPW, TMODE>(f, bs, share, stage, plane_bytes, xlo, tsel_of(c), wave);
+    auto issue = [&](const int c, const unsigned stage, const bool xlo) {
+        const Bases<NPL> bs = make_bases<NPL, MT, NPW>(a, c, b);
+        dma_chunk<NPL, MT, NPW, TMODE>(fs, bs, share, stage, plane_bytes, xlo, tsel_of(c), wave);
     };
-    auto issue = [&](const int c, const unsigned stage, const bool xlo) { issue_for(fs, tp.b, c, stage, xlo); };
     if (NST == 4) {                           // ring of four stages: chunks 0, 1, 2 in flight before the first multiply
         static_assert(NST != 4 || !PARTLO, "the four-stage ring counts its copies per chunk: one count for all chunks");
 #pragma unroll
@@ -140,7 +729,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
     // coordinates are formed here when the registers allow (the lone-workgroup forms and the one-plane 32-channel kernels), otherwise after
     // the K loop (the 64-channel kernels of the large launches sit at their 256-register limit and a co-resident workgroup covers it).
     constexpr int EKIND = (EPI & EPI_NCHW) ? 1 : ((EPI & EPI_PS) ? 2 : 0);
-    constexpr bool EARLY_COORDS = NST >= 2 || (MT == 1 && NPL == 1) || NTILE > 1;
+    constexpr bool EARLY_COORDS = NST >= 2 || (MT == 1 && NPL == 1);
     f32x16 acc[MT][R];
     EpiCoord<R> ec;
     auto seed = [&]() {
@@ -155,15 +744,13 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][r][i] = bz[m][i];
-        if constexpr (EARLY_COORDS) ec = epi_coords<R, EKIND>(a, tp.x0, tp.y0, wave, lane_o);
+        if constexpr (EARLY_COORDS) ec = epi_coords<R, EKIND>(a, x0, y0, wave, lane_o);
     };
     // The first chunk's copies go out in front of the K loop, the seed right behind them.  (Seeding inside the loop's first pass instead —
     // one copy of the issue code — made the accumulators' loop-carried registers VGPRs: 96 v_accvgpr moves per chunk, +0.35 us per chunk.)
     if (NST != 4) issue(0, lds0, !PARTLO || 0 < a.lo_chunks);
     __builtin_amdgcn_sched_barrier(0);
     ESR_TR();                                    // (slot 4) first chunk's copies issued
-    const int lo_end = PARTLO ? (a.lo_chunks < a.ncp ? a.lo_chunks : a.ncp) : a.ncp;
-  for (unsigned it = 0;;) {                      // (NTILE == 1: one pass, no loop)
     seed();
     ESR_TR();                                    // (slot 5) accumulators seeded, epilogue coordinates formed
     // One chunk: DMA (or prefetch of the next chunk), barrier, MFMAs, barrier.  XLO (compile time): this chunk's activations have a lo
@@ -178,7 +765,7 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         if (NST == 1) {
             if (cp > 0) issue(cp, lds0, xlo);
             ESR_TR();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (NTILE > 1, cp == 0: also the previous tile's stores — issued ahead of these copies' landing)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (NST == 4) {
             // NST == 4 (launches of few, small tiles with a long K axis — the critic's 512-channel layers on 8x8 / 4x4 maps): each chunk is a
             // handful of MFMAs behind a copy round trip, so the round trips of THREE chunks are kept in flight.  The stage refilled now
@@ -216,35 +803,14 @@ __global__ __launch_bounds__(NTHREADS, NST >= 2 ? 1 : (MT == 1 ? WGS_MT1 : WGS_M
         ESR_TR();
         __syncthreads();
     };
+    const int lo_end = PARTLO ? (a.lo_chunks < a.ncp ? a.lo_chunks : a.ncp) : a.ncp;
     for (int cp = 0; cp < lo_end; ++cp) step(std::true_type{}, cp);
     if constexpr (PARTLO)
         for (int cp = lo_end; cp < a.ncp; ++cp) step(std::false_type{}, cp);
     ESR_TR();
-    if constexpr (NTILE > 1) {
-        // the next tile of this workgroup: decoded and its first chunk's copies issued now — every wave is past the K loop's closing barrier, the
-        // stage is free — so that they land while the epilogue below stores this tile
-        const bool more = it + 1 < ntl;
-        TilePos tn = tp;
-        FetchState<MAXS> fn = fs;
-        if (more) {
-            tn = decode(tile_f + it + 1);
-            fn = setup_tile<MAXS>(a, tn.x0, tn.y0, wave, lane);
-            issue_for(fn, tn.b, 0, lds0, !PARTLO || 0 < a.lo_chunks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        conv_epilogue<NPL, MT, R, EPI, FMT, PARTLO>(a, acc, tp.b, ec, lane);
-        ESR_TR();
-        if (!more) break;
-        tp = tn;
-        fs = fn;
-        ++it;
-    } else {
-        if constexpr (!EARLY_COORDS) ec = epi_coords<R, EKIND>(a, tp.x0, tp.y0, wave, lane);
-        conv_epilogue<NPL, MT, R, EPI, FMT, PARTLO>(a, acc, tp.b, ec, lane);
-        ESR_TR();
-        break;
-    }
-  }
+    if constexpr (!EARLY_COORDS) ec = epi_coords<R, EKIND>(a, x0, y0, wave, lane);
+    conv_epilogue<NPL, MT, R, EPI, FMT, PARTLO>(a, acc, b, ec, lane);
+    ESR_TR();
 #ifdef ESR_TRACE
     if (tr && tid == 0) tr[127] = wall_clock64();
 #endif
@@ -329,30 +895,26 @@ struct TileCfg { int TH, TW, P, NPIX_T, NPIX_L, tiles_x, tiles_y; size_t lds; };
 
 // Choose (TH, TW): minimise the number of workgroup tiles (every wave always runs R column tiles per tile) plus a small
 // halo-traffic term, under the LDS budget that keeps `nwg` workgroups resident per CU.
-TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg, bool full_width);
+TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg);
 // the search walks up to W column splits: remember the last few geometries per thread (a forward pass repeats three or four of them 351 times)
-// full_width: whole-row tiles only (tiles_x == 1: what the chain kernel's vertical halo recompute needs); TH == 0 when a row does not fit a tile
-TileCfg pick_tile(int H, int W, int npl, int mt, int nwg, bool full_width = false) {
-    struct Entry { int H, W, npl, mt, nwg; bool fw; TileCfg cfg; };
+TileCfg pick_tile(int H, int W, int npl, int mt, int nwg) {
+    struct Entry { int H, W, npl, mt, nwg; TileCfg cfg; };
     static thread_local Entry cache[8];
     static thread_local int next = 0;
     for (const Entry& e : cache)
-        if (e.H == H && e.W == W && e.npl == npl && e.mt == mt && e.nwg == nwg && e.fw == full_width && e.cfg.P) return e.cfg;
-    const TileCfg cfg = pick_tile_search(H, W, npl, mt, nwg, full_width);
-    if (cfg.P) {
-        Entry& e = cache[next];
-        next = (next + 1) % 8;
-        e = Entry{H, W, npl, mt, nwg, full_width, cfg};
-    }
-    return cfg;
+        if (e.H == H && e.W == W && e.npl == npl && e.mt == mt && e.nwg == nwg && e.cfg.P) return e.cfg;
+    Entry& e = cache[next];
+    next = (next + 1) % 8;
+    e = Entry{H, W, npl, mt, nwg, pick_tile_search(H, W, npl, mt, nwg)};
+    return e.cfg;
 }
-TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg, bool full_width) {
+TileCfg pick_tile_search(int H, int W, int npl, int mt, int nwg) {
     const int R = r_of(mt), MAXS = maxs_of(mt);
     TileCfg best{};
     double best_cost = -1;
     const size_t budget = 160 * 1024;
     const int max_px = 32 * NW * R;
-    for (int ntx = 1; ntx <= (full_width ? 1 : W); ++ntx) {
+    for (int ntx = 1; ntx <= W; ++ntx) {
         const int TW = (W + ntx - 1) / ntx;
         const int P = TW + 2;
         if (P > max_px) continue;
@@ -413,36 +975,18 @@ void dma_share_host(int npl, int nwi, int nslots, unsigned (&out)[NW]) {
     }
 }
 
-// esr_conv3x3_chain: while set (per thread), esr_conv3x3 goes through all of its validation and launch planning and then hands the argument
-// block and the kernel variant it chose to the capture instead of launching
-struct ChainCapture { ConvArgs a; ConvVariant v; int captured; };
-thread_local ChainCapture* g_capture = nullptr;
-
-template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0, int NTILE = 1>
+template <int NPL, int MT, int EPI, int NST, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 int launch_nst(const ConvArgs& a, hipStream_t s) {
-    if (g_capture) {
-        g_capture->a = a;
-        g_capture->v = ConvVariant{NPL, MT, EPI, NST, FMT, NPW, PARTLO ? 1 : 0, TMODE, NTILE};
-        g_capture->captured += 1;
-        return ESR_OK;
-    }
-    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMODE, NTILE>;
+    void (*k)(const ConvArgs) = conv3x3_tile_kernel<NPL, MT, EPI, NST, FMT, NPW, PARTLO, TMODE>;
     ESR_ALLOW_160K_LDS(k);
     const int nslices = a.wslice ? a.nslices : 1;
     const size_t stage = (size_t)2 * NPL * a.NPIX_L * 16 + (size_t)9 * MT * NPW * 1024;
     const size_t lds = (NST == 1 ? 1 : (NST == 4 ? 4 : 2)) * stage;
-    // NTILE tiles per workgroup: 8 x ceil(longest XCD sweep / NTILE) workgroups (conv3x3_tile_kernel)
-    const int grid_x = NTILE == 1 ? a.ntiles : 8 * ((a.xcd_q + (a.xcd_r ? 1 : 0) + NTILE - 1) / NTILE);
     ESR_CLEAR_ERR();
-    hipLaunchKernelGGL(k, dim3(grid_x, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(a.ntiles, nslices, a.ksplit > 1 ? a.ksplit : 1), dim3(NTHREADS), lds, s, a);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
-
-// Tiles per workgroup of the one-MFMA-per-product single-stage kernels (one-plane weights, 32 output channels) in launches of at least
-// NTILE_MIN_TILES tiles: VERDICT r5 item 2 — the per-workgroup set-up is 27 % of a workgroup's life there (profiles/r05_one_mfma_phases.log).
-constexpr int NTILE_ONE_MFMA = 2;
-constexpr int NTILE_MIN_TILES = 1024;
 
 template <int NPL, int MT, int EPI, int FMT, int NPW, bool PARTLO, int TMODE = 0>
 int launch(const ConvArgs& a, hipStream_t s) {
@@ -461,9 +1005,6 @@ int launch(const ConvArgs& a, hipStream_t s) {
     if constexpr (TMODE != 0 && NPL == 2) return launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s);
     else {
         const bool two = force ? force == 2 : small;
-        if constexpr (NTILE_ONE_MFMA > 1 && MT == 1 && NPW == 1 && TMODE == 0 && (EPI & EPI_NCHW) == 0) {
-            if (!two && ntiles >= NTILE_MIN_TILES && !a.wslice && a.ksplit <= 1) return launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE, NTILE_ONE_MFMA>(a, s);
-        }
         return two ? launch_nst<NPL, MT, EPI, 2, FMT, NPW, PARTLO, TMODE>(a, s) : launch_nst<NPL, MT, EPI, 1, FMT, NPW, PARTLO, TMODE>(a, s);
     }
 }
@@ -659,9 +1200,7 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     }
     const int mt_k = mslice ? 1 : mt;                              // M tiles per workgroup of the kernel that runs
     const int wgs_per_cu = mt_k == 1 ? WGS_MT1 : WGS_MT2;
-    // (planning a chain — g_capture — asks for whole-row tiles; a row that does not fit one tile ends the plan: chain_prepare reads ESR_E_UNSUPPORTED
-    // from a capturing call as "these layers run separately")
-    const TileCfg t = pick_tile(d->H, d->W, npl, mt_k, wgs_per_cu, g_capture != nullptr);
+    const TileCfg t = pick_tile(d->H, d->W, npl, mt_k, wgs_per_cu);
     if (t.TH == 0) return ESR_E_UNSUPPORTED;
     if (mslice) { a.cout = 32; a.nslices = 2; }
     a.TH = t.TH; a.TW = t.TW; a.P = t.P; a.NPIX_T = t.NPIX_T; a.NPIX_L = t.NPIX_L;
@@ -811,110 +1350,3 @@ extern "C" int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream) {
     if (split) return mt_k == 1 ? launch_epi<2, 1, 0, 2>(a, epi, s) : launch_epi<2, 2, 0, 2>(a, epi, s);
     return mt_k == 1 ? launch_epi<1, 1, 0, 1>(a, epi, s) : launch_epi<1, 2, 0, 1>(a, epi, s);
 }
-
-// ---- a chain of 32-channel layers as one launch (csrc/esr_chain.hip)
-namespace {
-// byte interval of groups [g0, g0 + ng) of a view's hi plane in image 0
-struct Span { const char* lo; const char* hi; long long period; };
-Span span_of(const DView& v, int g0, int ng) {
-    const char* p = (const char*)v.hi + (long long)g0 * v.cs * 16;
-    return Span{p, p + (long long)ng * v.cs * 16, v.bs * 16};
-}
-// may the two group ranges share a byte in ANY image?  Views of one buffer (same batch stride, bases less than one image apart) repeat with the
-// same period, so image 0 decides; anything else is compared over its whole extent across the batch.
-bool spans_overlap(const Span& x, const Span& y, int B) {
-    if (x.lo == x.hi || y.lo == y.hi) return false;
-    const long long d = x.lo - y.lo;
-    if (x.period == y.period && d < x.period && -d < x.period) return x.lo < y.hi && y.lo < x.hi;
-    return x.lo < y.hi + (long long)(B - 1) * y.period && y.lo < x.hi + (long long)(B - 1) * x.period;
-}
-}  // namespace
-
-// 1: the layers fuse (c, v0 filled in); 0: they run as separate launches; < 0: a layer's descriptor is invalid (its ESR_E_* code)
-static int chain_prepare(const esr_conv3x3_desc* const* descs, int n, ChainArgs& c, ConvVariant& v0) {
-    if (!descs || n <= 0) return ESR_E_ARG;
-    for (int i = 0; i < n; ++i)
-        if (!descs[i]) return ESR_E_ARG;
-    auto separately = []() { return 0; };
-    const esr_stream_t stream = nullptr;                      // (capturing: nothing is launched)
-    if (n < 2 || n > CHAIN_MAX) return separately();
-    // only plain 32-channel layers can be chained: one kernel launch each, act-layout destination at the input resolution
-    for (int i = 0; i < n; ++i) {
-        const esr_conv3x3_desc* d = descs[i];
-        if (d->cout > 32 || d->out_nchw || d->pixel_shuffle > 1 || d->upsample > 1 || d->res1.hi || d->res2.hi || d->k_split_ws || d->lds_stages == 1 ||
-            !d->out.hi || d->B != descs[0]->B || d->H != descs[0]->H || d->W != descs[0]->W)
-            return separately();
-    }
-    // the launches as esr_conv3x3 would issue them: validation, tiling, kernel variant
-    c = ChainArgs{};
-    c.n = n;
-    v0 = ConvVariant{};
-    for (int i = 0; i < n; ++i) {
-        ChainCapture cap{};
-        g_capture = &cap;
-        const int rc = esr_conv3x3(descs[i], stream);
-        g_capture = nullptr;
-        if (rc == ESR_E_UNSUPPORTED) return separately();          // (no whole-row tile, or a layer the separate launch refuses too: it will say so itself)
-        if (rc != ESR_OK) return rc;
-        if (cap.captured != 1) return ESR_E_LAUNCH;              // (not reachable for the layers admitted above: they are single launches)
-        c.l[i] = cap.a;
-        if (i == 0) v0 = cap.v;
-        const ConvVariant& v = cap.v;
-        if (v.npl != v0.npl || v.mt != v0.mt || v.epi != v0.epi || v.nst != v0.nst || v.fmt != v0.fmt || v.npw != v0.npw || v.partlo != v0.partlo ||
-            v.tmode != v0.tmode || v.ntile != v0.ntile)
-            return separately();
-    }
-    const ConvArgs& a0 = c.l[0];
-    // the small-launch form only (a lone workgroup per CU, two LDS stages), whole-width tiles (the halo recompute is vertical only)
-    if (v0.mt != 1 || v0.nst != 2 || a0.tiles_x != 1 || a0.wslice || a0.ksplit > 1) return separately();
-    for (int i = 1; i < n; ++i) {
-        const ConvArgs& a = c.l[i];
-        if (a.TH != a0.TH || a.TW != a0.TW || a.P != a0.P || a.NPIX_L != a0.NPIX_L || a.nslots != a0.nslots || a.ntiles != a0.ntiles ||
-            a.share[0] != a0.share[0] || a.share[1] != a0.share[1] || a.share[2] != a0.share[2] || a.share[3] != a0.share[3] || a.wslice || a.ksplit > 1)
-            return separately();
-        c.l[i].reverse = a0.reverse;                           // one sweep direction for the launch (a cache hint: results do not depend on it)
-    }
-    // What the halo recompute relies on.  (1) A layer's output is written by several workgroups at different times: nothing any layer up to and
-    // including it reads (inputs, masks) and no other layer's output may alias it.  (2) The first two K chunks (four channel groups) of every
-    // layer are not outputs of the chain: they are fetched before the previous layer's stores are known to have landed.
-    const int B = a0.B;
-    for (int j = 0; j < n; ++j) {
-        const ConvArgs& w = c.l[j];
-        const Span outs[2] = {span_of(w.out, 0, (w.cout + 7) / 8), w.out2.hi ? span_of(w.out2, 0, (w.cout + 7) / 8) : Span{nullptr, nullptr, 0}};
-        for (const Span& o : outs) {
-            for (int i = 0; i < n; ++i) {
-                const ConvArgs& r = c.l[i];
-                if (i <= j && (spans_overlap(o, span_of(r.in0, 0, r.in0.ncg), B) || spans_overlap(o, span_of(r.in1, 0, r.in1.ncg), B))) return separately();
-                if (r.mask.hi && spans_overlap(o, span_of(r.mask, 0, r.mask.ncg), B)) return separately();
-                if (i != j && (spans_overlap(o, span_of(r.out, 0, (r.cout + 7) / 8), B) ||
-                               (r.out2.hi && spans_overlap(o, span_of(r.out2, 0, (r.cout + 7) / 8), B))))
-                    return separately();
-                if (i > j) {
-                    const int g1 = 4 - r.in0.ncg < r.in1.ncg ? 4 - r.in0.ncg : r.in1.ncg;
-                    if (spans_overlap(o, span_of(r.in0, 0, r.in0.ncg < 4 ? r.in0.ncg : 4), B) || (g1 > 0 && spans_overlap(o, span_of(r.in1, 0, g1), B))) return separately();
-                }
-            }
-        }
-    }
-    return esr_internal_chain_launch(&c, (const int*)&v0, nullptr, /*query_only=*/1) == ESR_OK ? 1 : 0;
-}
-
-extern "C" int esr_conv3x3_chain_fuses(const esr_conv3x3_desc* const* descs, int n) {
-    ChainArgs c;
-    ConvVariant v0;
-    return chain_prepare(descs, n, c, v0);
-}
-
-extern "C" int esr_conv3x3_chain(const esr_conv3x3_desc* const* descs, int n, esr_stream_t stream) {
-    ChainArgs c;
-    ConvVariant v0;
-    const int fuse = chain_prepare(descs, n, c, v0);
-    if (fuse < 0) return fuse;
-    if (fuse == 1) return esr_internal_chain_launch(&c, (const int*)&v0, (hipStream_t)stream, 0);
-    for (int i = 0; i < n; ++i) {
-        const int rc = esr_conv3x3(descs[i], stream);
-        if (rc != ESR_OK) return rc;
-    }
-    return ESR_OK;
-}
-

@@ -11,20 +11,6 @@ extern "C" int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t str
         int rc;
         switch (c.op) {
             case ESR_OP_CONV3X3: rc = esr_conv3x3(&c.u.conv, stream); break;
-            case ESR_OP_CONV3X3_CHAIN: {
-                // the marker is followed by its layers' own commands: run them as one call and step over them
-                const int m = c.u.chain.n;
-                const esr_conv3x3_desc* ds[4];
-                if (m >= 1 && m <= 4 && i + m <= n - 1) {
-                    rc = ESR_OK;
-                    for (int k = 0; k < m; ++k) {
-                        if (cmds[i + 1 + k].op != ESR_OP_CONV3X3) rc = ESR_E_ARG;
-                        ds[k] = &cmds[i + 1 + k].u.conv;
-                    }
-                    if (rc == ESR_OK) rc = esr_conv3x3_chain(ds, m, stream);
-                    if (rc == ESR_OK) i += m;
-                } else rc = ESR_E_ARG;
-            } break;
             case ESR_OP_PACK_NCHW: {
                 const esr_cmd_pack_nchw& a = c.u.pack_nchw;
                 rc = esr_pack_nchw(a.src, a.src_batch_stride, a.B, a.C, a.h, a.w, a.c0, a.nc, a.pad, a.down, &a.dst, stream);

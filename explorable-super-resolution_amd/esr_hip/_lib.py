@@ -63,7 +63,7 @@ class AdamTensor(C.Structure):
 # ---- launch lists (esr_cmd / esr_run, include/esr_hip.h)
 OP_CONV3X3, OP_PACK_NCHW, OP_UNPACK_GRAD_NCHW, OP_ACT_COMBINE, OP_PIXEL_UNSHUFFLE, OP_GRAD_ABSMAX, OP_GRAD_SCALE, OP_WGRAD_BATCH_RUN, \
     OP_PACK_BATCH_RUN, OP_ZERO, OP_UNPACK_NCHW, OP_WGRAD, OP_BN_REDUCE, OP_BN_APPLY, OP_BN_FINALIZE, OP_BN_PARAM_GRADS, \
-    OP_BN_FINALIZE_APPLY, OP_CONV3X3_CHAIN = range(1, 19)
+    OP_BN_FINALIZE_APPLY = range(1, 18)
 
 
 class CmdPackNchw(C.Structure):
@@ -129,15 +129,11 @@ class CmdBnParamGrads(C.Structure):
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('g_gamma', C.c_void_p)]
 
 
-class CmdChain(C.Structure):
-    _fields_ = [('n', C.c_int32)]
-
-
 class CmdUnion(C.Union):
     _fields_ = [('conv', Conv3x3Desc), ('pack_nchw', CmdPackNchw), ('unpack_grad_nchw', CmdUnpackGradNchw), ('act_combine', CmdActCombine),
                 ('pixel_unshuffle', CmdPixelUnshuffle), ('grad_absmax', CmdGradAbsmax), ('grad_scale', CmdGradScale),
                 ('wgrad_batch_run', CmdWgradBatchRun), ('pack_batch_run', CmdPackBatchRun), ('zero', CmdZero), ('unpack_nchw', CmdUnpackNchw),
-                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads), ('bn_finalize_apply', CmdBnFinalizeApply), ('chain', CmdChain)]
+                ('wgrad', WgradDesc), ('bn', CmdBn), ('bn_finalize', CmdBnFinalize), ('bn_param_grads', CmdBnParamGrads), ('bn_finalize_apply', CmdBnFinalizeApply)]
 
 
 class Cmd(C.Structure):
@@ -148,7 +144,7 @@ class Cmd(C.Structure):
 CMD_MEMBER = {OP_CONV3X3: 'conv', OP_PACK_NCHW: 'pack_nchw', OP_UNPACK_GRAD_NCHW: 'unpack_grad_nchw', OP_ACT_COMBINE: 'act_combine',
               OP_PIXEL_UNSHUFFLE: 'pixel_unshuffle', OP_GRAD_ABSMAX: 'grad_absmax', OP_GRAD_SCALE: 'grad_scale',
               OP_WGRAD_BATCH_RUN: 'wgrad_batch_run', OP_PACK_BATCH_RUN: 'pack_batch_run', OP_ZERO: 'zero', OP_UNPACK_NCHW: 'unpack_nchw',
-              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads', OP_BN_FINALIZE_APPLY: 'bn_finalize_apply', OP_CONV3X3_CHAIN: 'chain'}
+              OP_WGRAD: 'wgrad', OP_BN_REDUCE: 'bn', OP_BN_APPLY: 'bn', OP_BN_FINALIZE: 'bn_finalize', OP_BN_PARAM_GRADS: 'bn_param_grads', OP_BN_FINALIZE_APPLY: 'bn_finalize_apply'}
 
 
 _SIGS = {
@@ -166,8 +162,6 @@ _SIGS = {
     'esr_cmd_bytes': (C.c_int64, []),
     'esr_version': (C.c_int, []),
     'esr_conv3x3': (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
-    'esr_conv3x3_chain': (C.c_int, [C.POINTER(C.POINTER(Conv3x3Desc)), C.c_int, C.c_void_p]),
-    'esr_conv3x3_chain_fuses': (C.c_int, [C.POINTER(C.POINTER(Conv3x3Desc)), C.c_int]),
     'esr_pixel_unshuffle': (C.c_int, [C.POINTER(ActView), C.c_int, C.POINTER(ActView), C.c_int, C.c_void_p]),
     'esr_conv_wpack_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'esr_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -551,58 +551,11 @@ def conv3x3(pc, in1, B, H, W, cout, in0=None, upsample=1, act_slope=1.0, alpha=1
         d.tap_mask_m[:] = tap_mask_m
     if k_split_ws is not None:            # fp32 workspace the library may use to split the K axis of a small, deep launch (esr_hip.h)
         d.k_split_ws, d.k_split_ws_floats = k_split_ws.data_ptr(), k_split_ws.numel()
-    pending = getattr(_tls, 'chain', None)
-    if pending is not None:             # inside `with chain():` — collected, issued together when the block ends
-        pending.append(d)
-        return
     rec = _rec()
     if rec is not None:
         rec.emit(_lib.OP_CONV3X3, d, ('out_nchw',))
         return
     check(_lib.lib.esr_conv3x3(C.byref(d), stream_ptr()), 'esr_conv3x3')
-
-
-CHAIN_LOG = None   # a list: every chain block appends esr_conv3x3_chain_fuses' answer for its layers (tests)
-CHAINS = True      # module attribute (tests / experiments clear it): `with chain():` blocks issue their launches one by one
-
-
-class chain:
-    """with chain(): conv3x3(...) x 2..4 — consecutive layers handed to the library as ONE esr_conv3x3_chain call (a launch list gets the
-    ESR_OP_CONV3X3_CHAIN marker in front of the layers' own commands).  The library runs them as a single launch when they form a chain it can
-    fuse by halo recompute (the four 32-channel convs of a dense block and of its backward at small launch sizes, csrc/esr_chain.hip) and as
-    separate launches otherwise: bit-identical either way, so callers wrap whatever is consecutive and dependent.  enabled=False (or
-    act.CHAINS = False): the block is transparent."""
-
-    def __init__(self, enabled=True):
-        self.enabled = enabled and CHAINS
-
-    def __enter__(self):
-        if self.enabled:
-            assert getattr(_tls, 'chain', None) is None, 'chains do not nest'
-            _tls.chain = []
-        return self
-
-    def __exit__(self, et, ev, tb):
-        if not self.enabled:
-            return
-        ds, _tls.chain = _tls.chain, None
-        if et is not None or not ds:
-            return
-        if CHAIN_LOG is not None and len(ds) > 1:     # tests: which blocks the library fuses
-            arr = (C.POINTER(_lib.Conv3x3Desc) * len(ds))(*[C.pointer(d) for d in ds])
-            CHAIN_LOG.append(int(_lib.lib.esr_conv3x3_chain_fuses(arr, len(ds))))
-        rec = _rec()
-        if rec is not None:
-            if len(ds) > 1:
-                rec.emit(_lib.OP_CONV3X3_CHAIN, _lib.CmdChain(len(ds)))
-            for d in ds:
-                rec.emit(_lib.OP_CONV3X3, d, ('out_nchw',))
-            return
-        if len(ds) == 1:
-            check(_lib.lib.esr_conv3x3(C.byref(ds[0]), stream_ptr()), 'esr_conv3x3')
-            return
-        arr = (C.POINTER(_lib.Conv3x3Desc) * len(ds))(*[C.pointer(d) for d in ds])
-        check(_lib.lib.esr_conv3x3_chain(arr, len(ds), stream_ptr()), 'esr_conv3x3_chain')
 
 
 def pixel_unshuffle(src, r, dst, B):

@@ -685,13 +685,12 @@ def _zero_region(rec, bs, region):
 
 
 def _acquire(eng, x, groups=1):
-    """x: the input tensor, or (shape, device)"""
-    (B, Cin, H, W), device = (x.shape, x.device) if torch.is_tensor(x) else x
+    B, Cin, H, W = x.shape
     if B % groups:
         raise EsrError('critic: %d images do not split into %d equal groups' % (B, groups))
     key = (B, Cin, H, W, eng.planes, groups)
     free = eng._free_sets.setdefault(key, [])
-    bs = free.pop() if free else _BufSet(eng, B, Cin, H, W, device, groups)
+    bs = free.pop() if free else _BufSet(eng, B, Cin, H, W, x.device, groups)
     fp = eng.pointer_fingerprint()
     if bs.plans_fp != fp:
         bs.plans, bs.plans_fp, bs.wg = {}, fp, {}
@@ -714,124 +713,17 @@ def _replay(bs, key, ext, build):
     plan.run(ext)
 
 
-class _Prefetch:
-    """The first batch of an upcoming grouped call, already on its way on the engine's second stream (critic_prefetch_first)."""
-
-
-def _fwd_part(eng, bs, x_part, feat, training, b0, nb, g0, ng, key, zero):
-    """The forward launches of images [b0, b0 + nb) = groups [g0, g0 + ng) of the buffer set, as one launch list on the current stream: pack, then
-    per block conv -> statistics -> normalise + activate, features of those images into their rows of `feat`.  zero: this part clears the
-    statistics' accumulators (of ALL groups: the first part of a pass does)."""
-    B, G = bs.B, bs.groups
-
-    def build(rec):
-        Cin = bs.in_shape[1]
-        if zero:
-            _zero_region(rec, bs, bs.fwd_zero)
-        A.pack_nchw(x_part, view_of(bs.t0, b0=b0), 0, Cin)
-        t = bs.t0
-        for i, L in enumerate(eng.layers):
-            h, w = bs.hw[i]
-            y, z = bs.y[i], bs.z[i]
-            kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
-            vi, vo, Bc, hc, wc = conv_io(t, y, nb, h, w, b0)
-            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, k_split_ws=bs.ksw, **kw)
-            st = bs.stats(eng, i, training, g0)
-            if L.bn is not None and training:
-                # statistics, then ONE launch that turns the sums into the affine (and the stored / running statistics) and applies it
-                bn = L.bn
-                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, nb, y, st, False, groups=ng, b0=b0), 0, bs.ptr(i, 'sums', g0, eng))
-                track = bn.track_running_stats and bn.running_mean is not None
-                fin = _lib.CmdBnFinalize(bs.ptr(i, 'sums', g0, eng), ng, L.cout, bs.Bg * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                                         st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
-                                         bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None)
-                if FUSE_FINALIZE:
-                    rec.emit(_lib.OP_BN_FINALIZE_APPLY, _lib.CmdBnFinalizeApply(_desc(L, nb, y, st, bs.s2d[i], out0=z, groups=ng, b0=b0), fin))
-                    t = z
-                    continue
-                rec.emit(_lib.OP_BN_FINALIZE, fin)
-            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, nb, y, st, bs.s2d[i], out0=z, groups=ng, b0=b0), 0)
-            t = z
-        per_image = bs.feat_shape[1] * bs.feat_shape[2] * bs.feat_shape[3]
-        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t, b0=b0), nb, bs.feat_shape[1], feat.data_ptr() + 4 * b0 * per_image), ('dst',))
-    _replay(bs, key, {'x': x_part, 'feat': feat}, build)
-
-
-# The FIRST batch of a grouped call on a second stream, ahead of time (round 6, VERDICT r5 item 3).  In the WGAN-GP step the critic's three
-# inputs are [real, fake, interpolated] (reference codes/models/SRRaGAN_model.py:328 / :347-349): netD(var_ref) depends on nothing the generator
-# computes, yet the grouped pass runs it behind the generator's forward as a third of a latency-bound chain.  critic_prefetch_first() runs
-# that third's forward at once — same buffer set, same kernels on images [0, Bg), its own BatchNorm statistics (group 0), the running
-# statistics moved by it FIRST, as in the reference's order of calls — on the engine's second stream, under whatever the caller enqueues next
-# on the main stream (the generator's forward); the grouped call that follows recognises its first input, makes the main stream wait for the
-# part that is done and runs the other batches only.  The backward passes are those of the grouped call, unchanged.
-OVERLAP_FIRST = True
-PREFETCH_ON_MAIN = False     # experiments: the prefetched part on the caller's stream (the split schedule without the concurrency)
-
-
-def critic_prefetch_first(eng, x_first, n_inputs, training=None):
-    """Start critic(x_first) as the first of the `n_inputs` equally shaped batches of the critic_forward_group() call that follows (its
-    xs[0] must be this very tensor, unmodified).  A prefetch that is not picked up by the next grouped call is dropped (its work was
-    redundant, never wrong: the call then runs all batches itself — but the running statistics have then seen x_first twice; callers
-    prefetch only what they are about to pass)."""
-    if not (FUSED and GROUPED and OVERLAP_FIRST) or n_inputs < 2:
-        return False
-    A.require_gpu(x_first, 'critic input')
-    training = eng.net.training if training is None else training
-    eng.refresh()                                             # weight packs, on the caller's stream: the second stream starts behind it
-    x0 = x_first.detach().float().contiguous()
-    Bg, Cin, H, W = x0.shape
-    bs = _acquire(eng, ((n_inputs * Bg, Cin, H, W), x0.device), n_inputs)
-    feat = torch.empty(bs.feat_shape, dtype=torch.float32, device=x0.device)
-    if getattr(eng, '_side', None) is None:
-        eng._side = torch.cuda.Stream(device=x0.device)
-    main = torch.cuda.current_stream()
-    if PREFETCH_ON_MAIN:
-        _fwd_part(eng, bs, x0, feat, training, 0, Bg, 0, 1, ('fwd0', training), zero=True)
-        ev = torch.cuda.Event()
-        ev.record(main)
-    else:
-        eng._side.wait_stream(main)
-        with torch.cuda.stream(eng._side):
-            _fwd_part(eng, bs, x0, feat, training, 0, Bg, 0, 1, ('fwd0', training), zero=True)
-            ev = torch.cuda.Event()
-            ev.record(eng._side)
-    pre = _Prefetch()
-    pre.bs, pre.feat, pre.event, pre.src, pre.x0, pre.training, pre.version = bs, feat, ev, x_first, x0, training, x_first._version
-    old = getattr(eng, '_prefetched', None)
-    if old is not None:
-        _release(eng, old.bs)
-    eng._prefetched = pre
-    return True
-
-
-def _take_prefetch(eng, first, x, training, groups):
-    """The pending prefetch if it is the first batch of this very call, else None (a stale one is dropped)."""
-    pre = getattr(eng, '_prefetched', None)
-    if pre is None:
-        return None
-    eng._prefetched = None
-    ok = (first is pre.src and first._version == pre.version and pre.training == training and pre.bs.groups == groups and
-          tuple(x.shape) == pre.bs.in_shape and pre.bs.plans_fp == eng.pointer_fingerprint())
-    if not ok:
-        torch.cuda.current_stream().wait_event(pre.event)     # (its launches still use the set: give it back behind them)
-        _release(eng, pre.bs)
-        return None
-    return pre
-
-
-def _fwd_pass(eng, x, training, groups=1, first=None):
+def _fwd_pass(eng, x, training, groups=1):
     """-> (features fp32 [B, C, h, w], state).  One launch list: pack, then per block conv -> statistics -> normalise + activate.  groups > 1:
     x is `groups` batches back to back, each normalised with its own batch statistics (the critic's separate calls as one pass; the running
-    statistics are updated group after group, as the separate calls would).  first: the tensor the caller passed as the first batch — if
-    critic_prefetch_first() has already run it, only the other batches run here, behind it."""
+    statistics are updated group after group, as the separate calls would)."""
     x = x.float().contiguous()
-    pre = _take_prefetch(eng, first, x, training, groups) if first is not None else None
-    bs = pre.bs if pre is not None else _acquire(eng, x, groups)
+    bs = _acquire(eng, x, groups)
     B, G = bs.B, bs.groups
     S = _State()
     S.bs, S.training = bs, training
     weakref.finalize(S, _release, eng, bs)
-    feat = pre.feat if pre is not None else torch.empty(bs.feat_shape, dtype=torch.float32, device=x.device)
+    feat = torch.empty(bs.feat_shape, dtype=torch.float32, device=x.device)
     tracked = []
     if not training:
         for i, L in enumerate(eng.layers):
@@ -846,11 +738,36 @@ def _fwd_pass(eng, x, training, groups=1, first=None):
             bs.eval_affine[i][0].copy_(sc); bs.eval_affine[i][1].copy_(sh)
     else:
         tracked = [L.bn.num_batches_tracked for L in eng.layers if L.bn is not None and L.bn.track_running_stats and L.bn.num_batches_tracked is not None]
-    if pre is not None:
-        torch.cuda.current_stream().wait_event(pre.event)     # batch 0 is done (statistics, running statistics, features): the others follow
-        _fwd_part(eng, bs, x[bs.Bg:], feat, training, bs.Bg, B - bs.Bg, 1, G - 1, ('fwdR', training), zero=False)
-    else:
-        _fwd_part(eng, bs, x, feat, training, 0, B, 0, G, ('fwd', training), zero=True)
+
+    def build(rec):
+        Cin = bs.in_shape[1]
+        _zero_region(rec, bs, bs.fwd_zero)
+        A.pack_nchw(x, view_of(bs.t0), 0, Cin)
+        t = bs.t0
+        for i, L in enumerate(eng.layers):
+            h, w = bs.hw[i]
+            y, z = bs.y[i], bs.z[i]
+            kw = dict(tap_mask_k=MASK_FWD, tap_mask_k_shift=1) if (L.strided and MASK_FWD) else {}
+            vi, vo, Bc, hc, wc = conv_io(t, y, B, h, w)
+            A.conv3x3(L.fwd, vi, Bc, hc, wc, L.cout, out=vo, reverse=False, k_split_ws=bs.ksw, **kw)
+            st = bs.stats(eng, i, training)
+            if L.bn is not None and training:
+                # statistics, then ONE launch that turns the sums into the affine (and the stored / running statistics) and applies it
+                bn = L.bn
+                _emit_bn(rec, _lib.OP_BN_REDUCE, _desc(L, B, y, st, False, groups=G), 0, bs.ptr(i, 'sums'))
+                track = bn.track_running_stats and bn.running_mean is not None
+                fin = _lib.CmdBnFinalize(bs.ptr(i, 'sums'), G, L.cout, bs.Bg * h * w, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                         st.gamma, bn.bias.data_ptr() if bn.bias is not None else None, st.mean, st.rstd, st.scale, st.shift,
+                                         bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None)
+                if FUSE_FINALIZE:
+                    rec.emit(_lib.OP_BN_FINALIZE_APPLY, _lib.CmdBnFinalizeApply(_desc(L, B, y, st, bs.s2d[i], out0=z, groups=G), fin))
+                    t = z
+                    continue
+                rec.emit(_lib.OP_BN_FINALIZE, fin)
+            _emit_bn(rec, _lib.OP_BN_APPLY, _desc(L, B, y, st, bs.s2d[i], out0=z, groups=G), 0)
+            t = z
+        rec.emit(_lib.OP_UNPACK_NCHW, _lib.CmdUnpackNchw(view_of(t), B, bs.feat_shape[1], feat.data_ptr()), ('dst',))
+    _replay(bs, ('fwd', training), {'x': x, 'feat': feat}, build)
     if tracked:
         torch._foreach_add_(tracked, G)
     return feat, S
@@ -1069,7 +986,7 @@ class _CriticFwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, training, groups, x, *params):
         ctx.set_materialize_grads(False)
-        feat, S = _fwd_pass(eng, x.detach(), training, groups, first=getattr(eng, '_group_first', None))
+        feat, S = _fwd_pass(eng, x.detach(), training, groups)
         ctx.eng, ctx.S, ctx.np = eng, S, len(params)
         ys = tuple(y.detach() for y in S.bs.y)        # fresh tensor objects over the set's storage: autograd attaches its history to these
         ctx.save_for_backward(*[p for p in params if p is not None], *ys)
@@ -1159,11 +1076,7 @@ def critic_forward_group(eng, xs):
     if xs[0].shape[1] != eng.layers[0].cin:
         raise EsrError('critic input: %d channels expected' % eng.layers[0].cin)
     x = xs[0] if len(xs) == 1 else torch.cat(xs)
-    eng._group_first = xs[0] if len(xs) > 1 else None       # (lets the pass recognise a batch critic_prefetch_first() has already run)
-    try:
-        outs = _CriticFwd.apply(eng, net.training, len(xs), x, *_param_list(eng))
-    finally:
-        eng._group_first = None
+    outs = _CriticFwd.apply(eng, net.training, len(xs), x, *_param_list(eng))
     feat = outs[0]
     logits = net.classifier(feat.reshape(feat.size(0), -1))
     res = [logits] if len(xs) == 1 else list(logits.chunk(len(xs)))

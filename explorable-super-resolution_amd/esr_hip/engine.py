@@ -79,9 +79,6 @@ class RRDBEngine:
         # CU), the last one behind the chain on the main stream, which then waits for the second.  Same slicing as the one launch: bit-identical
         # gradients.  0: one launch behind the chain.
         self.wgrad_overlap = WGRAD_OVERLAP
-        # the four 32-channel convs of a dense block (forward, and the mirrored data-gradient ones) handed to the library as ONE esr_conv3x3_chain
-        # call: fused into one launch by halo recompute where the launch is small, separate launches otherwise — bit-identical (act.chain)
-        self.fuse_chains = FUSE_CHAINS
         self._side, self._xs = None, None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
 
@@ -393,7 +390,7 @@ class RRDBEngine:
     def _plan_key(self, kind, *what):
         # a forward list points into the forward packs only: creating the data-gradient packs later (first backward) leaves it valid
         packs = self._pack_gen[0] if kind == 'fwd' else tuple(self._pack_gen)
-        return (kind,) + what + (self.split, self._ptr_epoch, packs, bool(self.fuse_chains and A.CHAINS))
+        return (kind,) + what + (self.split, self._ptr_epoch, packs)
 
     @A.one_stream
     def run_forward(self, x, pad=0, keep=False):
@@ -477,11 +474,10 @@ class RRDBEngine:
             rrdb_in = buf_of(3 * r)
             for k in range(3):
                 buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
-                with A.chain(self.fuse_chains):      # the four growing convs: one launch at the small launch sizes (esr_conv3x3_chain)
-                    for i in range(4):
-                        o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
-                        conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                             out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
+                for i in range(4):
+                    o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
+                    conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
+                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
                     conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
@@ -709,15 +705,11 @@ class RRDBEngine:
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
                 if need_dw:
                     wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
-                with A.chain(self.fuse_chains):          # the mirrored dense block: one launch at the small launch sizes (esr_conv3x3_chain)
-                    for c in (3, 2, 1, 0):
-                        g0 = 8 + 4 * (3 - c)             # dy of conv c goes right behind the gradients it is computed from
-                        conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
-                             mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
-                # (recorded behind the chain: a weight gradient's place in a launch list — where its dy is final — is behind the launch that wrote it)
-                if need_dw:
-                    for c in (3, 2, 1, 0):
-                        g0 = 8 + 4 * (3 - c)
+                for c in (3, 2, 1, 0):
+                    g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
+                    conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
+                         mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
+                    if need_dw:
                         wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
@@ -780,9 +772,6 @@ def _pow2_scale(t, exp):
 
 # RRDBEngine.wgrad_overlap of new engines (see there); 0 = one weight-gradient launch behind the data-gradient chain
 WGRAD_OVERLAP = 3
-
-# RRDBEngine.fuse_chains of new engines
-FUSE_CHAINS = True
 
 _SIDE_CAPPED = {}
 

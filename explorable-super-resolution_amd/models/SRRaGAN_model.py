@@ -24,7 +24,7 @@ import CEM.CEMnet as CEMnet
 import models.networks as networks
 from esr_hip import dist as esr_dist
 from esr_hip import optim as esr_optim
-from esr_hip.critic import CriticEngine, critic_forward, critic_forward_group, critic_prefetch_first
+from esr_hip.critic import CriticEngine, critic_forward, critic_forward_group
 from esr_hip._lib import EsrError
 from models.modules.loss import CreateRangeLoss, FilterLoss, GANLoss, GradientPenaltyLoss, Latent_channels_desc_2_num_channels
 from .base_model import BaseModel
@@ -70,7 +70,6 @@ class SRRaGANModel(BaseModel):
         self.generator_started_learning = False
         self.optimalZ_loss_type = None
         self.D_engine, self.D_engine_mode, self.D_engine_fallback = None, None, None
-        self.overlap_D_real = True       # the critic's real-image forward under the generator's forward (optimize_parameters; A/B: clear it)
         self.timing = None               # set to {} to accumulate per-phase GPU milliseconds of optimize_parameters (bench.py --workload c3)
         if self.is_train:
             if train_opt['feature_weight'] is not None:
@@ -419,13 +418,6 @@ class SRRaGANModel(BaseModel):
                 self.var_H, self.var_ref = self.CEM_net.HR_unpadder(self.var_H), self.CEM_net.HR_unpadder(self.var_ref)
             if first_dual:
                 static_Z = self.GetLatent() if self.latent_input is not None else None
-                # netD(var_ref) depends on nothing the generator computes (reference :328 vs :347-349): its forward starts NOW, on the critic engine's
-                # second stream, under the generator's forward; the grouped critic call of the D step below runs the other two batches behind it
-                # (esr_hip.critic.critic_prefetch_first — same kernels, same BatchNorm statistics and running-statistics order: real first)
-                if self.D_exists and self.discriminator_step and train_opt['gan_type'] == 'wgan-gp' and self.overlap_D_real:
-                    eng = self._D_engine_for(self.var_ref)
-                    if eng is not None:
-                        critic_prefetch_first(eng, self.var_ref, 3)
             if optimized_Z_step:
                 self.Z_optimizer.feed_data({'LR': self.var_L, 'desired': self.var_H})
                 self.Z_optimizer.optimize()               # leaves self.fake_H = G(optimal Z) with G's graph

@@ -153,17 +153,6 @@ typedef struct {
 
 int esr_conv3x3(const esr_conv3x3_desc* d, esr_stream_t stream);
 
-/* n consecutive conv layers, each as esr_conv3x3 would run it (descs[i] in order; the same validation, the same results BIT FOR BIT).  When the
- * layers form a chain of plain 32-channel convs at a small launch size — the four growing convs of ResidualDenseBlock_5C
- * (codes/models/modules/block.py:230-235) and the four mirrored data-gradient convs of its backward, on the 52 x 52 training crops or single
- * images: no more tiles than CUs, whole-width tiles, act-layout destinations, no residual / upsample / pixel-shuffle / fp32 destination, and no
- * layer's output aliasing anything an earlier-or-same layer reads — they run as ONE launch: a workgroup that owns output rows [y0, y1) of the
- * last layer computes rows [y0 - e, y1 + e) of layer i (e = n - 1 - i) itself, so nothing is exchanged between workgroups (csrc/esr_chain.hip).
- * Anything else: n separate launches.  2 <= n <= 4 can fuse; the return value is the first failing layer's ESR_E_* code. */
-int esr_conv3x3_chain(const esr_conv3x3_desc* const* descs, int n, esr_stream_t stream);
-/* Would esr_conv3x3_chain run these layers as one launch?  1 yes, 0 no (separate launches), < 0 the ESR_E_* code of an invalid layer.  Launches nothing. */
-int esr_conv3x3_chain_fuses(const esr_conv3x3_desc* const* descs, int n);
-
 /* Adjoint of the pixel-shuffle store: dst[b][g*r^2 + s][y][x] = src[b][g][r*y + s / r][r*x + s % r] for every group g of `src`
  * (dst.ncg == src.ncg * r^2, src.H == r*dst.H): the gradient of the shuffled tensor laid out in the conv's row-group order
  * (autograd of nn.PixelShuffle, block.py:287). */
@@ -437,8 +426,7 @@ enum {
     ESR_OP_CONV3X3 = 1, ESR_OP_PACK_NCHW = 2, ESR_OP_UNPACK_GRAD_NCHW = 3, ESR_OP_ACT_COMBINE = 4, ESR_OP_PIXEL_UNSHUFFLE = 5,
     ESR_OP_GRAD_ABSMAX = 6, ESR_OP_GRAD_SCALE = 7, ESR_OP_WGRAD_BATCH_RUN = 8, ESR_OP_PACK_BATCH_RUN = 9, ESR_OP_ZERO = 10,
     ESR_OP_UNPACK_NCHW = 11, ESR_OP_WGRAD = 12, ESR_OP_BN_REDUCE = 13, ESR_OP_BN_APPLY = 14, ESR_OP_BN_FINALIZE = 15, ESR_OP_BN_PARAM_GRADS = 16,
-    ESR_OP_BN_FINALIZE_APPLY = 17,
-    ESR_OP_CONV3X3_CHAIN = 18      /* the next u.chain.n commands (all ESR_OP_CONV3X3) as one esr_conv3x3_chain call */
+    ESR_OP_BN_FINALIZE_APPLY = 17
 };
 typedef struct { const float* src; int64_t src_batch_stride; int32_t B, C, h, w, c0, nc, pad, down; esr_act_view dst; } esr_cmd_pack_nchw;
 typedef struct { esr_act_view G; float* dst; int64_t dst_batch_stride; int32_t B, C, h, w, c0, nc, pad, down, accumulate; } esr_cmd_unpack_grad_nchw;
@@ -460,7 +448,6 @@ typedef struct { const double* sums2; const double* sums3; const float* rstd; in
  * (same fp64 arithmetic) and its first block per channel group stores mean / rstd / scale / shift and moves the running statistics.  d->scale,
  * d->shift, d->mean, d->rstd are not read (f's are written); f->groups, f->C, f->n_per_group must agree with d.  Nine launches fewer per
  * forward of Discriminator_VGG_128 (codes/models/modules/architecture.py:446-508). */
-typedef struct { int32_t n; } esr_cmd_chain;
 typedef struct { esr_bn_desc d; esr_cmd_bn_finalize f; } esr_cmd_bn_finalize_apply;
 int esr_bn_finalize_apply(const esr_bn_desc* d, const esr_cmd_bn_finalize* f, esr_stream_t stream);
 typedef struct {
@@ -483,7 +470,6 @@ typedef struct {
         esr_cmd_bn_finalize bn_finalize;
         esr_cmd_bn_param_grads bn_param_grads;
         esr_cmd_bn_finalize_apply bn_finalize_apply;
-        esr_cmd_chain chain;
     } u;
 } esr_cmd;
 int esr_run(const esr_cmd* cmds, int n, int* failed, esr_stream_t stream);

@@ -462,58 +462,6 @@ def test_grouped_call_equals_separate_calls(monkeypatch, splitk):
         assert rel(v, u) < tol, (name, rel(v, u))
 
 
-@pytest.mark.parametrize('precision', ['split', 'bf16'])
-def test_prefetched_real_batch_equals_the_grouped_call(precision):
-    """Round 6: critic_prefetch_first(real) runs the first batch of the WGAN-GP step's grouped call ahead of time on the engine's
-    second stream (in the trainer: under the generator's forward), the grouped call then runs [fake, interp] behind it — the split schedule of
-    the SAME pass: same kernels on the same images, the same per-batch statistics, the running statistics moved in the reference's order (real,
-    fake, interpolated), one backward over all three batches.  Everything the step produces (logits, the penalty and its input gradient, every
-    parameter gradient, the running statistics) equals the one-list grouped call to the last bits the fp64 statistics atomics leave open; a
-    prefetch whose tensor is NOT the call's first input is dropped and the call still gives the grouped result."""
-    from esr_hip import critic as K
-    netD = make_D(64)
-    real, fake = seeded_uniform((8, 3, 64, 64), 31).cuda(), seeded_uniform((8, 3, 64, 64), 32).cuda()
-    pt = seeded_uniform((8, 1, 1, 1), 33).cuda()
-    params = list(netD.parameters())
-    bns = [m for m in netD.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-
-    def step(prefetch):
-        eng = K.CriticEngine(netD, precision)
-        for p in params:
-            p.grad = None
-        for m in bns:
-            m.reset_running_stats()
-        outs = []
-        for it in range(2):                          # the second round replays the recorded lists
-            interp = (pt * fake + (1 - pt) * real).requires_grad_(True)
-            if prefetch == 'real':
-                assert K.critic_prefetch_first(eng, real, 3)
-                torch.cuda._sleep(2000000)           # (stands for the generator's forward: the main stream is busy meanwhile)
-            elif prefetch == 'stale':
-                assert K.critic_prefetch_first(eng, real.clone(), 3)     # not the tensor the call passes: must be ignored
-            pr, pf, crit = K.critic_forward_group(eng, [real, fake, interp])
-            with K.input_grad_only(group=2):
-                g = torch.autograd.grad(crit, interp, torch.ones_like(crit), create_graph=True, retain_graph=True)[0]
-            gp = 10.0 * ((g.reshape(g.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
-            (pf.mean() - pr.mean() + gp).backward()
-            outs = [pr.detach().clone(), pf.detach().clone(), crit.detach().clone(), g.detach().clone(), gp.detach().clone()] + [p.grad.clone() for p in params] + \
-                [bns[0].running_mean.clone(), bns[-1].running_var.clone(), bns[3].num_batches_tracked.clone()]
-        return outs
-    a, b = step(None), step('real')
-    names = ['pred_real', 'pred_fake', 'pred_interp', 'dD/dx', 'gp'] + [n for n, _ in netD.named_parameters()] + ['running_mean', 'running_var', 'num_batches_tracked']
-    scale = max(float(g.norm()) for g in a[5:-3])
-    assert int(b[-1]) == 6
-    for name, u, v in zip(names, a, b):
-        if name == 'num_batches_tracked':
-            assert torch.equal(u, v)
-            continue
-        if max(float(u.norm()), float(v.norm())) < 1e-3 * scale and not name.startswith(('pred', 'running', 'dD', 'gp')):
-            continue                                  # analytically zero (conv bias in front of BatchNorm)
-        assert rel(v, u) < 1e-5, (name, rel(v, u))
-    c = step('stale')
-    assert rel(c[0], a[0]) < 1e-5 and rel(c[2], a[2]) < 1e-5
-
-
 def test_finalize_folded_into_the_normalise_launch_equals_the_separate_launch(monkeypatch):
     """esr_bn_finalize_apply (the forward's default: statistics -> ONE launch that derives the affine, stores mean / rstd / scale / shift,
     moves the running statistics and normalises) against esr_bn_finalize followed by esr_bn_apply: same fp64 arithmetic on the same sums

@@ -237,89 +237,6 @@ def test_small_launch_output_slices_are_bit_identical_to_the_64_channel_form(pre
     assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'mixed', 'f16'])
-def test_two_tiles_per_workgroup_are_bit_identical_to_one_tile_per_workgroup(precision):
-    """Round 6: in launches of >= 1024 tiles the one-MFMA 32-channel kernels give every workgroup TWO consecutive tiles of its
-    XCD's sweep (conv3x3_tile_kernel<..., NTILE = 2>: arguments read once, the second tile's first copies issued under the first tile's stores).
-    Same tiles, same products in the same order: the forward (and, where the precision trains, the input gradient and every weight gradient)
-    must not change by a bit against esr_conv3x3_desc.lds_stages = 2, which keeps every launch in the one-tile two-stage form.  19 images of
-    148 x 148 = 1140 tiles: XCD sweeps of 143 and 142 tiles, i.e. also a last workgroup with a single tile."""
-    from esr_hip import act as A
-
-    def run(stages):
-        keep = A.LDS_STAGES
-        A.LDS_STAGES = stages
-        try:
-            net = make_net(nb=1, lat=0, sf=2, precision=precision)
-            x = inputs(19, 0, 2, 148, 148, 79)
-            if precision == 'f16':                   # an inference precision
-                with torch.no_grad():
-                    return net(x).clone(), None, []
-            x.requires_grad_(True)
-            y = net(x)
-            (y * seeded_uniform(tuple(y.shape), 80).cuda()).sum().backward()
-            return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]
-        finally:
-            A.LDS_STAGES = keep
-    y0, dx0, dw0 = run(2)
-    y1, dx1, dw1 = run(0)
-    assert torch.equal(y0, y1)
-    assert dx0 is None or torch.equal(dx0, dx1)
-    assert all(torch.equal(a, b) for a, b in zip(dw0, dw1))
-
-
-@pytest.mark.parametrize('precision,lat,shape', [('split', 3, (2, 52, 52)), ('bf16', 3, (2, 52, 52)), ('bf16', 0, (3, 24, 20)), ('split', 0, (1, 32, 32)),
-                                                 ('f16', 0, (2, 40, 36))])
-def test_fused_dense_block_chains_are_bit_identical_to_separate_launches(precision, lat, shape):
-    """Round 6: at the small launch sizes the four 32-channel convs of every dense block — and the four mirrored data-gradient
-    convs of its backward — run as ONE launch each (esr_conv3x3_chain, csrc/esr_chain.hip): a workgroup recomputes the halo rows of the earlier
-    layers instead of waiting for its neighbours.  Every output pixel sees the same MFMA sequence on the same operands, the interior rows land
-    in the dense-block buffer exactly as the four launches leave them: forward, input gradient and every weight gradient (they contract the
-    stored interiors) must not change by a bit against act.CHAINS = False.  Shapes: 52 x 52 (8 tiles per image, a ragged last one, with and
-    without the latent group), one and several tiles per image, a single image; recorded (launch list) and direct launches; the frozen-generator
-    forward (second destination: the mask stash) as well."""
-    from esr_hip import act as A
-    B, h, w = shape
-
-    def run(chains, use_plans, frozen):
-        keep = A.CHAINS
-        A.CHAINS = chains
-        A.CHAIN_LOG = log = []
-        try:
-            net = make_net(nb=2, lat=lat, precision=precision)
-            net.engine.use_plans = use_plans
-            x = inputs(B, lat, 4, h, w, 83)
-            if precision == 'f16':
-                with torch.no_grad():
-                    return net(x).clone(), None, []
-            if frozen:
-                for p in net.parameters():
-                    p.requires_grad_(False)
-            x.requires_grad_(True)
-            outs = []
-            for it in range(2):                      # the second pass replays the recorded lists
-                x.grad = None
-                for p in net.parameters():
-                    p.grad = None
-                y = net(x)
-                (y * seeded_uniform(tuple(y.shape), 84).cuda()).sum().backward()
-                outs = [y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None]]
-                del y
-            return outs
-        finally:
-            A.CHAINS, A.CHAIN_LOG = keep, None
-            if chains:                               # the comparison is not vacuous: every dense block of this run went out as one launch
-                assert log and all(v == 1 for v in log), log
-    for use_plans, frozen in ((True, False), (False, False), (True, True)):
-        y0, dx0, dw0 = run(False, use_plans, frozen)
-        y1, dx1, dw1 = run(True, use_plans, frozen)
-        assert torch.equal(y0, y1), (use_plans, frozen)
-        assert dx0 is None or torch.equal(dx0, dx1), (use_plans, frozen)
-        assert len(dw0) == len(dw1) and all(torch.equal(a, b) for a, b in zip(dw0, dw1)), (use_plans, frozen)
-        if precision == 'f16':
-            break
-
-
 @pytest.mark.parametrize('split', [True, False, 'f16x2', 'f16x3'])
 def test_batched_weight_pack_is_bit_identical_to_the_single_tensor_pack(split):
     """esr_pack_batch_run (one launch for every pack of a step: each (K chunk, M tile) staged through LDS) against esr_pack_conv_weights (one

@@ -36,7 +36,7 @@ def main():
         assert tail in src
         src = src.replace(tail, tail[:-2] + '    }\n}\n')
     cp = os.path.join(tmp, 'esr_conv_isa.hip')
-    open(cp, 'w').write(src.replace('#include "esr_common.h"', '#include "%s/esr_common.h"' % CSRC).replace('#include "esr_conv_dev.h"', '#include "%s/esr_conv_dev.h"' % CSRC))
+    open(cp, 'w').write(src.replace('#include "esr_common.h"', '#include "%s/esr_common.h"' % CSRC))
     out = a.keep or os.path.join(tmp, 'conv.s')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-function', '-Wno-unused-command-line-argument',
                            '--cuda-device-only', '-S', cp, '-o', out])
