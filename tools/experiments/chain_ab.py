@@ -1,4 +1,5 @@
-"""Same-process A/B of the fused dense-block chains (esr_conv3x3_chain, csrc/esr_chain.hip): esr_hip.act.CHAINS on / off,
+"""(Runs against the tree with tools/experiments/patches/r06_three_experiments.patch applied = commit bc221d6: the experiment lost and is not in the shipping tree.)
+Same-process A/B of the fused dense-block chains (esr_conv3x3_chain, csrc/esr_chain.hip): esr_hip.act.CHAINS on / off,
 alternating, on (a) the configs[2] G + D training step at its per-GPU shape (bench.run_c3's model and data: 32 crops of 52 x 52, bf16),
 with the step's phase times, and (b) configs[0] on the GPU (RRDB-3 x4 + CEM on one 32 x 32 frame: tools/experiments/c1_latency.py) per precision.
 

@@ -1,4 +1,5 @@
-"""Same-process A/B of the critic's real-image forward under the generator's forward (SRRaGANModel.overlap_D_real -> esr_hip.critic.critic_prefetch_first;
+"""(Runs against the tree with tools/experiments/patches/r06_three_experiments.patch applied = commit bc221d6: the experiment lost and is not in the shipping tree.)
+Same-process A/B of the critic's real-image forward under the generator's forward (SRRaGANModel.overlap_D_real -> esr_hip.critic.critic_prefetch_first;
 VERDICT r5 item 3) on the configs[2] G + D training step at its per-GPU shape (bench.run_c3's model and data: 32 crops of 52 x 52, bf16), alternating,
 with the step's phase times (GPU time between events on the main stream: with the overlap the real third of the critic's forward leaves 'D_step'
 and shows — as far as it delays the generator's launches — in 'G_forward').

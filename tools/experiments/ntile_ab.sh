@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Runs against the tree with tools/experiments/patches/r06_three_experiments.patch applied = commit bc221d6.)
 # Same-box A/B of the tiles-per-workgroup constant of the one-MFMA conv kernels (csrc/esr_conv.hip: NTILE_ONE_MFMA):
 #   tools/experiments/ntile_ab.sh <other.so> [repeats]
 # prints ms per step of configs[4] (f16) and of configs[1] in 'mixed' for the shipping library and for <other.so> (a build of the same sources

@@ -1,4 +1,5 @@
-"""Phase stamps of the one-MFMA 32-channel conv kernel with ONE and with TWO tiles per workgroup (csrc/esr_conv.hip: NTILE_ONE_MFMA)
+"""(Runs against the tree with tools/experiments/patches/r06_three_experiments.patch applied = commit bc221d6: the experiment lost and is not in the shipping tree.)
+Phase stamps of the one-MFMA 32-channel conv kernel with ONE and with TWO tiles per workgroup (csrc/esr_conv.hip: NTILE_ONE_MFMA)
 at the configs[1] shape in 'mixed' — written by tools/experiments/trace_conv_mixed.py (instrumented build) into gpurun_out/trace_<cin>_32.npy.
 
     python tools/experiments/ntile_phases.py <trace.npy> <chunks>

@@ -1,4 +1,5 @@
-"""The fused dense-block chain (esr_conv3x3_chain, csrc/esr_chain.hip) against its four separate launches at the training-crop shape, and where a
+"""(Runs against the tree with tools/experiments/patches/r06_three_experiments.patch applied = commit bc221d6: the experiment lost and is not in the shipping tree.)
+The fused dense-block chain (esr_conv3x3_chain, csrc/esr_chain.hip) against its four separate launches at the training-crop shape, and where a
 workgroup of the fused launch spends its time (phase stamps of the instrumented build: make -C explorable-super-resolution_amd/csrc trace;
 ESR_HIP_LIBRARY=explorable-super-resolution_amd/esr_hip/libesr_hip_trace.so).
 
