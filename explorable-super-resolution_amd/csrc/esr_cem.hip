@@ -327,6 +327,46 @@ __device__ __forceinline__ float tap_sum(const float* __restrict__ t, const int 
     return (a0 + a1) + (a2 + a3);
 }
 
+// tap_sum for a column of values `stride` words apart (the vertical passes): the same four running sums in the same order — tap c goes to sum
+// c & 3, the tail to sum 0 — with the address as a pointer that advances once per four taps (the lambda form above re-derives c * stride per tap
+// on the scalar unit: round-5 counters of the downscale kernel, 26.0 M scalar for 34.2 M vector instructions).
+__device__ __forceinline__ float tap_sum_strided(const float* __restrict__ t, const int k, const float* p, const int stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int s2 = 2 * stride, s3 = 3 * stride, s4 = 4 * stride;
+    int c = 0;
+    for (; c + 4 <= k; c += 4, p += s4) {
+        a0 = fmaf(t[c], p[0], a0);
+        a1 = fmaf(t[c + 1], p[stride], a1);
+        a2 = fmaf(t[c + 2], p[s2], a2);
+        a3 = fmaf(t[c + 3], p[s3], a3);
+    }
+    for (; c < k; ++c, p += stride) a0 = fmaf(t[c], p[0], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+
+// tap_sum over a row stored de-interleaved by phase: window column c sits in plane c % SF at column c / SF (planes `pstride` words apart).  Same
+// sums in the same order as tap_sum; SF is a compile-time constant, the taps are walked in blocks of lcm(SF, 4) so that every tap's plane, column
+// step and running sum are constants of the unrolled block and the address is one pointer per plane that advances once per block.
+template <int SF>
+__device__ __forceinline__ float tap_sum_phased(const float* __restrict__ t, const int k, const float* base, const int pstride) {
+    constexpr int BLK = SF % 4 == 0 ? SF : (SF % 2 == 0 ? 2 * SF : 4 * SF);      // lcm(SF, 4)
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const int kmain = k & ~3;                                 // taps [0, kmain) in fours, the tail to sum 0 (tap_sum's rule)
+    int c0 = 0;
+    const float* p = base;                                    // column c0 / SF of plane 0
+    for (; c0 + BLK <= kmain; c0 += BLK, p += BLK / SF) {
+#pragma unroll
+        for (int j = 0; j < BLK; ++j) a[j & 3] = fmaf(t[c0 + j], p[(j % SF) * pstride + j / SF], a[j & 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {                           // the last, partial block
+        const int c = c0 + j;
+        if (c < kmain) a[j & 3] = fmaf(t[c], p[(j % SF) * pstride + j / SF], a[j & 3]);
+        else if (c < k) a[0] = fmaf(t[c], p[(j % SF) * pstride + j / SF], a[0]);
+    }
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Separable fast path.  The bicubic ds_kernel and its inv_hTh are rank one (sigma_2 / sigma_1 ~ 1e-16), taps[a][b] = tv[a]*th[b]:
 // every filter is a horizontal pass followed by a vertical one (or the reverse) on the tile a workgroup holds in LDS — 2k instead of k^2 MACs
@@ -448,14 +488,15 @@ __global__ __launch_bounds__(256) void cem_downscale_sep_kernel(const float* __r
         // window column c of row r sits in plane c % sf at column c / sf
         const float* base = tile + r * qpitch + tx;
         const int pstride = rows * qpitch;
-        hp[r * hpp + tx] = tap_sum(th, k, [&](const int c) { const int q = SFT ? c / SFT : c / sf; return base[(c - q * sf) * pstride + q]; });
+        if constexpr (SFT != 0) hp[r * hpp + tx] = tap_sum_phased<SFT>(th, k, base, pstride);
+        else hp[r * hpp + tx] = tap_sum(th, k, [&](const int c) { const int q = c / sf; return base[(c - q * sf) * pstride + q]; });
     }
     __syncthreads();
     const int ty = threadIdx.x >> 4;
     const int i = i0 + ty, j = j0 + tx;
     if (i < h && j < w) {
         const float* col = hp + ty * sf * hpp + tx;
-        float acc = tap_sum(tv, k, [&](const int a) { return col[a * hpp]; });
+        float acc = tap_sum_strided(tv, k, col, hpp);
         if (lr) {
             const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
             acc = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - acc;
@@ -614,11 +655,18 @@ __global__ __launch_bounds__(256) void cem_downscale_stream_kernel(const float* 
 // the column only and is now formed once per thread and serves four rows; a workgroup's latency chain load -> pass -> pass -> store moves four
 // times the pixels.)
 constexpr int US_Y = 64, US_X = 64, US_RPT = US_Y / 16;
-template <bool TWO, int SFT>
+// FILT (round 6): the LR filter in front of the upscale — out = U(K(f)) instead of U(f) — folded into this kernel.  K = inv_hTh is a kf-tap
+// separable filter on the LR grid with replicate padding (cem_lrfilter_sep_kernel: 27 taps for the x4 bicubic CEM): a tile's window of K(f)
+// ((US + k) / sf + 3 = 23 LR pixels a side at x4) needs f on a (23 + kf - 1)^2 window — staged with clamped indices, filtered in LDS with the
+// separate kernel's two passes and summation order (bit-identical to it: the 64 x 16 tiles of that kernel and these windows evaluate the same
+// FMA sequence per LR pixel), 45 k multiply-adds per tile and plane.  What it removes: a launch of its own (37.5 us of latency at configs[1],
+// 17 MB written and read back) and an LR-sized intermediate per projection.
+template <bool TWO, int SFT, bool FILT = false>
 __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int sf_rt, int pre,
                                                             const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
-                                                            int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc, int vp) {
-    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [US_Y][vp] | vertical pass 2 | tv[k] | th[k]   (vp = 16 mod 32: two rows of a 32-lane group on disjoint banks)
+                                                            int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int wr, int wc, int vp,
+                                                            const float* __restrict__ tvf, const float* __restrict__ thf, int kf, int ep, int hpp) {
+    extern __shared__ float sm[];             // window 1 [wr][wc] | window 2 | vertical pass 1 [US_Y][vp] | vertical pass 2 | tv[k] | th[k] | FILT: raw window [wr + kf - 1][ep] | its horizontal pass [wr + kf - 1][hpp]   (vp = 16 mod 32: two rows of a 32-lane group on disjoint banks)
     float* const w1 = sm;
     float* const w2 = w1 + wr * wc;
     float* const v1 = w2 + (TWO ? wr * wc : 0);
@@ -658,14 +706,63 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
     const int ib = (fy >= 0 ? fy / sf : -((-fy + sf - 1) / sf)), jb = (fx >= 0 ? fx / sf : -((-fx + sf - 1) / sf));
     const float* s1 = f + bc * h * (long long)w;
     const float* s2 = TWO ? f2 + bc * h * (long long)w : nullptr;
-    for (int e = threadIdx.x; e < wr * wc; e += 256) {
-        const int r = e / wc, c = e - r * wc;
-        const int i = ib + r, j = jb + c;
-        const bool in = i >= 0 && i < h && j >= 0 && j < w;
-        w1[e] = in ? s1[(long long)i * w + j] : 0.f;
-        if (TWO) w2[e] = in ? s2[(long long)i * w + j] : 0.f;
+    if constexpr (FILT) {
+        float* const eraw = ths + k;
+        float* const hp = eraw + (wr + kf - 1) * ep;
+        const int pf = kf / 2, er = wr + kf - 1, ec = wc + kf - 1;
+        for (int win = 0; win < (TWO ? 2 : 1); ++win) {
+            const float* const src = win ? s2 : s1;
+            float* const wdst = win ? w2 : w1;
+            // the raw window, replicate-padded by clamping (the LR filter's rule); SB independent loads per thread in flight together
+            constexpr int SB = 8;
+            for (int e0 = threadIdx.x; e0 < er * ec; e0 += 256 * SB) {
+                float tmp[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int e = e0 + u * 256, r = e / ec, c = e - r * ec;
+                    tmp[u] = e < er * ec ? src[(long long)clampi(ib - pf + r, 0, h - 1) * w + clampi(jb - pf + c, 0, w - 1)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int e = e0 + u * 256, r = e / ec, c = e - r * ec;
+                    if (e < er * ec) eraw[r * ep + c] = tmp[u];
+                }
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < er * wc; e += 256) {           // horizontal pass (cem_lrfilter_sep_kernel's sums: even taps, odd taps)
+                const int r = e / wc, c = e - r * wc;
+                const float* row = eraw + r * ep + c;
+                float a0 = 0.f, a1 = 0.f;
+                int cc = 0;
+#pragma unroll 4
+                for (; cc + 1 < kf; cc += 2) { a0 = fmaf(thf[cc], row[cc], a0); a1 = fmaf(thf[cc + 1], row[cc + 1], a1); }
+                if (cc < kf) a0 = fmaf(thf[cc], row[cc], a0);
+                hp[r * hpp + c] = a0 + a1;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < wr * wc; e += 256) {           // vertical pass; samples outside the LR image do not exist for the upscale: zero
+                const int r = e / wc, c = e - r * wc;
+                const float* col = hp + r * hpp + c;
+                float a0 = 0.f, a1 = 0.f;
+                int a = 0;
+#pragma unroll 4
+                for (; a + 1 < kf; a += 2) { a0 = fmaf(tvf[a], col[a * hpp], a0); a1 = fmaf(tvf[a + 1], col[(a + 1) * hpp], a1); }
+                if (a < kf) a0 = fmaf(tvf[a], col[a * hpp], a0);
+                const int i = ib + r, j = jb + c;
+                wdst[e] = (i >= 0 && i < h && j >= 0 && j < w) ? a0 + a1 : 0.f;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int e = threadIdx.x; e < wr * wc; e += 256) {
+            const int r = e / wc, c = e - r * wc;
+            const int i = ib + r, j = jb + c;
+            const bool in = i >= 0 && i < h && j >= 0 && j < w;
+            w1[e] = in ? s1[(long long)i * w + j] : 0.f;
+            if (TWO) w2[e] = in ? s2[(long long)i * w + j] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int e = threadIdx.x; e < US_Y * wc; e += 256) {      // vertical pass
         const int ry1 = e / wc, c = e - ry1 * wc;
         const int Y1 = yo0 + ry1 + crop;
@@ -904,30 +1001,50 @@ extern "C" int esr_cem_lrfilter_sep(const float* x, int B, int C, int h, int w, 
     return ESR_OK;
 }
 
-extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k,
-                                   const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream) {
+// tvf / thf / kf: the LR filter folded in front of the upscale (esr_cem_filter_upscale_sep), or NULL / 0
+static int upscale_sep_launch(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tvf, const float* thf, int kf,
+                              const float* tv, const float* th, int k, const float* g, int crop, int mode, float range, float* out, float* out2,
+                              esr_stream_t stream) {
     if (!f || !tv || !th || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 2 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
     if (mode < 0 || mode > 3 || crop < 0 || 2 * crop >= h * sf || 2 * crop >= w * sf) return ESR_E_ARG;
     if ((mode >= 1 && !g) || (mode >= 2 && !f2) || (mode == 3 && !out2)) return ESR_E_ARG;
+    const bool filt = kf > 0;
+    if (filt && (!tvf || !thf || !(kf & 1))) return ESR_E_ARG;
     const int wr = (US_Y + 2 * (k / 2)) / sf + 3, wc = (US_X + 2 * (k / 2)) / sf + 3;
     const int two = mode >= 2 ? 2 : 1;
     const int vp = wc + (16 - wc % 32 + 32) % 32;                       // pass-1 row pitch = 16 (mod 32)
-    const size_t lds = ((size_t)two * wr * wc + (size_t)two * US_Y * vp + 2 * (size_t)k) * 4;
-    if (lds > 60 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
+    const int er = wr + kf - 1, ec = wc + kf - 1;
+    const int ep = ec | 1, hpp = wc | 1;                                // odd pitches: a column walk down the rows touches every bank once
+    const size_t lds = ((size_t)two * wr * wc + (size_t)two * US_Y * vp + 2 * (size_t)k + (filt ? (size_t)er * ep + (size_t)er * hpp : 0)) * 4;
+    if (lds > 64 * 1024 || (long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
     const dim3 tg((Wo + US_X - 1) / US_X, (Ho + US_Y - 1) / US_Y, B * C);
     ESR_CLEAR_ERR();
-    typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int);
+    typedef void (*up_t)(const float*, const float*, int, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int,
+                         const float*, const float*, int, int, int);
     up_t kern;
-    if (mode >= 2)
-        kern = sf == 2 ? cem_upscale_sep_kernel<true, 2> : sf == 3 ? cem_upscale_sep_kernel<true, 3> : sf == 4 ? cem_upscale_sep_kernel<true, 4>
-               : sf == 8 ? cem_upscale_sep_kernel<true, 8> : cem_upscale_sep_kernel<true, 0>;
-    else
-        kern = sf == 2 ? cem_upscale_sep_kernel<false, 2> : sf == 3 ? cem_upscale_sep_kernel<false, 3> : sf == 4 ? cem_upscale_sep_kernel<false, 4>
-               : sf == 8 ? cem_upscale_sep_kernel<false, 8> : cem_upscale_sep_kernel<false, 0>;
-    hipLaunchKernelGGL(kern, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2, wr, wc, vp);
+#define ESR_UP_PICK(TWO_, FILT_)                                                                                                                   \
+    (sf == 2 ? cem_upscale_sep_kernel<TWO_, 2, FILT_> : sf == 3 ? cem_upscale_sep_kernel<TWO_, 3, FILT_> : sf == 4 ? cem_upscale_sep_kernel<TWO_, 4, FILT_> \
+     : sf == 8 ? cem_upscale_sep_kernel<TWO_, 8, FILT_> : cem_upscale_sep_kernel<TWO_, 0, FILT_>)
+    if (filt) kern = mode >= 2 ? ESR_UP_PICK(true, true) : ESR_UP_PICK(false, true);
+    else kern = mode >= 2 ? ESR_UP_PICK(true, false) : ESR_UP_PICK(false, false);
+#undef ESR_UP_PICK
+    hipLaunchKernelGGL(kern, tg, dim3(256), lds, (hipStream_t)stream, f, f2, h, w, sf, pre, tv, th, k, g, crop, mode, range, out, out2, wr, wc, vp, tvf, thf, kf,
+                       ep, hpp);
     ESR_CHECK_LAUNCH();
     return ESR_OK;
+}
+
+extern "C" int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k,
+                                   const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream) {
+    return upscale_sep_launch(f, f2, B, C, h, w, sf, pre, nullptr, nullptr, 0, tv, th, k, g, crop, mode, range, out, out2, stream);
+}
+
+extern "C" int esr_cem_filter_upscale_sep(const float* e, const float* e2, int B, int C, int h, int w, int sf, int pre, const float* tvf, const float* thf,
+                                          int kf, const float* tv, const float* th, int k, const float* g, int crop, int mode, float range, float* out,
+                                          float* out2, esr_stream_t stream) {
+    if (kf < 1) return ESR_E_ARG;
+    return upscale_sep_launch(e, e2, B, C, h, w, sf, pre, tvf, thf, kf, tv, th, k, g, crop, mode, range, out, out2, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -144,8 +144,7 @@ class _CemProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lr, g, taps_down, taps_inv, taps_up, sf, pre, lr_pad, crop):
         e = cem_ops.downscale_raw(g, taps_down, sf, pre, lr=lr, lr_pad=lr_pad)
-        f = cem_ops.lr_filter_raw(e, taps_inv)
-        out = cem_ops.upscale_raw(f, taps_up, sf, pre, g=g, crop=crop, mode=1)
+        out = cem_ops.filter_upscale_raw(e, taps_inv, taps_up, sf, pre, g=g, crop=crop, mode=1)
         ctx.cfg = (sf, pre, lr_pad, crop, tuple(g.shape), tuple(e.shape))
         ctx.tabs = (_tabs_for(taps_down), _tabs_for(taps_inv), _tabs_for(taps_up))
         return out

@@ -132,6 +132,44 @@ def upscale_raw(f, taps, sf, pre, f2=None, g=None, crop=0, mode=0, rng=0.0, out=
     return (out, out2) if mode == 3 else out
 
 
+# K(.) folded into the upscale launch (esr_cem_filter_upscale_sep; both tap sets rank one) — for launches of at most FOLD_MAX_TILES 64 x 64 output
+# tiles.  Measured on MI355X (tools/experiments/cem_fold_ab.py, profiles/r06_cem_fold_ab.log): every tile re-filters its own (23 + 26)^2 window of
+# the LR operand, 1.8 x the multiply-adds of the separate filter launch per LR pixel, inside a kernel that is instruction-issue bound — the
+# projection gets SLOWER where the launches are large (configs[1], 8,256 tiles: 0.200 vs 0.186 ms; configs[4]: 1.27 vs 1.15 ms) and faster only
+# where a launch is all latency (configs[0] on the GPU, 48 tiles: 557.7 vs 562.7 us per forward).  True / False force it on / off (tests).
+FUSE_FILTER_UPSCALE = None
+FOLD_MAX_TILES = 512
+
+
+def filter_upscale_raw(e, taps_inv, taps_up, sf, pre, e2=None, g=None, crop=0, mode=0, rng=0.0, out=None):
+    """upscale_raw(lr_filter_raw(e, taps_inv), taps_up, ..., f2=lr_filter_raw(e2, taps_inv)) — as ONE launch (esr_cem_filter_upscale_sep: every tile
+    filters its own window of e on chip, bit-identical to the two launches) when both filters are separable and the windows fit, else as the two
+    (three) launches."""
+    e = _prep(e, 'LR image')
+    sep_i, sep_u = _sep(taps_inv, e.device), _sep(taps_up, e.device)
+    B, Cc, h, w = e.shape
+    Ho, Wo = sf * h - 2 * crop, sf * w - 2 * crop
+    fold = FUSE_FILTER_UPSCALE if FUSE_FILTER_UPSCALE is not None else B * Cc * ((Ho + 63) // 64) * ((Wo + 63) // 64) <= FOLD_MAX_TILES
+    if fold and sep_i is not None and sep_u is not None:
+        o = out if out is not None else torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=e.device)
+        assert o.shape == (B, Cc, Ho, Wo) and o.dtype == torch.float32 and o.is_contiguous()
+        o2 = torch.empty_like(o) if mode == 3 else None
+        e2p = _prep(e2, 'LR image') if e2 is not None else None
+        gp = _prep(g, 'generated image') if g is not None else None
+        if gp is not None:
+            assert gp.shape == (B, Cc, sf * h, sf * w)
+        rc = _lib.lib.esr_cem_filter_upscale_sep(e.data_ptr(), e2p.data_ptr() if e2p is not None else None, B, Cc, h, w, sf, pre, sep_i[0].data_ptr(),
+                                                 sep_i[1].data_ptr(), _taps(taps_inv, e.device).shape[0], sep_u[0].data_ptr(), sep_u[1].data_ptr(),
+                                                 _taps(taps_up, e.device).shape[0], gp.data_ptr() if gp is not None else None, crop, mode,
+                                                 float(rng if rng is not None else 0.0), o.data_ptr(), o2.data_ptr() if o2 is not None else None, stream_ptr())
+        if rc != _lib.ESR_E_UNSUPPORTED:
+            check(rc, 'esr_cem_filter_upscale_sep')
+            return (o, o2) if mode == 3 else o
+    f = lr_filter_raw(e, taps_inv)
+    f2 = lr_filter_raw(e2, taps_inv) if e2 is not None else None
+    return upscale_raw(f, taps_up, sf, pre, f2=f2, g=g, crop=crop, mode=mode, rng=rng, out=out)
+
+
 def adjoint_raw(dy, tabs, kind, sf, pre, in_shape, base=None, alpha=1.0):
     """Transpose of one CEM filter: dy (the op's output gradient) -> base + alpha * (gradient w.r.t. the op's input of shape `in_shape`).
     tabs: autograd.AdjointTables — rank-one taps run the two 1-D passes (esr_cem_adjoint_sep), anything else the 2-D gather."""
@@ -202,18 +240,16 @@ def project(lr, g, taps_down, taps_inv, taps_up, sf, pre, lr_pad=0, crop=0, sigm
             out = torch.empty(B, g.shape[1], g.shape[2] - 2 * crop, g.shape[3] - 2 * crop, dtype=torch.float32, device=g.device)
             for b0 in range(0, B, nb):
                 gc, lc = g[b0:b0 + nb], lr[b0:b0 + nb]
-                f = lr_filter_raw(downscale_raw(gc, taps_down, sf, pre, lr=lc, lr_pad=lr_pad), taps_inv)
-                upscale_raw(f, taps_up, sf, pre, g=gc, crop=crop, mode=1, out=out[b0:b0 + nb])
+                e = downscale_raw(gc, taps_down, sf, pre, lr=lc, lr_pad=lr_pad)
+                filter_upscale_raw(e, taps_inv, taps_up, sf, pre, g=gc, crop=crop, mode=1, out=out[b0:b0 + nb])
             return out
         e = downscale_raw(g, taps_down, sf, pre, lr=lr, lr_pad=lr_pad)       # x - D(g) on the padded frame
-        f = lr_filter_raw(e, taps_inv)                                        # K (x - D g)
-        return upscale_raw(f, taps_up, sf, pre, g=g, crop=crop, mode=1)       # crop(g + U(.))
+        return filter_upscale_raw(e, taps_inv, taps_up, sf, pre, g=g, crop=crop, mode=1)       # crop(g + U(K(x - D g)))
     lr_p = torch.nn.functional.pad(lr, (lr_pad,) * 4, mode='replicate') if lr_pad else lr
-    fx = lr_filter_raw(lr_p, taps_inv)
-    fg = lr_filter_raw(downscale_raw(g, taps_down, sf, pre), taps_inv)
+    dg = downscale_raw(g, taps_down, sf, pre)
     if decomposed:
-        ortho, ns = upscale_raw(fx, taps_up, sf, pre, f2=fg, g=g, crop=crop, mode=3)
+        ortho, ns = filter_upscale_raw(lr_p, taps_inv, taps_up, sf, pre, e2=dg, g=g, crop=crop, mode=3)
         if sigmoid_range is not None:
             ns = torch.tanh(ns) * sigmoid_range
         return [ortho, ns]
-    return upscale_raw(fx, taps_up, sf, pre, f2=fg, g=g, crop=crop, mode=2, rng=sigmoid_range)
+    return filter_upscale_raw(lr_p, taps_inv, taps_up, sf, pre, e2=dg, g=g, crop=crop, mode=2, rng=sigmoid_range)

@@ -238,6 +238,14 @@ int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w, int sf, in
 int esr_cem_lrfilter_sep(const float* x, int B, int C, int h, int w, const float* tv, const float* th, int k, float* out, esr_stream_t stream);
 int esr_cem_upscale_sep(const float* f, const float* f2, int B, int C, int h, int w, int sf, int pre, const float* tv, const float* th, int k,
                         const float* g, int crop, int mode, float range, float* out, float* out2, esr_stream_t stream);
+/* esr_cem_lrfilter_sep followed by esr_cem_upscale_sep as ONE launch: every mode of esr_cem_upscale_sep with K(e) (and K(e2)) in place of f (f2),
+ * K = the kf-tap separable LR filter tvf x thf with replicate padding (CEM_PyTorch.forward's Conv_LR_with_Inv_hTh_OP in front of Upscale_OP,
+ * codes/CEM/CEMnet.py:305-309).  Each tile filters its own window of e on chip, with the separate kernel's passes and summation order: results are
+ * bit-identical to the two launches, the LR-sized intermediate and its launch are gone.  ESR_E_UNSUPPORTED: the windows do not fit on chip for this
+ * (sf, k, kf) — run the two launches. */
+int esr_cem_filter_upscale_sep(const float* e, const float* e2, int B, int C, int h, int w, int sf, int pre, const float* tvf, const float* thf, int kf,
+                               const float* tv, const float* th, int k, const float* g, int crop, int mode, float range, float* out, float* out2,
+                               esr_stream_t stream);
 
 /* ---- backward-pass helpers (autograd of the reference's torch ops) ----
  * out = alpha*A + beta*sumpool_s(Bv), optionally * LeakyReLU'(mask) — gradient of the nearest upsample

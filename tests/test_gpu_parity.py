@@ -418,6 +418,55 @@ def test_separable_cem_kernels_match_the_2d_kernels(sf, kernel):
         assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max())), (i, float((u - v).abs().max()))
 
 
+@pytest.mark.parametrize('sf,kernel,hw', [(2, None, (21, 37)), (3, None, (21, 37)), (4, None, (21, 37)), (4, None, (148, 148)), (8, None, (19, 23)),
+                                          (8, 'blurry_cubic_2.0', (40, 33)), (4, 'blurry_cubic_1.0', (21, 37))])
+def test_filter_folded_into_the_upscale_launch_is_bit_identical_to_the_two_launches(sf, kernel, hw):
+    """Round 6: esr_cem_filter_upscale_sep — the LR filter K = inv_hTh evaluated per tile inside the upscale launch (every tile
+    filters its own clamped window of the LR operand on chip, with the separate kernel's two passes and summation order) against
+    esr_cem_lrfilter_sep followed by esr_cem_upscale_sep: every mode (plain, g + U(K e) with crop, tanh range with two operands, decomposed),
+    ragged sizes (tiles that stick out of the image, windows that reach past every border: the replicate clamp of K and the zero frame of U),
+    one LR-sized intermediate and one launch fewer per projection.  Equal to the last bit; so are project() and its differentiable form."""
+    from esr_hip import cem_ops
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    import CEM.CEMnet as C
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    td, ti, tu = G.DownscaleOP.taps(), G.Conv_LR_with_Inv_hTh_OP.taps(), G.Upscale_OP.taps()
+    pre = sf - sf // 2 - 1
+    h, w = hw
+    y = seeded_uniform((2, 3, sf * h, sf * w), 311).to(DEV)
+    x = seeded_uniform((2, 3, h, w), 313, -1.0, 1.0).to(DEV)
+    x2 = seeded_uniform((2, 3, h, w), 314, -1.0, 1.0).to(DEV)
+    lr = seeded_uniform((2, 3, h - 6, w - 6), 312).to(DEV)
+
+    def run():
+        out = [cem_ops.filter_upscale_raw(x, ti, tu, sf, pre), cem_ops.filter_upscale_raw(x, ti, tu, sf, pre, g=y, crop=2 * sf, mode=1),
+               cem_ops.filter_upscale_raw(x, ti, tu, sf, pre, e2=x2, g=y, crop=sf, mode=2, rng=1.0)]
+        out += list(cem_ops.filter_upscale_raw(x, ti, tu, sf, pre, e2=x2, g=y, crop=0, mode=3))
+        out.append(cem_ops.project(lr, y, td, ti, tu, sf, pre, lr_pad=3, crop=3 * sf))
+        out.append(cem_ops.project(lr, y, td, ti, tu, sf, pre, lr_pad=3, crop=3 * sf, sigmoid_range=1.0))
+        yg = y.clone().requires_grad_(True)
+        o = cem_ops.project(lr, yg, td, ti, tu, sf, pre, lr_pad=3, crop=3 * sf)
+        o.sum().backward()
+        return out + [o.detach(), yg.grad]
+    calls = []
+    real = cem_ops._lib.lib.esr_cem_filter_upscale_sep
+    try:
+        cem_ops.FUSE_FILTER_UPSCALE = True
+        cem_ops._lib.lib.esr_cem_filter_upscale_sep = lambda *a: (calls.append(real(*a)), calls[-1])[1]
+        a = run()
+        cem_ops._lib.lib.esr_cem_filter_upscale_sep = real
+        cem_ops.FUSE_FILTER_UPSCALE = False
+        b = run()
+    finally:
+        cem_ops._lib.lib.esr_cem_filter_upscale_sep = real
+        cem_ops.FUSE_FILTER_UPSCALE = None
+    assert len(calls) == 7 and all(rc == 0 for rc in calls), calls            # the folded launch really ran (no quiet fallback to the two launches)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert u.shape == v.shape and torch.equal(u, v), (i, float((u - v).abs().max()))
+
+
 def test_anisotropic_kernels_keep_the_2d_path():
     from esr_hip import cem_ops
     from oracle.gen_golden import aniso_gaussian_kernel
