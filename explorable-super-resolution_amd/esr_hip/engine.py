@@ -81,6 +81,10 @@ class RRDBEngine:
         self.wgrad_overlap = WGRAD_OVERLAP
         self._side, self._xs = None, None
         self.n_up = 1 if net.upscale == 3 else len([1 for mod in net.model if isinstance(mod, torch.nn.Sequential)])
+        # channel groups (8 channels each) of the residual stream (nf) and of a dense block's buffer [x (nf) | x1 | x2 | x3 | x4 (gc = 32 each)]:
+        # 8 and 24 for the reference's nf = 64 (every shipped options file); nf = 16, 32, 48 run the same plan
+        self.ng = net.nf // 8
+        self.nd = self.ng + 16
 
     def set_precision(self, precision):
         # 'mixed': fp16; residual stream stored hi+lo; hi+lo weights x hi+lo activations (3 MFMAs) in the few layers outside the dense blocks,
@@ -289,6 +293,7 @@ class RRDBEngine:
         if self._packed_rdb_t is None:
             d = {}
             mods = {name: (c, lat) for name, c, lat in self._convs()}
+            nf = self.net.nf
             for r in range(self.net.nb):
                 for k in range(3):
                     name = 'rrdb%d.rdb%d' % (r, k)
@@ -297,9 +302,9 @@ class RRDBEngine:
                     s4 = 0.2 * (0.2 if k == 2 else 1.0)
                     pieces = [(ws[4], s4), (ws[3], 1.0), (ws[2], 1.0), (ws[1], 1.0), (ws[0], 1.0)]
                     for c in (3, 2, 1, 0):
-                        rows = list(range(lat + 64 + 32 * c, lat + 96 + 32 * c))
+                        rows = list(range(lat + nf + 32 * c, lat + nf + 32 + 32 * c))
                         d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self._bwd_wfmt(True))
-                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + 64))] * 5, split=self._bwd_wfmt(True))
+                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + nf))] * 5, split=self._bwd_wfmt(True))
                     if lat:
                         d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_wfmt(True))
             self._packed_rdb_t = d
@@ -338,7 +343,7 @@ class RRDBEngine:
 
     def _new_buffers(self, B, h, w, dev, keep):
         net, sp = self.net, self.split
-        sf = net.upscale
+        sf, ng = net.upscale, self.ng
         d = {}
         has_lat = net.latent_input is not None and net.num_latent_channels > 0
         if has_lat:
@@ -346,21 +351,21 @@ class RRDBEngine:
             if net._lat_all_layers:
                 d['zhr'] = A.ActBuf(B, 1, sf * h, sf * w, dev, sp)
         d['xin'] = A.ActBuf(B, 1, h, w, dev, sp)
-        d['fea'] = A.ActBuf(B, 8, h, w, dev, sp)
+        d['fea'] = A.ActBuf(B, ng, h, w, dev, sp)
         # inference: three rotating RDB buffers; differentiable forward: one per RDB (saved activations)
-        d['rdb'] = [A.ActBuf(B, 24, h, w, dev, sp) for _ in range(3 * net.nb if keep is True else 3)]
+        d['rdb'] = [A.ActBuf(B, self.nd, h, w, dev, sp) for _ in range(3 * net.nb if keep is True else 3)]
         if keep == 'masks':
             one_plane = 'f16' if sp in ('mixed', 'f16', 'f16x2', 'f16x3') else False
             d['stash'] = [A.ActBuf(B, 16, h, w, dev, one_plane) for _ in range(3 * net.nb)]
-        d['last'] = A.ActBuf(B, 8, h, w, dev, sp)
-        d['trunk'] = A.ActBuf(B, 8, h, w, dev, sp)
+        d['last'] = A.ActBuf(B, ng, h, w, dev, sp)
+        d['trunk'] = A.ActBuf(B, ng, h, w, dev, sp)
         ups = []
         s = 1
         for j in range(self.n_up):
             s *= 3 if sf == 3 else 2
-            ups.append(A.ActBuf(B, 8, s * h, s * w, dev, sp))
+            ups.append(A.ActBuf(B, ng, s * h, s * w, dev, sp))
         d['ups'] = ups
-        d['hr0'] = A.ActBuf(B, 8, sf * h, sf * w, dev, sp)
+        d['hr0'] = A.ActBuf(B, ng, sf * h, sf * w, dev, sp)
         d['_plans'] = {}                      # recorded launch lists over this buffer set (shared by its leased copies)
         return d
 
@@ -435,6 +440,7 @@ class RRDBEngine:
         h, w = h0 + 2 * pad, w0 + 2 * pad
         H, W = sf * h, sf * w
         conv = A.conv3x3
+        nf, ng, nd = net.nf, self.ng, self.nd
         A.reset_launch_parity()
 
         # ---- input packing (+ replicate pad, + latent bilinear /sf)
@@ -460,11 +466,11 @@ class RRDBEngine:
             return rdb[j] if keep is True else rdb[j % 3]
 
         # ---- fea_conv -> fea (shortcut source) and the first RDB buffer
-        conv(pk['fea'], bufs['xin'].view(), B, h, w, 64, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, 8) if net.nb else None, name='fea_conv')
+        conv(pk['fea'], bufs['xin'].view(), B, h, w, nf, in0=zlr, out=bufs['fea'].view(), out2=buf_of(0).view(0, ng) if net.nb else None, name='fea_conv')
         # 'mixed': the dense blocks' intermediate activations (outputs of convs 0-3, read only inside their RDB) are ONE fp16 plane; only
         # the RDB input (groups 0:8, the residual stream) keeps hi+lo.  Their lo planes are never written (they stay zero).
         mixed = self.split == 'mixed'
-        lo8 = dict(in1_lo_groups=8) if mixed else {}
+        lo8 = dict(in1_lo_groups=ng) if mixed else {}
         xlo_mode = self.mixed_xlo
         lo_in = lo8 if xlo_mode == 'all' else dict(in1_lo_groups=-1)
         lo_c4 = lo8 if xlo_mode in ('all', 'conv4') else dict(in1_lo_groups=-1)
@@ -476,18 +482,18 @@ class RRDBEngine:
                 buf, nxt = buf_of(3 * r + k), buf_of(3 * r + k + 1)
                 for i in range(4):
                     o2 = dict(out2=bufs['stash'][3 * r + k].view(4 * i, 4)) if keep == 'masks' else {}      # the one-plane copy the backward's masks read
-                    conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, 8 + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
-                         out=buf.view(8 + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
+                    conv(pk['rrdb%d.rdb%d.conv%d' % (r, k, i)], buf.view(0, ng + 4 * i), B, h, w, 32, in0=zall, act_slope=0.2,
+                         out=buf.view(ng + 4 * i, 4, with_lo=not mixed), name='rrdb%d.rdb%d.conv%d' % (r, k, i), **(lo_in if (i > 0 or xlo_mode != 'all') else {}), **o2)
                 name = 'rrdb%d.rdb%d.conv4' % (r, k)
                 if k < 2:     # RDB output: 0.2*conv5 + x            (block.py:235)
-                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.2, res1=buf.view(0, 8), beta1=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
+                    conv(pk[name], buf.view(0, nd), B, h, w, nf, in0=zall, alpha=0.2, res1=buf.view(0, ng), beta1=1.0, out=nxt.view(0, ng), name=name, **lo_c4)
                 else:         # RRDB output: 0.2*(0.2*conv5 + x) + x_rrdb   (block.py:270); lands in the next RRDB's first buffer
                     # (inference: that is rrdb_in's own buffer when the three buffers rotate; the kernel's in-place residual is safe)
-                    conv(pk[name], buf.view(0, 24), B, h, w, 64, in0=zall, alpha=0.04, res1=buf.view(0, 8), beta1=0.2,
-                         res2=rrdb_in.view(0, 8), beta2=1.0, out=nxt.view(0, 8), name=name, **lo_c4)
-        last = buf_of(nrdb).view(0, 8) if net.nb else bufs['fea'].view()
+                    conv(pk[name], buf.view(0, nd), B, h, w, nf, in0=zall, alpha=0.04, res1=buf.view(0, ng), beta1=0.2,
+                         res2=rrdb_in.view(0, ng), beta2=1.0, out=nxt.view(0, ng), name=name, **lo_c4)
+        last = buf_of(nrdb).view(0, ng) if net.nb else bufs['fea'].view()
         # LR_conv + trunk shortcut (block.py:96)
-        conv(pk['lr_conv'], last, B, h, w, 64, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view(), name='LR_conv')
+        conv(pk['lr_conv'], last, B, h, w, nf, in0=zall, res1=bufs['fea'].view(), beta1=1.0, out=bufs['trunk'].view(), name='LR_conv')
         # upsamplers: nearest xs folded into the conv's input read
         src, s = bufs['trunk'], 1
         for j in range(self.n_up):
@@ -497,9 +503,9 @@ class RRDBEngine:
                 for q in range(f * f):
                     conv(pk['up%d' % j, q], src.view(), B, s // f * h, s // f * w, 64, act_slope=0.2, out=bufs['ups'][j].view(), pixel_shuffle=f, ps_rowgroup0=8 * q, name='upconv%d' % j)
             else:
-                conv(pk['up%d' % j], src.view(), B, s * h, s * w, 64, upsample=f, act_slope=0.2, out=bufs['ups'][j].view(), name='upconv%d' % j)
+                conv(pk['up%d' % j], src.view(), B, s * h, s * w, nf, upsample=f, act_slope=0.2, out=bufs['ups'][j].view(), name='upconv%d' % j)
             src = bufs['ups'][j]
-        conv(pk['hr0'], src.view(), B, H, W, 64, in0=zhr, act_slope=0.2, out=bufs['hr0'].view(), name='HR_conv0')
+        conv(pk['hr0'], src.view(), B, H, W, nf, in0=zhr, act_slope=0.2, out=bufs['hr0'].view(), name='HR_conv0')
         conv(pk['hr1'], bufs['hr0'].view(), B, H, W, net.out_nc, in0=zhr, out_nchw=g)
         A.host_op(lambda ctx: self._ev and self._ev[1].record())
 
@@ -559,6 +565,7 @@ class RRDBEngine:
         dev = dg.device
         pt = self.packed_t()
         conv = A.conv3x3
+        nf, ng, nd = net.nf, self.ng, self.nd
         A.reset_launch_parity()
         f16_bwd = sp == 'mixed'
         gscale = None                 # device scalar: the power of two the gradients in flight are currently scaled by
@@ -626,20 +633,20 @@ class RRDBEngine:
         # ---- HR part
         G_g = galloc(B, 1, H, W)
         A.pack_nchw(dg, G_g.view(), 0, net.out_nc)
-        G_hr0 = galloc(B, 8, H, W)
+        G_hr0 = galloc(B, ng, H, W)
         # the latent's own gradient is only computed when the input asks for one (Z search); a training step — Z is a noise input — skips
         # those launches (one 192 -> lat data-gradient conv per RDB plus the HR ones: ~1.5 ms of the configs[2] step)
         zgrad = need_dx and lat
         GZ_hr = galloc(B, 1, H, W) if (has_lat and zgrad) else None
         GZ_lr = galloc(B, 1, h, w) if (has_lat and need_dx) else None
         wg.conv('hr1', G_g.view(), bufs['hr0'].view(), zview('zhr') if lat else None, H, W, keep=(G_g,))
-        dgrad('hr1', G_g.view(), G_hr0, 0, 8, H, W, mask=(bufs['hr0'], 0, 8))
+        dgrad('hr1', G_g.view(), G_hr0, 0, ng, H, W, mask=(bufs['hr0'], 0, ng))
         if GZ_hr is not None:
             dgrad_z('hr1', G_g.view(), GZ_hr, H, W, 1.0, first=True)
-        G_up = galloc(B, 8, H, W)
+        G_up = galloc(B, ng, H, W)
         src_act = bufs['ups'][-1] if self.n_up else bufs['trunk']
         wg.conv('hr0', G_hr0.view(), src_act.view(), zview('zhr') if lat else None, H, W, keep=(G_hr0,))
-        dgrad('hr0', G_hr0.view(), G_up, 0, 8, H, W, mask=(src_act, 0, 8) if self.n_up else None)
+        dgrad('hr0', G_hr0.view(), G_up, 0, ng, H, W, mask=(src_act, 0, ng) if self.n_up else None)
         if GZ_hr is not None:
             dgrad_z('hr0', G_hr0.view(), GZ_hr, H, W, 1.0, first=False)
         del G_hr0, G_g
@@ -661,10 +668,10 @@ class RRDBEngine:
                 cur_g = nxt_g
                 continue
             wg.conv('up%d' % j, cur_g.view(), below.view(), None, Hj, Wj, upsample=f, keep=(cur_g,))
-            tmp = galloc(B, 8, Hj, Wj)
-            dgrad('up%d' % j, cur_g.view(), tmp, 0, 8, Hj, Wj)
+            tmp = galloc(B, ng, Hj, Wj)
+            dgrad('up%d' % j, cur_g.view(), tmp, 0, ng, Hj, Wj)
             s //= f
-            nxt_g = galloc(B, 8, s * h, s * w)
+            nxt_g = galloc(B, ng, s * h, s * w)
             A.act_combine(nxt_g.view(), B, Bv=tmp.view(), beta=1.0, s=f, mask=below.view() if j > 0 else None)
             cur_g = nxt_g
             del tmp
@@ -679,16 +686,16 @@ class RRDBEngine:
         pr = self.packed_rdb_t() if net.nb else {}
         # RDB gradient buffers G' (see packed_rdb_t): 4 rotating ones — unless weight gradients are wanted: then every RDB keeps its
         # own, because its dy slices feed the deferred batched launch
-        ring = [galloc(B, 24, h, w) for _ in range(4)] if (net.nb and not need_dw) else []
+        ring = [galloc(B, nd, h, w) for _ in range(4)] if (net.nb and not need_dw) else []
         nseq = 3 * net.nb
 
         def gbuf(n):                          # n-th RDB in backward order (n = 0: last RDB of the last RRDB)
-            return ring[n % 4] if ring else galloc(B, 24, h, w)
+            return ring[n % 4] if ring else galloc(B, nd, h, w)
 
         G_cur = gbuf(0) if net.nb else None
-        G_first = G_cur if net.nb else galloc(B, 8, h, w)      # receives d(output of the last RRDB) = d(LR_conv input)
+        G_first = G_cur if net.nb else galloc(B, ng, h, w)      # receives d(output of the last RRDB) = d(LR_conv input)
         wg.conv('lr_conv', G_trunk.view(), last_act.view(), zview('zlr') if lat else None, h, w, keep=(G_trunk,))
-        dgrad('lr_conv', G_trunk.view(), G_first, 0, 8, h, w)
+        dgrad('lr_conv', G_trunk.view(), G_first, 0, ng, h, w)
         zfirst = True
         if zgrad:
             dgrad_z('lr_conv', G_trunk.view(), GZ_lr, h, w, 1.0, first=True)
@@ -704,37 +711,37 @@ class RRDBEngine:
                 name = 'rrdb%d.rdb%d' % (r, k)
                 s_out = 0.2 if k == 2 else 1.0          # RDB3's output enters the RRDB sum scaled by 0.2
                 if need_dw:
-                    wg.conv(name + '.conv4', G.view(0, 8), X.view(0, 24), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
+                    wg.conv(name + '.conv4', G.view(0, ng), X.view(0, nd), zview('zlr') if lat else None, h, w, alpha=0.2 * s_out, keep=(G, X))
                 for c in (3, 2, 1, 0):
-                    g0 = 8 + 4 * (3 - c)                 # dy of conv c goes right behind the gradients it is computed from
+                    g0 = ng + 4 * (3 - c)                # dy of conv c goes right behind the gradients it is computed from
                     conv(pr[name, 'g%d' % c], G.view(0, g0), B, h, w, 32, out=G.view(g0, 4, with_lo=not f16_bwd), use_bias=False,
-                         mask_src=X.view(8 + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
+                         mask_src=X.view(ng + 4 * c, 4) if stash is None else stash.view(4 * c, 4), mask_cg=(0, 4), mask_slope=0.2, **hi_only)
                     if need_dw:
-                        wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, 8 + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
+                        wg.conv('%s.conv%d' % (name, c), G.view(g0, 4), X.view(0, ng + 4 * c), zview('zlr') if lat else None, h, w, keep=(G, X))
                 if zgrad:
                     kwz = {} if zfirst else dict(res1=GZ_lr.view(), beta1=1.0)
-                    conv(pr[name, 'gz'], G.view(0, 24), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
+                    conv(pr[name, 'gz'], G.view(0, nd), B, h, w, lat1, out=GZ_lr.view(), use_bias=False, **kwz, **hi_only)
                     zfirst = False
                 # d(RDB input) = s_out*dy_out + sum_i W_i^T dy_i  (+ d(out of the RRDB) for its first RDB: the RRDB skip connection),
                 # written where the next RDB in backward order expects its dy_out
                 n += 1
-                G_next = gbuf(n) if n < nseq else galloc(B, 8, h, w)
-                kw = dict(res2=G_rrdb.view(0, 8), beta2=1.0) if k == 0 else {}
-                conv(pr[name, 'gx'], G.view(0, 24), B, h, w, 64, out=G_next.view(0, 8), use_bias=False, res1=G.view(0, 8), beta1=s_out, **kw, **hi_only)
+                G_next = gbuf(n) if n < nseq else galloc(B, ng, h, w)
+                kw = dict(res2=G_rrdb.view(0, ng), beta2=1.0) if k == 0 else {}
+                conv(pr[name, 'gx'], G.view(0, nd), B, h, w, nf, out=G_next.view(0, ng), use_bias=False, res1=G.view(0, ng), beta1=s_out, **kw, **hi_only)
                 G_cur = G_next
             if f16_bwd and self.grad_renorm:
                 # d(input of RRDB r) is complete and not yet recorded anywhere: renormalise it (and the latent gradient accumulated so far)
-                scaler.rescale(B, [G_cur.view(0, 8)] + ([GZ_lr.view()] if zgrad and not zfirst else []), 10)
+                scaler.rescale(B, [G_cur.view(0, ng)] + ([GZ_lr.view()] if zgrad and not zfirst else []), 10)
                 gscale = scaler.current
                 wg.gscale = gscale
             dout = G_cur
         # d fea = d trunk (shortcut) + d(first RRDB input)
-        G_fea = galloc(B, 8, h, w)
+        G_fea = galloc(B, ng, h, w)
         G_short = G_trunk
         if f16_bwd and net.nb:        # the shortcut's gradient at the current scale (a copy: the weight-gradient launch still reads G_trunk)
-            G_short = galloc(B, 8, h, w)
+            G_short = galloc(B, ng, h, w)
             scaler.rescaled_copy(B, G_trunk.view(), G_short.view(), gscale_trunk)
-        A.act_combine(G_fea.view(), B, A_=dout.view(0, 8), alpha=1.0, Bv=G_short.view(), beta=1.0, s=1)
+        A.act_combine(G_fea.view(), B, A_=dout.view(0, ng), alpha=1.0, Bv=G_short.view(), beta=1.0, s=1)
         wg.conv('fea', G_fea.view(), bufs['xin'].view(), zview('zlr'), h, w, keep=(G_fea,))
         if need_dx:
             if dx is None:

@@ -200,6 +200,34 @@ def gen_F8():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_first_layer.npz'), **out)
 
 
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+
+
+def gen_F13():
+    """RRDBNet with nf != 64 (architecture.py:228-230 takes any nf; growth channels stay 32): forward, input gradient, weight-gradient digests.
+    Its own fixture file (round 6): F4's stays byte-identical."""
+    import models.modules.architecture as arch
+    out = {}
+    for name, nf, nb, sf, lat in NF_CASES:
+        torch.manual_seed(0)
+        net = arch.RRDBNet(in_nc=3, out_nc=3, nf=nf, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA', upsample_mode='upconv',
+                           latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
+        n = fill_formula_weights(net, gain=1.0)
+        x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 131 + nf + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+        if lat:
+            x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+        x.requires_grad_(True)
+        y = net(x)
+        cot = seeded_uniform(tuple(y.shape), 141 + nf + nb + sf + lat, -1.0, 1.0)
+        (y * cot).sum().backward()
+        out[name + '/out'] = y.detach().numpy()
+        out[name + '/dx'] = x.grad.numpy()
+        out[name + '/dparams'] = np.stack([_param_digest(p.grad) for _, p in net.named_parameters()])
+        out[name + '/nparams'] = np.array([n, sum(p.numel() for p in net.parameters())])
+        print(name, tuple(y.shape), float(y.detach().abs().mean()), float(x.grad.abs().mean()))
+    np.savez_compressed(os.path.join(GOLDEN, 'rrdb_nf.npz'), **out)
+
+
 def gen_F9():
     """RRDBNet(upsample_mode='pixelshuffle') (architecture.py:254-259 -> block.py:278-291): forward, input gradient, weight-gradient digests."""
     import models.modules.architecture as arch
@@ -506,7 +534,7 @@ def gen_F12():
     np.savez_compressed(os.path.join(GOLDEN, 'callers_dual.npz'), **out)
 
 
-ALL = {'F12': gen_F12, 'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10, 'F11': gen_F11}
+ALL = {'F12': gen_F12, 'F1': gen_F1, 'F2': gen_F2, 'F3': gen_F3, 'F4': gen_F4, 'F5': gen_F5, 'F6': gen_F6, 'F7': gen_F7, 'F8': gen_F8, 'F9': gen_F9, 'F10': gen_F10, 'F11': gen_F11, 'F13': gen_F13}
 
 if __name__ == '__main__':
     _refshim.install()

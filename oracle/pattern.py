@@ -29,14 +29,14 @@ def rrdb_node(t):
     raise LookupError('no generator node behind this tensor')
 
 
-def stored_lrelu_outputs(bufs, nb):
+def stored_lrelu_outputs(bufs, nb, nf=64):
     """The HIP forward's stored LeakyReLU outputs (fp32 NCHW on the CPU) in the ORACLE's call order of rrdb_oracle._lrelu: convs 0-3 of every
-    RDB, the upconvs, HR_conv0.  `bufs`: RRDBEngine.run_forward(..., keep=True)[1]."""
+    RDB, the upconvs, HR_conv0.  `bufs`: RRDBEngine.run_forward(..., keep=True)[1]; nf: the generator's stream width."""
     out = []
     for j in range(3 * nb):
         for i in range(4):
-            out.append(bufs['rdb'][j].to_nchw(32, cg0=8 + 4 * i).cpu())
-    return out + [b.to_nchw(64).cpu() for b in bufs['ups']] + [bufs['hr0'].to_nchw(64).cpu()]
+            out.append(bufs['rdb'][j].to_nchw(32, cg0=nf // 8 + 4 * i).cpu())
+    return out + [b.to_nchw(nf).cpu() for b in bufs['ups']] + [bufs['hr0'].to_nchw(nf).cpu()]
 
 
 class capture_preactivations:

@@ -118,9 +118,9 @@ F4_CASES = [('nb1_x4', 1, 4, 0), ('nb3_x4', 3, 4, 0), ('nb1_x8', 1, 8, 0), ('nb1
             ('nb1_x4_lat3', 1, 4, 3), ('nb2_x4_lat3', 2, 4, 3), ('nb1_x2_lat1', 1, 2, 1)]
 
 
-def _rrdb(nb, sf, lat):
+def _rrdb(nb, sf, lat, nf=64):
     import models.modules.architecture as arch
-    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA',
+    net = arch.RRDBNet(in_nc=3, out_nc=3, nf=nf, nb=nb, gc=32, upscale=sf, norm_type=None, act_type='leakyrelu', mode='CNA',
                        upsample_mode='upconv', latent_input='all_layers_HR_downscaled' if lat else None, num_latent_channels=lat)
     fill_formula_weights(net, gain=1.0)
     return net
@@ -408,6 +408,68 @@ def test_pixelshuffle_generator_matches_oracle(sf, lat, prec):
     else:       # fp16 data gradient of 'mixed': bulk within 2e-3 of the gradient's rms (its own tests: tests/test_gpu_backward.py, mixed section)
         gg, rr = xg.grad.cpu().numpy().astype(np.float64), xc.grad.numpy().astype(np.float64)
         assert np.median(np.abs(gg - rr)) / np.sqrt((rr ** 2).mean()) < 2e-3 and rel_l2(gg, rr) < 5e-2
+
+
+# ---- other stream widths (round 6): nf = 16 / 32 / 48 generators against fixtures generated from the reference (F13), split precision
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+
+
+@pytest.mark.parametrize('name,nf,nb,sf,lat', NF_CASES, ids=[c[0] for c in NF_CASES])
+def test_other_stream_widths_match_reference_golden(name, nf, nb, sf, lat):
+    """RRDBNet(nf != 64) (reference architecture.py:228-230): the same launch plan over (nf / 8)-group streams and (nf / 8 + 16)-group dense-block
+    buffers.  Forward (split and mixed), input gradient (robust metric: the reference's forward took its own activation pattern), every weight /
+    bias gradient against the reference's digests, a replayed second step equal to the first bit for bit — and the forced-pattern fp64 check at
+    the plain 1e-3 bar."""
+    from oracle import pattern as PT
+    g = load('rrdb_nf.npz')
+    net = _rrdb(nb, sf, lat, nf=nf)
+    assert sum(p.numel() for p in net.parameters()) == int(g[name + '/nparams'][1])
+    net = net.to(DEV)
+    x0 = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 131 + nf + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+    if lat:
+        x0[:, -3:] = x0[:, -3:] * 0.5 + 0.5
+    cot = seeded_uniform(tuple(g[name + '/out'].shape), 141 + nf + nb + sf + lat, -1.0, 1.0)
+    net.set_precision('mixed')
+    with torch.no_grad():
+        ym = net(x0.to(DEV)).cpu().numpy()
+    assert rel_l2(ym, g[name + '/out']) < 3e-4, rel_l2(ym, g[name + '/out'])
+    net.set_precision('split')
+    runs = []
+    for it in range(2):
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().to(DEV).requires_grad_(True)
+        y = net(x)
+        (y * cot.to(DEV)).sum().backward()
+        runs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+        del y
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    y, dx, _ = runs[1]
+    assert rel_l2(y.cpu().numpy(), g[name + '/out']) < 1e-4 and rel_max(y.cpu().numpy(), g[name + '/out']) < 3e-4
+    assert_grad_close(dx.cpu().numpy(), g[name + '/dx'], name)
+    dig, bad = g[name + '/dparams'], []
+    for j, (k, p) in enumerate(net.named_parameters()):
+        f = p.grad.detach().cpu().reshape(-1).double()
+        idx = torch.linspace(0, f.numel() - 1, steps=24).long()
+        if abs(float(f.norm()) - dig[j][1]) > 2e-2 * max(dig[j][1], 1e-6):
+            bad.append((k, 'norm', float(f.norm()), dig[j][1]))
+        scale = max(dig[j][1] / np.sqrt(f.numel()), 1e-6)
+        if np.abs(f[idx].numpy() - dig[j][2:]).max() > 0.2 * scale + 1e-6:
+            bad.append((k, 'samples', float(np.abs(f[idx].numpy() - dig[j][2:]).max() / scale)))
+    assert not bad, bad[:5]
+    # the GPU's activation pattern forced on the fp64 oracle: arithmetic error alone, plain relative L2
+    eng = net.engine
+    gg, bufs = eng.run_forward(x0.to(DEV), pad=0, keep=True)
+    dxe, grads = eng.run_backward(tuple(x0.shape), 0, bufs, cot.to(DEV), need_dx=True, need_dw=True)
+    stored = PT.stored_lrelu_outputs(bufs, nb, nf=nf)
+    sd64 = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    xg = x0.double().clone().requires_grad_(True)
+    with PT.forced_pattern(stored):
+        (ro.rrdb_forward(params, xg, nb, sf, lat) * cot.double()).sum().backward()
+    assert rel_l2(dxe.cpu().numpy(), xg.grad.numpy()) < 1e-3
+    for k, p in net.named_parameters():
+        assert rel_l2(grads[p].cpu().numpy(), params[k].grad.numpy()) < 1e-3, k
 
 
 # ---- the sign-flip statement, tested: with the activation pattern the GPU forward actually took, the HIP backward is the exact adjoint

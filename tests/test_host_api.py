@@ -304,9 +304,11 @@ def test_unsupported_generator_configurations_fail_loudly():
     import models.modules.architecture as arch
     base = dict(in_nc=3, out_nc=3, nf=64, nb=1, upscale=4, num_latent_channels=0)
     arch.RRDBNet(**base)
-    for bad in (dict(norm_type='batch'), dict(act_type='relu'), dict(mode='NAC'), dict(nf=32), dict(upsample_mode='nearest')):
+    for bad in (dict(norm_type='batch'), dict(act_type='relu'), dict(mode='NAC'), dict(nf=128), dict(nf=36), dict(nf=24), dict(nf=32, upsample_mode='pixelshuffle'),
+                dict(upsample_mode='nearest')):
         with pytest.raises(NotImplementedError):
             arch.RRDBNet(**dict(base, **bad))
+    assert arch.RRDBNet(**dict(base, nf=32)).nf == 32          # 16, 32, 48, 64 (round 6)
     net = arch.RRDBNet(**dict(base, upsample_mode='pixelshuffle'))          # constructible (state_dict parity), not executable
     with pytest.raises(Exception):
         net(torch.zeros(1, 3, 8, 8))

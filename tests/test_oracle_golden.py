@@ -96,23 +96,23 @@ def formula_state_dict(keys, shapes, gain=1.0):
     return sd
 
 
-def rrdb_keys(nb, sf, lat, prefix='model'):
+def rrdb_keys(nb, sf, lat, prefix='model', nf=64):
     """state_dict keys/shapes of RRDBNet in reference order."""
     keys, shapes = [], []
 
     def add(k, cout, cin):
         keys.extend([k + '.weight', k + '.bias']); shapes.extend([(cout, cin, 3, 3), (cout,)])
-    add(prefix + '.0', 64, 3 + lat)
+    add(prefix + '.0', nf, 3 + lat)
     for r in range(nb):
         for d in (1, 2, 3):
             for i in range(5):
-                add('%s.1.sub.%d.RDB%d.convs.%d.0' % (prefix, r, d, i), 32 if i < 4 else 64, 64 + 32 * i + lat)
-    add('%s.1.sub.%d' % (prefix, nb), 64, 64 + lat)
+                add('%s.1.sub.%d.RDB%d.convs.%d.0' % (prefix, r, d, i), 32 if i < 4 else nf, nf + 32 * i + lat)
+    add('%s.1.sub.%d' % (prefix, nb), nf, nf + lat)
     idx = 2
     for _ in range(1 if sf == 3 else int(np.log2(sf))):
-        add('%s.%d.1' % (prefix, idx), 64, 64); idx += 1
-    add('%s.%d' % (prefix, idx), 64, 64 + lat)
-    add('%s.%d' % (prefix, idx + 2), 3, 64 + lat)
+        add('%s.%d.1' % (prefix, idx), nf, nf); idx += 1
+    add('%s.%d' % (prefix, idx), nf, nf + lat)
+    add('%s.%d' % (prefix, idx + 2), 3, nf + lat)
     return keys, shapes
 
 
@@ -140,6 +140,41 @@ def test_rrdb_fwd_bwd_matches_reference(name, nb, sf, lat):
     y = ro.rrdb_forward(sd, x, nb, sf, lat)
     assert rel_l2(y.detach().numpy(), g[name + '/out']) < 2e-6
     cot = seeded_uniform(tuple(y.shape), 41 + nb + sf + lat, -1.0, 1.0)
+    (y * cot).sum().backward()
+    assert rel_l2(x.grad.numpy(), g[name + '/dx']) < 5e-6
+    dig = g[name + '/dparams']
+    for j, k in enumerate(keys):
+        f = sd[k].grad.reshape(-1).double()
+        idx = torch.linspace(0, f.numel() - 1, steps=24).long()
+        mine = np.concatenate([[float(f.sum()), float(f.norm())], f[idx].numpy()])
+        assert abs(mine[1] - dig[j][1]) <= 1e-5 * max(dig[j][1], 1e-6), k
+        np.testing.assert_allclose(mine[2:], dig[j][2:], atol=2e-5 * max(dig[j][1] / np.sqrt(f.numel()), 1e-6) + 1e-6, err_msg=k)
+
+
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+
+
+def nf_input(nf, nb, sf, lat):
+    x = seeded_uniform((1, 3 + lat * sf * sf, 12, 16), 131 + nf + nb + sf + lat, -1.0 if lat else 0.0, 1.0)
+    if lat:
+        x[:, -3:] = x[:, -3:] * 0.5 + 0.5
+    return x
+
+
+@pytest.mark.parametrize('name,nf,nb,sf,lat', NF_CASES, ids=[c[0] for c in NF_CASES])
+def test_rrdb_with_other_stream_widths_matches_reference(name, nf, nb, sf, lat):
+    """F13: the reference's RRDBNet takes any nf (architecture.py:228-230; growth channels stay 32): forward, dx and weight-gradient digests of
+    nf = 16 / 32 / 48 generators generated from the reference itself, against the oracle."""
+    g = load('rrdb_nf.npz')
+    keys, shapes = rrdb_keys(nb, sf, lat, nf=nf)
+    sd = formula_state_dict(keys, shapes)
+    assert int(g[name + '/nparams'][1]) == sum(int(np.prod(s)) for s in shapes)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = nf_input(nf, nb, sf, lat).requires_grad_(True)
+    y = ro.rrdb_forward(sd, x, nb, sf, lat)
+    assert rel_l2(y.detach().numpy(), g[name + '/out']) < 2e-6
+    cot = seeded_uniform(tuple(y.shape), 141 + nf + nb + sf + lat, -1.0, 1.0)
     (y * cot).sum().backward()
     assert rel_l2(x.grad.numpy(), g[name + '/dx']) < 5e-6
     dig = g[name + '/dparams']
