@@ -353,6 +353,68 @@ class PackedConv:
         return self
 
 
+class PackedConvSlices:
+    """Forward pack of a conv with MORE than 64 output channels (a multiple of 64): one 64-row pack per output slice, back to back in one buffer
+    — the layout esr_conv3x3 takes for cout > 64 (output slices of one launch, include/esr_hip.h); the bias is the parameter itself, indexed by
+    absolute channel.  Same duck type as PackedConv for the engine's batched re-pack (prepare / jobs / weights / after_pack)."""
+
+    def __init__(self, weight, bias, lat, split=True):
+        assert weight.shape[0] % 64 == 0 and weight.shape[0] > 64
+        self.weight, self.bias_p, self.lat, self.split, self.transposed = weight, bias, lat, split, False
+        self.parts = [PackedConv(weight, None, lat, split=split, rows=list(range(64 * s, 64 * s + 64))) for s in range(weight.shape[0] // 64)]
+        self._key, self.wpack, self.bias = None, None, None
+
+    def weights(self):
+        return (self.weight,)
+
+    def key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, None if self.bias_p is None else (self.bias_p.data_ptr(), self.bias_p._version))
+
+    def stale(self):
+        return self.key() != self._key
+
+    def prepare(self):
+        if self.wpack is None:
+            w = self.weight
+            require_gpu(w, 'conv weight')
+            ncg_in = (1 if self.lat else 0) + (w.shape[1] - self.lat + 7) // 8
+            per = _lib.lib.esr_conv_wpack_bytes(ncg_in, 64, fmt_code(self.split))
+            self.wpack = torch.empty(len(self.parts) * per, dtype=torch.uint8, device=w.device)
+            for s, pk in enumerate(self.parts):
+                pk.wpack = self.wpack[s * per:(s + 1) * per]
+                pk.prepare()
+                assert pk.ncg_in == ncg_in
+            bp = self.bias_p
+            if bp is not None and bp.dtype == torch.float32 and bp.is_contiguous():
+                self.bias, self._bias_shared = bp.detach(), True
+            else:
+                self.bias, self._bias_shared = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device), False
+        return self
+
+    def jobs(self):
+        return [j for pk in self.parts for j in pk.jobs()]
+
+    @property
+    def needs_after_pack(self):
+        return not (self.bias_p is None or self._bias_shared)
+
+    def after_pack(self):
+        if self.bias_p is not None and not self._bias_shared:
+            self.bias.copy_(self.bias_p.detach().float())
+        if self._bias_shared and self.bias.data_ptr() != self.bias_p.data_ptr():
+            self.bias = self.bias_p.detach()
+        self._key = self.key()
+
+    def get(self):
+        if not self.stale():
+            return self
+        self.prepare()
+        run_pack_jobs(self.jobs(), self.split)
+        self.after_pack()
+        return self
+
+
 def run_pack_jobs(jobs, split):
     for wd, kmap, ncg_in, mmap, mtiles, transposed, scale, dst in jobs:
         check(_lib.lib.esr_pack_conv_weights(wd.data_ptr(), wd.shape[0], wd.shape[1], kmap.data_ptr(), ncg_in, mmap.data_ptr(), mtiles,

@@ -256,6 +256,8 @@ class RRDBEngine:
                 if name.startswith('up') and self._pshuf:
                     for q in range(self._pshuf ** 2):         # 64 * r^2 conv channels = r^2 launches of 64 rows
                         d[name, q] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name), rows=self._ps_rows(q))
+                elif c.weight.shape[0] > 64:                  # nf = 128, 192, ...: output slices of one launch
+                    d[name] = A.PackedConvSlices(c.weight, c.bias, lat, split=self._wfmt(name))
                 else:
                     d[name] = A.PackedConv(c.weight, c.bias, lat, split=self._wfmt(name))
             self._packed = d
@@ -288,7 +290,7 @@ class RRDBEngine:
         """Data-gradient packs of the dense blocks in "mirrored" form.  With the gradients of an RDB's five conv outputs stored as
         G' = [dy conv4 (8 groups) | dy conv3 (4) | dy conv2 | dy conv1 | dy conv0], the gradient of block c+1 (the output of conv c) is
         ONE conv over the first 8 + 4(3-c) groups of G' — sum_{i>c} W_i^T[rows of block c+1] * dy_i — masked by LeakyReLU', written
-        right behind them; the gradient of the RDB input is one conv over all 24 groups.  Per RDB: 'g3'..'g0' (32 rows), 'gx' (64 rows),
+        right behind them; the gradient of the RDB input is one conv over all 24 groups.  Per RDB: 'g3'..'g0' (32 rows), 'gx0' [, 'gx1' ...] (64 rows each),
         'gz' (latent rows).  conv4's 0.2 (and the RRDB's 0.2 for the third RDB) is folded into its piece of every pack."""
         if self._packed_rdb_t is None:
             d = {}
@@ -304,7 +306,8 @@ class RRDBEngine:
                     for c in (3, 2, 1, 0):
                         rows = list(range(lat + nf + 32 * c, lat + nf + 32 + 32 * c))
                         d[name, 'g%d' % c] = A.PackedSum(pieces[:4 - c], [rows] * (4 - c), split=self._bwd_wfmt(True))
-                    d[name, 'gx'] = A.PackedSum(pieces, [list(range(lat, lat + nf))] * 5, split=self._bwd_wfmt(True))
+                    for j in range((nf + 63) // 64):       # the gradient of the block input: 64 rows per launch
+                        d[name, 'gx%d' % j] = A.PackedSum(pieces, [list(range(lat + 64 * j, lat + min(nf, 64 * j + 64)))] * 5, split=self._bwd_wfmt(True))
                     if lat:
                         d[name, 'gz'] = A.PackedSum(pieces, [list(range(lat))] * 5, split=self._bwd_wfmt(True))
             self._packed_rdb_t = d
@@ -726,8 +729,10 @@ class RRDBEngine:
                 # written where the next RDB in backward order expects its dy_out
                 n += 1
                 G_next = gbuf(n) if n < nseq else galloc(B, ng, h, w)
-                kw = dict(res2=G_rrdb.view(0, ng), beta2=1.0) if k == 0 else {}
-                conv(pr[name, 'gx'], G.view(0, nd), B, h, w, nf, out=G_next.view(0, ng), use_bias=False, res1=G.view(0, ng), beta1=s_out, **kw, **hi_only)
+                for j in range((nf + 63) // 64):
+                    g_lo, g_n = 8 * j, min(ng - 8 * j, 8)
+                    kw = dict(res2=G_rrdb.view(g_lo, g_n), beta2=1.0) if k == 0 else {}
+                    conv(pr[name, 'gx%d' % j], G.view(0, nd), B, h, w, 8 * g_n, out=G_next.view(g_lo, g_n), use_bias=False, res1=G.view(g_lo, g_n), beta1=s_out, **kw, **hi_only)
                 G_cur = G_next
             if f16_bwd and self.grad_renorm:
                 # d(input of RRDB r) is complete and not yet recorded anywhere: renormalise it (and the latent gradient accumulated so far)

@@ -41,15 +41,13 @@ class RRDBNet(nn.Module):
         if act_type != 'leakyrelu' or mode != 'CNA':
             # the fused kernels implement conv -> LeakyReLU(0.2) (what define_G hard-wires, networks.py:97-99) and nothing else
             raise NotImplementedError("RRDBNet(act_type=%r, mode=%r): the HIP engine implements act_type='leakyrelu', mode='CNA' only" % (act_type, mode))
-        if nf < 16 or nf > 64 or nf % 16 or out_nc < 1 or in_nc < 1 or (upsample_mode == 'pixelshuffle' and nf != 64):
+        if nf < 16 or nf % 16 or (nf > 64 and nf % 64) or out_nc < 1 or in_nc < 1 or (upsample_mode == 'pixelshuffle' and nf != 64):
             # The residual stream is nf / 8 channel groups of the activation layout, a dense block ONE (nf / 8 + 16)-group buffer; nf = 16, 32, 48, 64
-            # run the same launch plan (round 6; reference architecture.py:228-230 takes any nf, every options file it ships uses 64).  Multiples
-            # of 16: a K chunk of the MFMA contraction is two channel groups, and the mirrored data gradient concatenates the layers' gradients
-            # chunk by chunk.
-            # Wider streams are not a one-line generalisation: a conv launch produces at most 64 output channels unless it takes the output-slice
-            # form, which has no residual-from-LDS epilogue, and the mirrored data gradient packs at most 64 rows per launch; the pixel-shuffle
-            # store orders its rows in blocks of 64 channels.
-            raise NotImplementedError("RRDBNet(nf=%r, upsample_mode=%r): the HIP engine runs nf = 16, 32, 48, 64 (the reference's options files use 64; "
+            # and 128, 192, ... run the same launch plan (round 6; reference architecture.py:228-230 takes any nf, every options file it ships uses
+            # 64).  Multiples of 16: a K chunk of the MFMA contraction is two channel groups, and the mirrored data gradient concatenates the layers'
+            # gradients chunk by chunk.  Above 64: multiples of 64 — a launch produces its output in 64-channel slices (esr_conv3x3_desc.cout > 64).
+            # The pixel-shuffle store orders its rows in blocks of 64 channels: nf = 64 only.
+            raise NotImplementedError("RRDBNet(nf=%r, upsample_mode=%r): the HIP engine runs nf = 16, 32, 48, 64, 128, 192, ... (the reference's options files use 64; "
                                       "gc is 32 — the reference ignores the argument too); pixel-shuffle upsamplers nf = 64 only" % (nf, upsample_mode))
 
         fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, return_module_list=True)

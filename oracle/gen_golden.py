@@ -200,7 +200,8 @@ def gen_F8():
     np.savez_compressed(os.path.join(GOLDEN, 'rrdb_first_layer.npz'), **out)
 
 
-NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1),
+            ('nf128_nb1_x4_lat3', 128, 1, 4, 3), ('nf128_nb1_x2', 128, 1, 2, 0)]
 
 
 def gen_F13():

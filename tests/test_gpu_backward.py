@@ -411,7 +411,8 @@ def test_pixelshuffle_generator_matches_oracle(sf, lat, prec):
 
 
 # ---- other stream widths (round 6): nf = 16 / 32 / 48 generators against fixtures generated from the reference (F13), split precision
-NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1),
+            ('nf128_nb1_x4_lat3', 128, 1, 4, 3), ('nf128_nb1_x2', 128, 1, 2, 0)]
 
 
 @pytest.mark.parametrize('name,nf,nb,sf,lat', NF_CASES, ids=[c[0] for c in NF_CASES])

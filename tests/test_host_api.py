@@ -304,7 +304,7 @@ def test_unsupported_generator_configurations_fail_loudly():
     import models.modules.architecture as arch
     base = dict(in_nc=3, out_nc=3, nf=64, nb=1, upscale=4, num_latent_channels=0)
     arch.RRDBNet(**base)
-    for bad in (dict(norm_type='batch'), dict(act_type='relu'), dict(mode='NAC'), dict(nf=128), dict(nf=36), dict(nf=24), dict(nf=32, upsample_mode='pixelshuffle'),
+    for bad in (dict(norm_type='batch'), dict(act_type='relu'), dict(mode='NAC'), dict(nf=96), dict(nf=36), dict(nf=24), dict(nf=32, upsample_mode='pixelshuffle'),
                 dict(upsample_mode='nearest')):
         with pytest.raises(NotImplementedError):
             arch.RRDBNet(**dict(base, **bad))

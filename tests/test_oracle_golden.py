@@ -151,7 +151,8 @@ def test_rrdb_fwd_bwd_matches_reference(name, nb, sf, lat):
         np.testing.assert_allclose(mine[2:], dig[j][2:], atol=2e-5 * max(dig[j][1] / np.sqrt(f.numel()), 1e-6) + 1e-6, err_msg=k)
 
 
-NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1)]
+NF_CASES = [('nf32_nb2_x4', 32, 2, 4, 0), ('nf32_nb1_x4_lat3', 32, 1, 4, 3), ('nf48_nb1_x2', 48, 1, 2, 0), ('nf16_nb1_x4_lat1', 16, 1, 4, 1),
+            ('nf128_nb1_x4_lat3', 128, 1, 4, 3), ('nf128_nb1_x2', 128, 1, 2, 0)]
 
 
 def nf_input(nf, nb, sf, lat):
