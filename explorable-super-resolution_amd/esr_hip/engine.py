@@ -398,7 +398,7 @@ class RRDBEngine:
     def _plan_key(self, kind, *what):
         # a forward list points into the forward packs only: creating the data-gradient packs later (first backward) leaves it valid
         packs = self._pack_gen[0] if kind == 'fwd' else tuple(self._pack_gen)
-        return (kind,) + what + (self.split, self._ptr_epoch, packs)
+        return (kind,) + what + (self.split, self._ptr_epoch, packs, A.LDS_STAGES)      # (the scheduling hint is part of every recorded descriptor)
 
     @A.one_stream
     def run_forward(self, x, pad=0, keep=False):
