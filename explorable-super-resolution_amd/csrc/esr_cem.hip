@@ -16,6 +16,9 @@
 
 namespace {
 
+// wave-streaming separable kernels on (the shipping behaviour); the instrumented build can switch them off for A/B runs (esr_debug_cem_wave)
+bool g_cem_wave = true;
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Workgroup -> (tile column, tile row, image plane) for the tiled kernels.  Workgroups are dispatched in linear order (x fastest), round-robin
@@ -846,6 +849,278 @@ __global__ __launch_bounds__(256) void cem_upscale_sep_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Wave-streaming separable kernels (round 6).  The tile kernels above spend ~1100 (downscale) and ~100 (upscale) vector instructions per output
+// pixel — staging index arithmetic, one LDS read per multiply-add — and sit at 74 % of the chip's VALU issue slots while moving 1.9-2.9 TB/s
+// (profiles/r06_cem_pmc.json): bound by their own instruction stream, not by HBM.  Here a WAVE owns a strip of the image and walks down its rows
+// with everything that depends on the column formed once: no workgroup barrier, no per-row index arithmetic, the vertical pass in registers.
+//
+// Downscale: lane l holds 4 adjacent window columns (one aligned 16-byte load per high-resolution row).  A window row sf m + ph feeds output rows
+// m - t with tap sf t + ph (t < NA = ceil(k / sf)): NA running sums per column, the oldest one complete at the end of every block of sf rows — it is
+// shifted out, passed through this wave's LDS image (de-interleaved by phase: the horizontal pass reads consecutive words), and lane j < ncol
+// finishes output column j with k multiply-adds.  Taps are padded with zeros to NA sf entries so that every LDS offset and tap index of the unrolled
+// loops is an immediate.  Same index rules as the tile kernels (clamped window = replicate padding, strided pick at `pre`, fused  lr_pad - D(y)).
+// Sums run in tap order in ONE accumulator per pass (the tile kernels use four / two partial sums): results agree to fp32 rounding, not to the bit.
+constexpr int WV_LANES = 64;
+template <int SFT, int NA>
+__global__ __launch_bounds__(256) void cem_downscale_wave_kernel(const float* __restrict__ y, int h, int w, int pre, const float* __restrict__ tv,
+                                                               const float* __restrict__ th, int k, const float* __restrict__ lr, int lr_pad,
+                                                               float* __restrict__ d, int nout, int R, int nct, int nst, long long nitems) {
+    constexpr int sf = SFT, NT = NA * SFT;
+    constexpr int QP = (256 / SFT + 1) > (WV_LANES + NA) ? (256 / SFT + 1) : (WV_LANES + NA);      // words per phase plane of a wave's row image
+    __shared__ float rows_lds[4][SFT * QP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* const L = rows_lds[wv];
+    // strips in (plane, column tile, row strip) order, four consecutive ones per workgroup; XCD x (workgroups g with g & 7 == x) sweeps a contiguous run
+    const unsigned nwg = gridDim.x, g = blockIdx.x, xcd = g & 7, q = nwg >> 3, rr = nwg & 7;
+    const long long item = (long long)(xcd * q + (xcd < rr ? xcd : rr) + (g >> 3)) * 4 + wv;
+    if (item >= nitems) return;
+    const int st = (int)(item % nst);
+    const long long t2 = item / nst;
+    const int ct = (int)(t2 % nct);
+    const long long bc = t2 / nct;
+    const int p = k / 2, Hh = h * sf, Wh = w * sf;
+    const int j0 = ct * nout, i0 = st * R;
+    const int nrow = min(R, h - i0), ncol = min(nout, w - j0);
+    const int Yb = sf * i0 + pre - p, Xb = sf * j0 + pre - p;
+    const int Xa = (Xb >> 2) << 2, off = Xb - Xa;             // the lane's vector starts at a multiple of 4: window column c = 4 lane + t - off
+    const int cols = (ncol - 1) * sf + k;                     // window columns this strip needs
+    const float* const src = y + bc * Hh * (long long)Wh;
+    const int x = Xa + 4 * lane;
+    const bool need = 4 * lane - off < cols && 4 * lane + 3 - off >= 0;
+    const bool fast = (Wh & 3) == 0 && (((size_t)src) & 15) == 0 && x >= 0 && x + 3 < Wh;
+    int xc[4], slot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        xc[t] = clampi(x + t, 0, Wh - 1);
+        const int c = 4 * lane + t - off;
+        slot[t] = (c >= 0 && c < cols) ? (c % sf) * QP + c / sf : -1;
+    }
+    float tvv[NT], thv[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) { tvv[a] = a < k ? tv[a] : 0.f; thv[a] = a < k ? th[a] : 0.f; }
+    // (the zero taps of the padded horizontal pass multiply image words past the strip's last window column: they have to be finite)
+    for (int e = lane; e < SFT * QP; e += 64) L[e] = 0.f;
+    const int nwin = (nrow - 1) * sf + k;                     // window rows of the strip
+    const int nblk = nrow + NA - 1;                           // blocks of sf window rows (the last ones past nwin: zeros)
+    float acc[NA][4];
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+    float4 cur[SFT], nxt[SFT];
+    auto load_blk = [&](float4 (&dst)[SFT], const int m) {
+#pragma unroll
+        for (int ph = 0; ph < sf; ++ph) {
+            const int wr = sf * m + ph;
+            dst[ph] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wr < nwin && need) {
+                const float* const rowp = src + (long long)clampi(Yb + wr, 0, Hh - 1) * Wh;
+                if (fast) dst[ph] = *(const float4*)(rowp + x);
+                else dst[ph] = make_float4(rowp[xc[0]], rowp[xc[1]], rowp[xc[2]], rowp[xc[3]]);
+            }
+        }
+    };
+    const int h0 = h - 2 * lr_pad, w0 = w - 2 * lr_pad;
+    load_blk(cur, 0);
+    for (int m = 0; m < nblk; ++m) {
+        if (m + 1 < nblk) load_blk(nxt, m + 1);               // the next block's rows are in flight under this block's arithmetic
+#pragma unroll
+        for (int ph = 0; ph < sf; ++ph) {
+            const float v[4] = {cur[ph].x, cur[ph].y, cur[ph].z, cur[ph].w};
+#pragma unroll
+            for (int t = 0; t < NA; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][c] = fmaf(tvv[sf * t + ph], v[c], acc[t][c]);
+        }
+        const int il = m - (NA - 1);                          // the output row whose last window row was in this block
+        if (il >= 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (slot[c] >= 0) L[slot[c]] = acc[NA - 1][c];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a wave's LDS operations execute in order: written, then read, by the same wave)
+            if (lane < ncol) {
+                float o = 0.f;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) o = fmaf(thv[b], L[(b % sf) * QP + lane + b / sf], o);
+                const int i = i0 + il, j = j0 + lane;
+                if (lr) o = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - o;
+                d[(bc * h + i) * (long long)w + j] = o;
+            }
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int t = NA - 1; t > 0; --t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][c] = acc[t - 1][c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[0][c] = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < sf; ++ph) cur[ph] = nxt[ph];
+    }
+}
+
+// Upscale (polyphase, zero-stuffed samples at sf i + pre, pre > 0): lane l owns 4 adjacent OUTPUT columns — one 16-byte load of g and one 16-byte store
+// per output row — and, for the vertical pass, low-resolution column jb + l (and jb + 64 + l where the wave's 256 output columns reach that far).
+//   vertical pass   output rows are walked in blocks of sf rows aligned to the sample grid: row r of a block uses the taps sf t (r = 0) or
+//                   sf - r + sf t (r > 0) on NA consecutive sample rows — a window of NA + 1 sample values per lane in registers, one new value per block
+//                   (requested a block ahead); the pass-1 value of every sample column goes to this wave's LDS row;
+//   horizontal pass per lane, once: which NV = NA + 1 consecutive pass-1 values its four columns meet and, per column, the NV taps that go with them
+//                   (zeros where a column's taps start one sample later or end at k); per row NV LDS reads and 4 NV multiply-adds, g added, stored.
+// No workgroup barrier, no index arithmetic per row.  Modes and index rules as cem_upscale_sep_kernel; sums in tap order in one accumulator per pass
+// (the tile kernel's order as well).
+template <bool TWO, int SFT, int NA>
+__global__ __launch_bounds__(256) void cem_upscale_wave_kernel(const float* __restrict__ f, const float* __restrict__ f2, int h, int w, int pre,
+                                                             const float* __restrict__ tv, const float* __restrict__ th, int k, const float* __restrict__ g,
+                                                             int crop, int mode, float range, float* __restrict__ out, float* __restrict__ out2, int S, int tcols,
+                                                             int nct, int nst, long long nitems) {
+    constexpr int sf = SFT, NV = NA + 1, NIN = TWO ? 2 : 1;
+    constexpr int NT1 = 252 / SFT + NV + 2;                   // pass-1 values a wave's 256 output columns can meet
+    constexpr int NP = (NT1 + 63) / 64;                       // vertical passes per row (sample columns per lane)
+    __shared__ float t_lds[4][NIN][NP * 64 + 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned nwg = gridDim.x, gi = blockIdx.x, xcd = gi & 7, q = nwg >> 3, rr = nwg & 7;
+    const long long item = (long long)(xcd * q + (xcd < rr ? xcd : rr) + (gi >> 3)) * 4 + wv;
+    if (item >= nitems) return;
+    const int st = (int)(item % nst);
+    const long long t2 = item / nst;
+    const int ct = (int)(t2 % nct);
+    const long long bc = t2 / nct;
+    const int p = k / 2, Hh = h * sf, Wh = w * sf, Ho = Hh - 2 * crop, Wo = Wh - 2 * crop;
+    const int xo0 = ct * tcols, yq0 = st * S;
+    const int nrows = min(S, Ho - yq0);
+    const int xo = xo0 + 4 * lane;
+    const bool live = 4 * lane < tcols && xo < Wo;             // this lane stores something
+    auto cdiv = [](const int a, const int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };      // ceil(a / b), b > 0
+    // sample column met by the first tap of output column X that lands on a sample: ceil((X - p - pre) / sf)
+    const int jb = cdiv(xo0 + crop - p - pre, sf);
+    const int X0 = xo + crop;
+    const int base = cdiv(X0 - p - pre, sf) - jb;             // first pass-1 value of this lane's columns, relative to the wave's first
+    float tq[4][NV];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int X = X0 + t;
+        int b0 = (pre + p - X) % sf; if (b0 < 0) b0 += sf;
+        const int dt = cdiv(X - p - pre, sf) - jb - base;     // 0 or 1
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int u = v - dt, b = b0 + sf * u;
+            tq[t][v] = (u >= 0 && b < k && live) ? th[b < k ? (b >= 0 ? b : 0) : 0] : 0.f;
+        }
+    }
+    // vertical taps per row of a block (uniform): tvr[r][t]
+    float tvr[SFT][NA];
+#pragma unroll
+    for (int r = 0; r < sf; ++r)
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int a = (r == 0 ? 0 : sf - r) + sf * t;
+            tvr[r][t] = a < k ? tv[a] : 0.f;
+        }
+    const float* const s1 = f + bc * h * (long long)w;
+    const float* const s2 = TWO ? f2 + bc * h * (long long)w : nullptr;
+    const int Y0 = yq0 + crop;                                // first output row of the strip, un-cropped coordinates
+    int ph0 = (Y0 - p - pre) % sf; if (ph0 < 0) ph0 += sf;
+    int Yblk = Y0 - ph0;                                      // block start: Yblk = p + pre (mod sf)
+    int ibb = (Yblk - p - pre) / sf;                          // (exact; may be negative)
+    const int nblk = (Y0 + nrows - Yblk + sf - 1) / sf;
+    // sample window: e[in][pass][0 .. NA] = rows ibb .. ibb + NA of this lane's sample column(s); e[..][NA + 1] = the next block's new row
+    float e[NIN][NP][NA + 2];
+    int jcol[NP];
+    bool jok[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) { jcol[pp] = jb + lane + 64 * pp; jok[pp] = jcol[pp] >= 0 && jcol[pp] < w && lane + 64 * pp < NT1; }
+    auto sample = [&](const int in, const int pp, const int i) -> float {
+        if (!jok[pp] || i < 0 || i >= h) return 0.f;
+        return (in ? s2 : s1)[(long long)i * w + jcol[pp]];
+    };
+#pragma unroll
+    for (int in = 0; in < NIN; ++in)
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int v = 0; v < NA + 1; ++v) e[in][pp][v] = sample(in, pp, ibb + v);
+    const bool gvec = mode >= 1 && live && xo + 3 < Wo && (Wh & 3) == 0 && (((size_t)(g + bc * Hh * (long long)Wh + X0)) & 15) == 0;
+    const bool ovec = live && xo + 3 < Wo && (Wo & 3) == 0 && (((size_t)(out + bc * Ho * (long long)Wo + xo)) & 15) == 0 &&
+                      (mode != 3 || (((size_t)(out2 + bc * Ho * (long long)Wo + xo)) & 15) == 0);
+    float* const T1 = t_lds[wv][0];
+    float* const T2 = t_lds[wv][NIN - 1];
+    for (int blk = 0; blk < nblk; ++blk, Yblk += sf, ++ibb) {
+        // next block's new sample row, and this block's rows of g: all requested before the arithmetic
+#pragma unroll
+        for (int in = 0; in < NIN; ++in)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) e[in][pp][NA + 1] = blk + 1 < nblk ? sample(in, pp, ibb + NA + 1) : 0.f;
+        float gv[SFT][4];
+#pragma unroll
+        for (int r = 0; r < sf; ++r) {
+            const int Y = Yblk + r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gv[r][t] = 0.f;
+            if (mode >= 1 && live && Y >= Y0 && Y < Y0 + nrows) {
+                const float* const gp = g + (bc * Hh + Y) * (long long)Wh + X0;
+                if (gvec) { const float4 t4 = *(const float4*)gp; gv[r][0] = t4.x; gv[r][1] = t4.y; gv[r][2] = t4.z; gv[r][3] = t4.w; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (xo + t < Wo) gv[r][t] = gp[t];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < sf; ++r) {
+            const int Y = Yblk + r;
+            if (Y < Y0 || Y >= Y0 + nrows) continue;          // (uniform)
+            // vertical pass: this row's value at every sample column of the wave
+#pragma unroll
+            for (int in = 0; in < NIN; ++in)
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NA; ++t) u = fmaf(tvr[r][t], e[in][pp][t + (r == 0 ? 0 : 1)], u);
+                    (in ? T2 : T1)[lane + 64 * pp] = u;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a wave's LDS operations execute in order)
+            if (live) {
+                float r1[NV], r2[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { r1[v] = T1[base + v]; r2[v] = TWO ? T2[base + v] : 0.f; }
+                float res[4], res2[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { u1 = fmaf(tq[t][v], r1[v], u1); if (TWO) u2 = fmaf(tq[t][v], r2[v], u2); }
+                    // (as selects, not as cem_upscale_sep_kernel's if-chain over two result arrays: hipcc 7.2 compiled that form of THIS kernel to a mode-3
+                    // `out` of stale register contents — found by the comparison with the tile kernel, tools/experiments/cem_wave_ab.py)
+                    const float gd = gv[r][t] - u2;                 // (modes 2 and 3; TWO only)
+                    res[t] = mode == 1 ? gv[r][t] + u1 : (mode == 2 ? u1 + tanhf(gd) * range : u1);
+                    res2[t] = gd;
+                }
+                const long long idx = (bc * Ho + (Y - crop)) * (long long)Wo + xo;
+                if (ovec) {
+                    *(float4*)(out + idx) = make_float4(res[0], res[1], res[2], res[3]);
+                    if (mode == 3) *(float4*)(out2 + idx) = make_float4(res2[0], res2[1], res2[2], res2[3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (xo + t < Wo) {
+                            out[idx + t] = res[t];
+                            if (mode == 3) out2[idx + t] = res2[t];
+                        }
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int in = 0; in < NIN; ++in)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                for (int v = 0; v < NA + 1; ++v) e[in][pp][v] = e[in][pp][v + 1];
+    }
+}
+
 }  // namespace
 
 extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k, const float* lr,
@@ -942,6 +1217,35 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
     if (lr && (h - 2 * lr_pad <= 0 || w - 2 * lr_pad <= 0 || lr_pad < 0)) return ESR_E_ARG;
     if ((long long)B * C > 65535) return ESR_E_UNSUPPORTED;
     {
+        // wave-streaming kernel (round 6): images large enough to give every CU several waves; chosen from the image geometry alone, so that a batch
+        // and its chunks run the same arithmetic
+        const int na = (k + sf - 1) / sf;
+        if (g_cem_wave && (sf == 2 || sf == 3 || sf == 4 || sf == 8) && na >= 4 && na <= 6 && (long long)h * w >= 4096) {
+            int nout = (252 - (k - 1)) / sf + 1;                // a lane's four columns start up to 3 columns left of the window
+            if (nout > WV_LANES) nout = WV_LANES;
+            const int nct = (w + nout - 1) / nout;
+            nout = (w + nct - 1) / nct;                         // equal tiles
+            // rows per strip: enough strips for ~12 waves per CU, at least 16 rows (a strip re-reads k - sf window rows of its upper neighbour)
+            const long long cols_total = (long long)B * C * nct;
+            int nst = (int)((3072 + cols_total - 1) / cols_total);
+            if (nst < 1) nst = 1;
+            int R = (h + nst - 1) / nst;
+            if (R < 16) R = 16;
+            if (R > h) R = h;
+            nst = (h + R - 1) / R;
+            const long long nitems = cols_total * nst;
+            const unsigned nwg = (unsigned)((nitems + 3) / 4);
+            typedef void (*wk_t)(const float*, int, int, int, const float*, const float*, int, const float*, int, float*, int, int, int, int, long long);
+#define ESR_DW_PICK(SF_) (na == 4 ? cem_downscale_wave_kernel<SF_, 4> : na == 5 ? cem_downscale_wave_kernel<SF_, 5> : cem_downscale_wave_kernel<SF_, 6>)
+            const wk_t wk = sf == 2 ? ESR_DW_PICK(2) : sf == 3 ? ESR_DW_PICK(3) : sf == 4 ? ESR_DW_PICK(4) : ESR_DW_PICK(8);
+#undef ESR_DW_PICK
+            ESR_CLEAR_ERR();
+            hipLaunchKernelGGL(wk, dim3(nwg), dim3(256), 0, (hipStream_t)stream, y, h, w, pre, tv, th, k, lr, lr_pad, d, nout, R, nct, nst, nitems);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
+    {
         // streaming kernel: strips of DS_COLS x DS_ROWS outputs, DS_STEP window rows per step
         const int cols = (DS_COLS - 1) * sf + k;
         int ring = 16;
@@ -1010,6 +1314,39 @@ static int upscale_sep_launch(const float* f, const float* f2, int B, int C, int
     if ((mode >= 1 && !g) || (mode >= 2 && !f2) || (mode == 3 && !out2)) return ESR_E_ARG;
     const bool filt = kf > 0;
     if (filt && (!tvf || !thf || !(kf & 1))) return ESR_E_ARG;
+    {
+        // wave-streaming kernel (round 6): chosen from the image geometry alone (a batch and its chunks run the same arithmetic); pre > 0: no sample on
+        // the first row / column of the zero-stuffed image (sf = 2 keeps the tile kernel and its replicate rule)
+        const int na = (k + sf - 1) / sf;
+        if (g_cem_wave && !filt && (sf == 3 || sf == 4 || sf == 8) && pre > 0 && na >= 4 && na <= 6 && (long long)h * w >= 4096 && (long long)B * C <= 65535) {
+            const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
+            const int nct = (Wo + 255) / 256;
+            const int tcols = ((Wo + nct - 1) / nct + 3) & ~3;          // equal column tiles, whole quads
+            const long long cols_total = (long long)B * C * nct;
+            int nst = (int)((3072 + cols_total - 1) / cols_total);
+            if (nst < 1) nst = 1;
+            int S = (Ho + nst - 1) / nst;
+            S = (S + sf - 1) / sf * sf;
+            if (S < 4 * sf) S = 4 * sf;
+            nst = (Ho + S - 1) / S;
+            const long long nitems = cols_total * nst;
+            const unsigned nwg = (unsigned)((nitems + 3) / 4);
+            typedef void (*uk_t)(const float*, const float*, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int,
+                                 int, long long);
+            uk_t uk;
+#define ESR_UW_PICK(TWO_)                                                                                                                                   \
+    (sf == 3 ? (na == 4 ? cem_upscale_wave_kernel<TWO_, 3, 4> : na == 5 ? cem_upscale_wave_kernel<TWO_, 3, 5> : cem_upscale_wave_kernel<TWO_, 3, 6>)              \
+     : sf == 4 ? (na == 4 ? cem_upscale_wave_kernel<TWO_, 4, 4> : na == 5 ? cem_upscale_wave_kernel<TWO_, 4, 5> : cem_upscale_wave_kernel<TWO_, 4, 6>)            \
+               : (na == 4 ? cem_upscale_wave_kernel<TWO_, 8, 4> : na == 5 ? cem_upscale_wave_kernel<TWO_, 8, 5> : cem_upscale_wave_kernel<TWO_, 8, 6>))
+            uk = mode >= 2 ? ESR_UW_PICK(true) : ESR_UW_PICK(false);
+#undef ESR_UW_PICK
+            ESR_CLEAR_ERR();
+            hipLaunchKernelGGL(uk, dim3(nwg), dim3(256), 0, (hipStream_t)stream, f, f2, h, w, pre, tv, th, k, g, crop, mode, range, out, out2, S, tcols, nct, nst,
+                               nitems);
+            ESR_CHECK_LAUNCH();
+            return ESR_OK;
+        }
+    }
     const int wr = (US_Y + 2 * (k / 2)) / sf + 3, wc = (US_X + 2 * (k / 2)) / sf + 3;
     const int two = mode >= 2 ? 2 : 1;
     const int vp = wc + (16 - wc % 32 + 32) % 32;                       // pass-1 row pitch = 16 (mod 32)
@@ -1172,3 +1509,7 @@ extern "C" int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, in
     ESR_CHECK_LAUNCH();
     return ESR_OK;
 }
+
+#ifdef ESR_TRACE
+extern "C" void esr_debug_cem_wave(int on) { g_cem_wave = on != 0; }
+#endif
