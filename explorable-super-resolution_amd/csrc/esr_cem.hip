@@ -1123,6 +1123,42 @@ __global__ __launch_bounds__(256) void cem_upscale_wave_kernel(const float* __re
 
 }  // namespace
 
+// which form of the separable kernels an image geometry takes (esr_cem_sep_form): decided from (sf, k, pre, h, w) alone, never from the batch
+static bool downscale_wave_ok(int sf, int k, int h, int w) {
+    const int na = (k + sf - 1) / sf;
+    return g_cem_wave && (sf == 2 || sf == 3 || sf == 4 || sf == 8) && na >= 4 && na <= 6 && (long long)h * w >= 4096;
+}
+static bool upscale_wave_ok(int sf, int k, int pre, int h, int w) {
+    // pre > 0: no sample on the first row / column of the zero-stuffed image (sf = 2 keeps the tile kernel and its replicate rule)
+    const int na = (k + sf - 1) / sf;
+    return g_cem_wave && (sf == 3 || sf == 4 || sf == 8) && pre > 0 && na >= 4 && na <= 6 && (long long)h * w >= 4096;
+}
+static bool downscale_stream_ok(int sf, int k, size_t* lds_out, int* qp_out, int* ring_out) {
+    const int cols = (DS_COLS - 1) * sf + k;
+    int ring = 16;
+    while (ring < k + 2 * DS_STEP + sf) ring <<= 1;       // rows an un-emitted output still needs + the step being written
+    int qp = (cols + sf - 1) / sf + 1;
+    qp |= 1;
+    const size_t lds_s = ((size_t)sf * DS_STEP * qp + (size_t)ring * (DS_COLS + 1) + 2 * (size_t)k) * 4;
+    const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * DS_SB && lds_s <= 64 * 1024;
+    // measured: configs[4] (sf 8, k 45: 109 KB tile window, one workgroup per CU) 1.88 -> 1.05 ms; configs[1] (sf 4, k 17: 24 KB)
+    // 111 -> 135 us — the streaming kernel pays ~1 us of barriers and LDS round trips per 8 rows, the tile kernel only loses where its
+    // window crowds the CU
+    const int rows_t = (DT - 1) * sf + k;
+    const size_t lds_tile = ((size_t)sf * rows_t * ((rows_t + sf - 1) / sf + 2) + (size_t)rows_t * (DT + 1)) * 4;
+    if (lds_out) *lds_out = lds_s;
+    if (qp_out) *qp_out = qp;
+    if (ring_out) *ring_out = ring;
+    return fits && lds_tile > 64 * 1024;
+}
+
+extern "C" int esr_cem_sep_form(int op, int sf, int k, int pre, int h, int w) {
+    if (sf < 1 || k < 1 || !(k & 1) || h <= 0 || w <= 0) return ESR_E_ARG;
+    if (op == 0) return downscale_wave_ok(sf, k, h, w) ? 2 : (downscale_stream_ok(sf, k, nullptr, nullptr, nullptr) ? 1 : 0);
+    if (op == 1) return upscale_wave_ok(sf, k, pre, h, w) ? 2 : 0;
+    return ESR_E_ARG;
+}
+
 extern "C" int esr_cem_downscale(const float* y, int B, int C, int h, int w, int sf, int pre, const float* taps, int k, const float* lr,
                                  int lr_pad, float* d, esr_stream_t stream) {
     if (!y || !taps || !d || B <= 0 || C <= 0 || h <= 0 || w <= 0 || sf < 1 || k < 1 || !(k & 1) || pre < 0 || pre >= sf) return ESR_E_ARG;
@@ -1220,7 +1256,7 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
         // wave-streaming kernel (round 6): images large enough to give every CU several waves; chosen from the image geometry alone, so that a batch
         // and its chunks run the same arithmetic
         const int na = (k + sf - 1) / sf;
-        if (g_cem_wave && (sf == 2 || sf == 3 || sf == 4 || sf == 8) && na >= 4 && na <= 6 && (long long)h * w >= 4096) {
+        if (downscale_wave_ok(sf, k, h, w)) {
             int nout = (252 - (k - 1)) / sf + 1;                // a lane's four columns start up to 3 columns left of the window
             if (nout > WV_LANES) nout = WV_LANES;
             const int nct = (w + nout - 1) / nout;
@@ -1247,19 +1283,9 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
     }
     {
         // streaming kernel: strips of DS_COLS x DS_ROWS outputs, DS_STEP window rows per step
-        const int cols = (DS_COLS - 1) * sf + k;
-        int ring = 16;
-        while (ring < k + 2 * DS_STEP + sf) ring <<= 1;       // rows an un-emitted output still needs + the step being written
-        int qp = (cols + sf - 1) / sf + 1;
-        qp |= 1;
-        const size_t lds_s = ((size_t)sf * DS_STEP * qp + (size_t)ring * (DS_COLS + 1) + 2 * (size_t)k) * 4;
-        const bool fits = DS_STEP * ((cols + 6) / 4 + 1) <= 256 * DS_SB && lds_s <= 64 * 1024;
-        // measured: configs[4] (sf 8, k 45: 109 KB tile window, one workgroup per CU) 1.88 -> 1.05 ms; configs[1] (sf 4, k 17: 24 KB)
-        // 111 -> 135 us — the streaming kernel pays ~1 us of barriers and LDS round trips per 8 rows, the tile kernel only loses where its
-        // window crowds the CU
-        const int rows_t = (DT - 1) * sf + k;
-        const size_t lds_tile = ((size_t)sf * rows_t * ((rows_t + sf - 1) / sf + 2) + (size_t)rows_t * (DT + 1)) * 4;
-        if (fits && lds_tile > 64 * 1024) {
+        size_t lds_s = 0;
+        int qp = 0, ring = 0;
+        if (downscale_stream_ok(sf, k, &lds_s, &qp, &ring)) {
             ESR_CLEAR_ERR();
             void (*ks)(const float*, int, int, int, int, const float*, const float*, int, const float*, int, float*, int, int) =
                 sf == 2 ? cem_downscale_stream_kernel<2> : sf == 3 ? cem_downscale_stream_kernel<3> : sf == 4 ? cem_downscale_stream_kernel<4>
@@ -1315,10 +1341,9 @@ static int upscale_sep_launch(const float* f, const float* f2, int B, int C, int
     const bool filt = kf > 0;
     if (filt && (!tvf || !thf || !(kf & 1))) return ESR_E_ARG;
     {
-        // wave-streaming kernel (round 6): chosen from the image geometry alone (a batch and its chunks run the same arithmetic); pre > 0: no sample on
-        // the first row / column of the zero-stuffed image (sf = 2 keeps the tile kernel and its replicate rule)
+        // wave-streaming kernel (round 6): chosen from the image geometry alone (a batch and its chunks run the same arithmetic)
         const int na = (k + sf - 1) / sf;
-        if (g_cem_wave && !filt && (sf == 3 || sf == 4 || sf == 8) && pre > 0 && na >= 4 && na <= 6 && (long long)h * w >= 4096 && (long long)B * C <= 65535) {
+        if (!filt && upscale_wave_ok(sf, k, pre, h, w)) {
             const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
             const int nct = (Wo + 255) / 256;
             const int tcols = ((Wo + nct - 1) / nct + 3) & ~3;          // equal column tiles, whole quads

@@ -352,8 +352,8 @@ def test_c2_rrdb23_probe_matches_reference_golden(precision, tol):
 
 @pytest.mark.parametrize('kernel', [None, 'blurry_cubic_2.0'])
 def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
-    """x8 kernels (k = 33 / 45) take the streaming form of the separable downscale (csrc/esr_cem.hip: strips of 32 x 64 outputs walked 8 window
-    rows at a time through a ring of horizontal-pass rows): 150 x 70 outputs = 3 x 3 strips with ragged last strips, plain and fused
+    """x8 kernels (k = 33 / 45) on small images take the streaming form of the separable downscale (csrc/esr_cem.hip: strips of 32 x 64 outputs walked 16
+    window rows at a time through a ring of horizontal-pass rows): 70 x 50 outputs = 2 x 2 strips with ragged last strips, plain and fused
     (lr_pad - D(y)) outputs, against the k^2 2-D kernel."""
     from esr_hip import cem_ops
     from CEM.imresize_CEM import imresize
@@ -364,7 +364,8 @@ def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
     G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
     td = G.DownscaleOP.taps()
     pre = sf - sf // 2 - 1
-    h, w = 150, 70
+    h, w = 70, 50             # (under 64 x 64 low-resolution pixels: larger images take the wave-streaming kernel, tested below)
+    assert cem_ops._lib.lib.esr_cem_sep_form(0, sf, int(td.shape[-1]), pre, h, w) == 1
     y = seeded_uniform((2, 3, sf * h, sf * w), 311).to(DEV)
     lr = seeded_uniform((2, 3, h - 8, w - 8), 312).to(DEV)
     try:
@@ -377,6 +378,55 @@ def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
     imresize.kernels = {}
     for u, v in zip(a, b):
         assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max()))
+
+
+@pytest.mark.parametrize('sf,kernel,hw,B', [(4, None, (148, 148), 2), (4, None, (70, 131), 1), (4, None, (65, 67), 3), (3, None, (70, 67), 2), (3, None, (64, 64), 1),
+                                            (8, None, (64, 64), 1), (8, 'blurry_cubic_2.0', (150, 70), 2), (4, 'blurry_cubic_1.0', (64, 80), 2), (2, None, (80, 90), 2)])
+def test_wave_streaming_cem_kernels_match_the_2d_kernels(sf, kernel, hw, B):
+    """Low-resolution images of at least 64 x 64 pixels take the wave-streaming separable kernels (round 6; csrc/esr_cem.hip cem_downscale_wave_kernel /
+    cem_upscale_wave_kernel: a wave walks down a strip of the image, vertical pass in registers, no workgroup barrier) — checked, through esr_cem_sep_form,
+    to be what runs here.  Against the k^2 2-D kernels: plain and fused downscale, every upscale mode, crops that keep and that break the 16-byte
+    alignment of g / out rows (x3: image rows are not multiples of 4 words at all — the element-wise paths), several column tiles and row strips with ragged
+    last ones, batches of 1..3.  x2 has pre = 0: its upscale keeps the tile kernel (the replicate rule of the zero-stuffed image's first row)."""
+    from esr_hip import cem_ops
+    from CEM.imresize_CEM import imresize
+    imresize.kernels = {}
+    import CEM.CEMnet as C
+    cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
+    G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
+    td, tu = G.DownscaleOP.taps(), G.Upscale_OP.taps()
+    pre = sf - sf // 2 - 1
+    h, w = hw
+    form = cem_ops._lib.lib.esr_cem_sep_form
+    assert form(0, sf, int(td.shape[-1]), pre, h, w) == 2 and form(1, sf, int(tu.shape[-1]), pre, h, w) == (2 if sf > 2 else 0)
+    y = seeded_uniform((B, 3, sf * h, sf * w), 321).to(DEV)
+    lr = seeded_uniform((B, 3, h - 6, w - 6), 322).to(DEV)
+    x = seeded_uniform((B, 3, h, w), 323, -1.0, 1.0).to(DEV)
+    x2 = seeded_uniform((B, 3, h, w), 324, -1.0, 1.0).to(DEV)
+
+    def run():
+        out = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=3),
+               cem_ops.upscale_raw(x, tu, sf, pre), cem_ops.upscale_raw(x, tu, sf, pre, g=y, crop=2 * sf, mode=1), cem_ops.upscale_raw(x, tu, sf, pre, g=y, crop=2 * sf + 1, mode=1),
+               cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=sf, mode=2, rng=1.0), cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=3, mode=2, rng=0.5)]
+        out += list(cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=0, mode=3))
+        out += list(cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=5, mode=3))
+        return out
+    try:
+        cem_ops.USE_SEPARABLE = True
+        a = run()
+        # a batch and its single images run the same arithmetic (the form is chosen from the image geometry alone)
+        one = cem_ops.downscale_raw(y[:1].contiguous(), td, sf, pre, lr=lr[:1].contiguous(), lr_pad=3)
+        assert torch.equal(one, a[1][:1])
+        one = cem_ops.upscale_raw(x[:1].contiguous(), tu, sf, pre, g=y[:1].contiguous(), crop=2 * sf, mode=1)
+        assert torch.equal(one, a[3][:1])
+        cem_ops.USE_SEPARABLE = False
+        b = run()
+    finally:
+        cem_ops.USE_SEPARABLE = True
+    imresize.kernels = {}
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert u.shape == v.shape and bool(torch.isfinite(u).all())
+        assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max())), (i, float((u - v).abs().max()))
 
 
 # ---- separable CEM fast path (rank-one taps: bicubic ds_kernel / inv_hTh) against the general 2-D kernels
