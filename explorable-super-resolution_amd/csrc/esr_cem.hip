@@ -18,6 +18,8 @@ namespace {
 
 // wave-streaming separable kernels on (the shipping behaviour); the instrumented build can switch them off for A/B runs (esr_debug_cem_wave)
 bool g_cem_wave = true;
+int g_cem_wave_target = 0;          // > 0 (instrumented build only): strips a launch aims for, instead of 0.9 x the chip's wave slots
+int g_cem_wave_rmin = 8;            // shortest downscale strip, output rows
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1123,6 +1125,30 @@ __global__ __launch_bounds__(256) void cem_upscale_wave_kernel(const float* __re
 
 }  // namespace
 
+// Strips (waves) of a wave-streaming launch: ONE resident round of the chip.  A strip count just above what the chip holds at once costs a second,
+// nearly empty round (configs[1] upscale: 4224 strips on 4096 wave slots 50 us, 3648 strips 39 us); fewer, longer strips lose memory parallelism
+// (2112: 46 us).  Slots = CUs x 4 workgroups-per-CU-by-occupancy x 4 waves, asked once per kernel; the launch aims at 0.9 of them.
+static int wave_strips_target(const void* kernel) {
+    if (g_cem_wave_target > 0) return g_cem_wave_target;        // (instrumented build: esr_debug_cem_wave)
+    struct Entry { const void* k; int dev; int slots; };
+    static thread_local Entry cache[8];
+    static thread_local int next = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (const Entry& e : cache)
+        if (e.k == kernel && e.dev == dev && e.slots) return e.slots;
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+        (void)hipGetLastError();
+        return 3072;
+    }
+    const int slots = (int)(0.9 * cus * per_cu * 4);
+    cache[next] = Entry{kernel, dev, slots};
+    next = (next + 1) % 8;
+    return slots;
+}
+
 // which form of the separable kernels an image geometry takes (esr_cem_sep_form): decided from (sf, k, pre, h, w) alone, never from the batch
 static bool downscale_wave_ok(int sf, int k, int h, int w) {
     const int na = (k + sf - 1) / sf;
@@ -1261,20 +1287,22 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
             if (nout > WV_LANES) nout = WV_LANES;
             const int nct = (w + nout - 1) / nout;
             nout = (w + nct - 1) / nct;                         // equal tiles
-            // rows per strip: enough strips for ~12 waves per CU, at least 16 rows (a strip re-reads k - sf window rows of its upper neighbour)
-            const long long cols_total = (long long)B * C * nct;
-            int nst = (int)((3072 + cols_total - 1) / cols_total);
-            if (nst < 1) nst = 1;
-            int R = (h + nst - 1) / nst;
-            if (R < 16) R = 16;
-            if (R > h) R = h;
-            nst = (h + R - 1) / R;
-            const long long nitems = cols_total * nst;
-            const unsigned nwg = (unsigned)((nitems + 3) / 4);
             typedef void (*wk_t)(const float*, int, int, int, const float*, const float*, int, const float*, int, float*, int, int, int, int, long long);
 #define ESR_DW_PICK(SF_) (na == 4 ? cem_downscale_wave_kernel<SF_, 4> : na == 5 ? cem_downscale_wave_kernel<SF_, 5> : cem_downscale_wave_kernel<SF_, 6>)
             const wk_t wk = sf == 2 ? ESR_DW_PICK(2) : sf == 3 ? ESR_DW_PICK(3) : sf == 4 ? ESR_DW_PICK(4) : ESR_DW_PICK(8);
 #undef ESR_DW_PICK
+            // rows per strip: one resident round of strips (wave_strips_target), at least 8 rows (a strip re-reads the k - sf window rows above it),
+            // strips of equal height
+            const long long cols_total = (long long)B * C * nct;
+            int nst = (int)(wave_strips_target((const void*)wk) / cols_total);
+            if (nst < 1) nst = 1;
+            int R = (h + nst - 1) / nst;
+            if (R < g_cem_wave_rmin) R = g_cem_wave_rmin;
+            if (R > h) R = h;
+            nst = (h + R - 1) / R;
+            R = (h + nst - 1) / nst;
+            const long long nitems = cols_total * nst;
+            const unsigned nwg = (unsigned)((nitems + 3) / 4);
             ESR_CLEAR_ERR();
             hipLaunchKernelGGL(wk, dim3(nwg), dim3(256), 0, (hipStream_t)stream, y, h, w, pre, tv, th, k, lr, lr_pad, d, nout, R, nct, nst, nitems);
             ESR_CHECK_LAUNCH();
@@ -1347,15 +1375,6 @@ static int upscale_sep_launch(const float* f, const float* f2, int B, int C, int
             const int Ho = h * sf - 2 * crop, Wo = w * sf - 2 * crop;
             const int nct = (Wo + 255) / 256;
             const int tcols = ((Wo + nct - 1) / nct + 3) & ~3;          // equal column tiles, whole quads
-            const long long cols_total = (long long)B * C * nct;
-            int nst = (int)((3072 + cols_total - 1) / cols_total);
-            if (nst < 1) nst = 1;
-            int S = (Ho + nst - 1) / nst;
-            S = (S + sf - 1) / sf * sf;
-            if (S < 4 * sf) S = 4 * sf;
-            nst = (Ho + S - 1) / S;
-            const long long nitems = cols_total * nst;
-            const unsigned nwg = (unsigned)((nitems + 3) / 4);
             typedef void (*uk_t)(const float*, const float*, int, int, int, const float*, const float*, int, const float*, int, int, float, float*, float*, int, int, int,
                                  int, long long);
             uk_t uk;
@@ -1365,6 +1384,17 @@ static int upscale_sep_launch(const float* f, const float* f2, int B, int C, int
                : (na == 4 ? cem_upscale_wave_kernel<TWO_, 8, 4> : na == 5 ? cem_upscale_wave_kernel<TWO_, 8, 5> : cem_upscale_wave_kernel<TWO_, 8, 6>))
             uk = mode >= 2 ? ESR_UW_PICK(true) : ESR_UW_PICK(false);
 #undef ESR_UW_PICK
+            const long long cols_total = (long long)B * C * nct;
+            int nst = (int)(wave_strips_target((const void*)uk) / cols_total);
+            if (nst < 1) nst = 1;
+            int S = (Ho + nst - 1) / nst;
+            S = (S + sf - 1) / sf * sf;                                  // whole blocks of sf rows
+            if (S < 4 * sf) S = 4 * sf;
+            nst = (Ho + S - 1) / S;
+            S = ((Ho + nst - 1) / nst + sf - 1) / sf * sf;              // strips of equal height
+            nst = (Ho + S - 1) / S;
+            const long long nitems = cols_total * nst;
+            const unsigned nwg = (unsigned)((nitems + 3) / 4);
             ESR_CLEAR_ERR();
             hipLaunchKernelGGL(uk, dim3(nwg), dim3(256), 0, (hipStream_t)stream, f, f2, h, w, pre, tv, th, k, g, crop, mode, range, out, out2, S, tcols, nct, nst,
                                nitems);
@@ -1536,5 +1566,5 @@ extern "C" int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, in
 }
 
 #ifdef ESR_TRACE
-extern "C" void esr_debug_cem_wave(int on) { g_cem_wave = on != 0; }
+extern "C" void esr_debug_cem_wave(int on) { g_cem_wave = (on & 1) != 0; if (on >> 8) g_cem_wave_target = on >> 8; if ((on >> 1) & 0x7F) g_cem_wave_rmin = (on >> 1) & 0x7F; }
 #endif
