@@ -20,6 +20,7 @@ namespace {
 bool g_cem_wave = true;
 int g_cem_wave_target = 0;          // > 0 (instrumented build only): strips a launch aims for, instead of 0.9 x the chip's wave slots
 int g_cem_wave_rmin = 8;            // shortest downscale strip, output rows
+int g_cem_filt_rmin = 18;           // shortest LR-filter strip (a strip starts K - 1 rows early: 26 / 18 / 13 rows 25 / 21 / 24 us at configs[1])
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1123,6 +1124,90 @@ __global__ __launch_bounds__(256) void cem_upscale_wave_kernel(const float* __re
     }
 }
 
+// LR filter (K = inv_hTh: 27 or 35 taps a side, replicate padding), wave-streaming: lane l owns window columns 2 l, 2 l + 1 of the wave's 128 — a pair of
+// running sums per tap in registers (packed fp32 multiply-adds): window row r feeds output rows r - t with tap t, the oldest pair is complete after every
+// row, goes through the wave's LDS row and lane l finishes output columns 2 l, 2 l + 1 with K multiply-adds each out of 14 (18) 8-byte LDS reads.
+// 128 - (K - 1) output columns per wave; strips of R output rows start K - 1 rows early.  Vertical sums in tap order, horizontal sums as even + odd taps (the tile
+// kernel: horizontal pass first): the two forms agree to fp32 rounding.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int K>
+__global__ __launch_bounds__(256) void cem_lrfilter_wave_kernel(const float* __restrict__ x, int h, int w, const float* __restrict__ tv, const float* __restrict__ th,
+                                                              float* __restrict__ out, int nout, int R, int nct, int nst, long long nitems) {
+    __shared__ float v_lds[4][128 + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* const V = v_lds[wv];
+    const unsigned nwg = gridDim.x, g = blockIdx.x, xcd = g & 7, q = nwg >> 3, rr = nwg & 7;
+    const long long item = (long long)(xcd * q + (xcd < rr ? xcd : rr) + (g >> 3)) * 4 + wv;
+    if (item >= nitems) return;
+    const int st = (int)(item % nst);
+    const long long t2 = item / nst;
+    const int ct = (int)(t2 % nct);
+    const long long bc = t2 / nct;
+    constexpr int p = K / 2;
+    const int j0 = ct * nout, i0 = st * R;
+    const int nrow = min(R, h - i0), ncol = min(nout, w - j0);
+    const float* const src = x + bc * h * (long long)w;
+    const int cw = 2 * lane;                                  // this lane's window columns cw, cw + 1
+    const bool need = cw < ncol + K - 1;
+    const int xa = clampi(j0 - p + cw, 0, w - 1), xb = clampi(j0 - p + cw + 1, 0, w - 1);
+    float tvv[K], thv[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) { tvv[a] = tv[a]; thv[a] = th[a]; }
+    f32x2 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) acc[t] = f32x2{0.f, 0.f};
+    const int nwin = nrow + K - 1;
+    auto load_row = [&](const int wr) -> f32x2 {
+        f32x2 v = f32x2{0.f, 0.f};
+        if (wr < nwin && need) {
+            const float* const rowp = src + (long long)clampi(i0 - p + wr, 0, h - 1) * w;
+            v.x = rowp[xa]; v.y = rowp[xb];
+        }
+        return v;
+    };
+    constexpr int PF = 4;                                     // rows of loads in flight
+    f32x2 pf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pf[u] = load_row(u);
+    for (int wr0 = 0; wr0 < nwin; wr0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int wr = wr0 + u;
+            const f32x2 v = pf[u];
+            pf[u] = load_row(wr + PF);
+            if (wr >= nwin) continue;                          // (uniform)
+#pragma unroll
+            for (int t = 0; t < K; ++t) acc[t] = acc[t] + tvv[t] * v;      // (contracted to packed fused multiply-adds)
+            const int il = wr - (K - 1);
+            if (il >= 0) {
+                if (need) *(f32x2*)(V + cw) = acc[K - 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a wave's LDS operations execute in order)
+                if (cw < ncol) {
+                    f32x2 r[K / 2 + 1];
+#pragma unroll
+                    for (int b = 0; b < K / 2 + 1; ++b) r[b] = *(const f32x2*)(V + cw + 2 * b);
+                    // even and odd taps in their own sums (two dependent chains of K / 2 per output instead of one of K: this pass is the wave's latency)
+                    float o0[2] = {0.f, 0.f}, o1[2] = {0.f, 0.f};
+#pragma unroll
+                    for (int b = 0; b < K; ++b) {
+                        const float va = (b & 1) ? r[b / 2].y : r[b / 2].x;                       // V[cw + b]
+                        const float vb = ((b + 1) & 1) ? r[(b + 1) / 2].y : r[(b + 1) / 2].x;     // V[cw + 1 + b]
+                        o0[b & 1] = fmaf(thv[b], va, o0[b & 1]);
+                        o1[b & 1] = fmaf(thv[b], vb, o1[b & 1]);
+                    }
+                    float* const op = out + (bc * h + i0 + il) * (long long)w + j0 + cw;
+                    op[0] = o0[0] + o0[1];
+                    if (cw + 1 < ncol) op[1] = o1[0] + o1[1];
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int t = K - 1; t > 0; --t) acc[t] = acc[t - 1];
+            acc[0] = f32x2{0.f, 0.f};
+        }
+    }
+}
+
 }  // namespace
 
 // Strips (waves) of a wave-streaming launch: ONE resident round of the chip.  A strip count just above what the chip holds at once costs a second,
@@ -1159,6 +1244,7 @@ static bool upscale_wave_ok(int sf, int k, int pre, int h, int w) {
     const int na = (k + sf - 1) / sf;
     return g_cem_wave && (sf == 3 || sf == 4 || sf == 8) && pre > 0 && na >= 4 && na <= 6 && (long long)h * w >= 4096;
 }
+static bool lrfilter_wave_ok(int k, int h, int w) { return g_cem_wave && (k == 27 || k == 35) && (long long)h * w >= 16384; }
 static bool downscale_stream_ok(int sf, int k, size_t* lds_out, int* qp_out, int* ring_out) {
     const int cols = (DS_COLS - 1) * sf + k;
     int ring = 16;
@@ -1182,6 +1268,7 @@ extern "C" int esr_cem_sep_form(int op, int sf, int k, int pre, int h, int w) {
     if (sf < 1 || k < 1 || !(k & 1) || h <= 0 || w <= 0) return ESR_E_ARG;
     if (op == 0) return downscale_wave_ok(sf, k, h, w) ? 2 : (downscale_stream_ok(sf, k, nullptr, nullptr, nullptr) ? 1 : 0);
     if (op == 1) return upscale_wave_ok(sf, k, pre, h, w) ? 2 : 0;
+    if (op == 2) return lrfilter_wave_ok(k, h, w) ? 2 : 0;
     return ESR_E_ARG;
 }
 
@@ -1347,6 +1434,26 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
 
 extern "C" int esr_cem_lrfilter_sep(const float* x, int B, int C, int h, int w, const float* tv, const float* th, int k, float* out, esr_stream_t stream) {
     if (!x || !tv || !th || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || k < 1 || !(k & 1)) return ESR_E_ARG;
+    if (lrfilter_wave_ok(k, h, w) && (long long)B * C <= 65535) {
+        typedef void (*fk_t)(const float*, int, int, const float*, const float*, float*, int, int, int, int, long long);
+        const fk_t fk = k == 27 ? cem_lrfilter_wave_kernel<27> : cem_lrfilter_wave_kernel<35>;
+        int nout = 128 - (k - 1);
+        const int nct = (w + nout - 1) / nout;
+        nout = ((w + nct - 1) / nct + 1) & ~1;                  // equal tiles, whole column pairs
+        const long long cols_total = (long long)B * C * nct;
+        int nst = (int)(wave_strips_target((const void*)fk) / cols_total);
+        if (nst < 1) nst = 1;
+        int R = (h + nst - 1) / nst;
+        if (R < g_cem_filt_rmin) R = g_cem_filt_rmin;            // (every strip runs k - 1 rows before its first output)
+        if (R > h) R = h;
+        nst = (h + R - 1) / R;
+        R = (h + nst - 1) / nst;
+        const long long nitems = cols_total * nst;
+        ESR_CLEAR_ERR();
+        hipLaunchKernelGGL(fk, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, h, w, tv, th, out, nout, R, nct, nst, nitems);
+        ESR_CHECK_LAUNCH();
+        return ESR_OK;
+    }
     int pitch = LT_TX + k - 1;
     pitch += (16 - pitch % 32 + 32) % 32;
     const size_t lds = ((size_t)(LT_TY + k - 1) * pitch + (size_t)(LT_TY + k - 1) * (LT_TX + 1)) * 4;
@@ -1566,5 +1673,5 @@ extern "C" int esr_cem_adjoint(const float* dy, int B, int C, int hq, int wq, in
 }
 
 #ifdef ESR_TRACE
-extern "C" void esr_debug_cem_wave(int on) { g_cem_wave = (on & 1) != 0; if (on >> 8) g_cem_wave_target = on >> 8; if ((on >> 1) & 0x7F) g_cem_wave_rmin = (on >> 1) & 0x7F; }
+extern "C" void esr_debug_cem_wave(int on) { g_cem_wave = (on & 1) != 0; if (on >> 8) g_cem_wave_target = on >> 8; if ((on >> 1) & 0x7F) { g_cem_wave_rmin = (on >> 1) & 0x7F; g_cem_filt_rmin = (on >> 1) & 0x7F; } }
 #endif

@@ -149,7 +149,12 @@ def filter_upscale_raw(e, taps_inv, taps_up, sf, pre, e2=None, g=None, crop=0, m
     sep_i, sep_u = _sep(taps_inv, e.device), _sep(taps_up, e.device)
     B, Cc, h, w = e.shape
     Ho, Wo = sf * h - 2 * crop, sf * w - 2 * crop
-    fold = FUSE_FILTER_UPSCALE if FUSE_FILTER_UPSCALE is not None else B * Cc * ((Ho + 63) // 64) * ((Wo + 63) // 64) <= FOLD_MAX_TILES
+    fold = FUSE_FILTER_UPSCALE
+    if fold is None:
+        # small launches only — and only where the separate filter launch is the TILE kernel, whose arithmetic the fold reproduces to the bit: images that
+        # take the wave-streaming filter (esr_cem_sep_form) are never folded, so that a batch and any shard of it run the same arithmetic whatever their size
+        fold = B * Cc * ((Ho + 63) // 64) * ((Wo + 63) // 64) <= FOLD_MAX_TILES and \
+            _lib.lib.esr_cem_sep_form(2, sf, int(_taps(taps_inv, e.device).shape[0]), pre, h, w) == 0
     if fold and sep_i is not None and sep_u is not None:
         o = out if out is not None else torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=e.device)
         assert o.shape == (B, Cc, Ho, Wo) and o.dtype == torch.float32 and o.is_contiguous()

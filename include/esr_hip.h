@@ -247,11 +247,11 @@ int esr_cem_filter_upscale_sep(const float* e, const float* e2, int B, int C, in
                                const float* tv, const float* th, int k, const float* g, int crop, int mode, float range, float* out, float* out2,
                                esr_stream_t stream);
 
-/* Which kernel form esr_cem_downscale_sep (op 0) / esr_cem_upscale_sep (op 1) runs for an image geometry — decided from these arguments alone, never
+/* Which kernel form esr_cem_downscale_sep (op 0) / esr_cem_upscale_sep (op 1) / esr_cem_lrfilter_sep (op 2; k = its tap count, sf and pre unused) runs for an image geometry — decided from these arguments alone, never
  * from the batch, so that a batch and its chunks run the same arithmetic: 0 = tile kernel (a workgroup stages a window in LDS), 1 = streaming tile
  * kernel (x8 downscale of small images), 2 = wave-streaming kernel (low-resolution images of at least 64 x 64 pixels, sf 2 / 3 / 4 / 8 with
- * ceil(k / sf) in 4..6; the upscale also needs pre > 0): a wave walks down a strip with the vertical pass in registers.  The upscale forms agree to
- * the bit, the downscale forms to fp32 rounding (different order of the two passes).  For tests and documentation; < 0: ESR_E_ARG. */
+ * ceil(k / sf) in 4..6; the upscale also needs pre > 0; the LR filter k = 27 or 35 and 128 x 128 pixels): a wave walks down a strip with the vertical pass in registers.  The
+ * upscale forms agree to the bit, the downscale and LR-filter forms to fp32 rounding (different order of the two passes).  For tests and documentation; < 0: ESR_E_ARG. */
 int esr_cem_sep_form(int op, int sf, int k, int pre, int h, int w);
 
 /* ---- backward-pass helpers (autograd of the reference's torch ops) ----

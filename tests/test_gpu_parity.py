@@ -380,12 +380,12 @@ def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
         assert float((u - v).abs().max()) < 2e-6 * max(1.0, float(v.abs().max()))
 
 
-@pytest.mark.parametrize('sf,kernel,hw,B', [(4, None, (148, 148), 2), (4, None, (70, 131), 1), (4, None, (65, 67), 3), (3, None, (70, 67), 2), (3, None, (64, 64), 1),
+@pytest.mark.parametrize('sf,kernel,hw,B', [(4, None, (148, 148), 2), (4, None, (131, 270), 1), (4, None, (70, 131), 1), (4, None, (65, 67), 3), (3, None, (70, 67), 2), (3, None, (64, 64), 1),
                                             (8, None, (64, 64), 1), (8, 'blurry_cubic_2.0', (150, 70), 2), (4, 'blurry_cubic_1.0', (64, 80), 2), (2, None, (80, 90), 2)])
 def test_wave_streaming_cem_kernels_match_the_2d_kernels(sf, kernel, hw, B):
     """Low-resolution images of at least 64 x 64 pixels take the wave-streaming separable kernels (round 6; csrc/esr_cem.hip cem_downscale_wave_kernel /
-    cem_upscale_wave_kernel: a wave walks down a strip of the image, vertical pass in registers, no workgroup barrier) — checked, through esr_cem_sep_form,
-    to be what runs here.  Against the k^2 2-D kernels: plain and fused downscale, every upscale mode, crops that keep and that break the 16-byte
+    cem_lrfilter_wave_kernel / cem_upscale_wave_kernel: a wave walks down a strip of the image, vertical pass in registers, no workgroup barrier) — checked,
+    through esr_cem_sep_form, to be what runs here.  Against the k^2 2-D kernels: plain and fused downscale, the LR filter, every upscale mode, crops that keep and that break the 16-byte
     alignment of g / out rows (x3: image rows are not multiples of 4 words at all — the element-wise paths), several column tiles and row strips with ragged
     last ones, batches of 1..3.  x2 has pre = 0: its upscale keeps the tile kernel (the replicate rule of the zero-stuffed image's first row)."""
     from esr_hip import cem_ops
@@ -394,18 +394,19 @@ def test_wave_streaming_cem_kernels_match_the_2d_kernels(sf, kernel, hw, B):
     import CEM.CEMnet as C
     cem = C.CEMnet(C.Get_CEM_Conf(sf), upscale_kernel=kernel)
     G = cem.WrapArchitecture_PyTorch(generated_image=None).to(DEV)
-    td, tu = G.DownscaleOP.taps(), G.Upscale_OP.taps()
+    td, ti, tu = G.DownscaleOP.taps(), G.Conv_LR_with_Inv_hTh_OP.taps(), G.Upscale_OP.taps()
     pre = sf - sf // 2 - 1
     h, w = hw
     form = cem_ops._lib.lib.esr_cem_sep_form
     assert form(0, sf, int(td.shape[-1]), pre, h, w) == 2 and form(1, sf, int(tu.shape[-1]), pre, h, w) == (2 if sf > 2 else 0)
+    assert form(2, sf, int(ti.shape[-1]), pre, h, w) == (2 if h * w >= 128 * 128 else 0)           # (the LR filter: from 128 x 128 pixels)
     y = seeded_uniform((B, 3, sf * h, sf * w), 321).to(DEV)
     lr = seeded_uniform((B, 3, h - 6, w - 6), 322).to(DEV)
     x = seeded_uniform((B, 3, h, w), 323, -1.0, 1.0).to(DEV)
     x2 = seeded_uniform((B, 3, h, w), 324, -1.0, 1.0).to(DEV)
 
     def run():
-        out = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=3),
+        out = [cem_ops.downscale_raw(y, td, sf, pre), cem_ops.downscale_raw(y, td, sf, pre, lr=lr, lr_pad=3), cem_ops.lr_filter_raw(x, ti),
                cem_ops.upscale_raw(x, tu, sf, pre), cem_ops.upscale_raw(x, tu, sf, pre, g=y, crop=2 * sf, mode=1), cem_ops.upscale_raw(x, tu, sf, pre, g=y, crop=2 * sf + 1, mode=1),
                cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=sf, mode=2, rng=1.0), cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=3, mode=2, rng=0.5)]
         out += list(cem_ops.upscale_raw(x, tu, sf, pre, f2=x2, g=y, crop=0, mode=3))
@@ -418,7 +419,8 @@ def test_wave_streaming_cem_kernels_match_the_2d_kernels(sf, kernel, hw, B):
         one = cem_ops.downscale_raw(y[:1].contiguous(), td, sf, pre, lr=lr[:1].contiguous(), lr_pad=3)
         assert torch.equal(one, a[1][:1])
         one = cem_ops.upscale_raw(x[:1].contiguous(), tu, sf, pre, g=y[:1].contiguous(), crop=2 * sf, mode=1)
-        assert torch.equal(one, a[3][:1])
+        assert torch.equal(one, a[4][:1])
+        assert torch.equal(cem_ops.lr_filter_raw(x[:1].contiguous(), ti), a[2][:1])
         cem_ops.USE_SEPARABLE = False
         b = run()
     finally:
@@ -513,8 +515,16 @@ def test_filter_folded_into_the_upscale_launch_is_bit_identical_to_the_two_launc
         cem_ops._lib.lib.esr_cem_filter_upscale_sep = real
         cem_ops.FUSE_FILTER_UPSCALE = None
     assert len(calls) == 7 and all(rc == 0 for rc in calls), calls            # the folded launch really ran (no quiet fallback to the two launches)
+    # The fold evaluates K with the TILE kernel's passes and summation order: where the separate launch is that kernel, to the last bit.  Images of at
+    # least 64 x 64 low-resolution pixels take the wave-streaming filter (vertical pass first, one accumulator): equal to fp32 rounding there (the fold
+    # itself is only used for small launches: cem_ops.FOLD_MAX_TILES).
+    tile_filter = cem_ops._lib.lib.esr_cem_sep_form(2, sf, int(ti.shape[-1]), pre, h, w) == 0
     for i, (u, v) in enumerate(zip(a, b)):
-        assert u.shape == v.shape and torch.equal(u, v), (i, float((u - v).abs().max()))
+        assert u.shape == v.shape
+        if tile_filter:
+            assert torch.equal(u, v), (i, float((u - v).abs().max()))
+        else:
+            assert float((u - v).abs().max()) < 4e-6 * max(1.0, float(v.abs().max())), (i, float((u - v).abs().max()))
 
 
 def test_anisotropic_kernels_keep_the_2d_path():

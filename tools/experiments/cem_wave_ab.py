@@ -1,4 +1,4 @@
-"""Same-process A/B of the wave-streaming separable CEM kernels (csrc/esr_cem.hip: cem_downscale_wave_kernel, cem_upscale_wave_kernel) against the tile
+"""Same-process A/B of the wave-streaming separable CEM kernels (csrc/esr_cem.hip: cem_downscale_wave_kernel, cem_lrfilter_wave_kernel, cem_upscale_wave_kernel) against the tile
 kernels they replace at the large image sizes: the instrumented build's switch esr_debug_cem_wave (make -C explorable-super-resolution_amd/csrc trace;
 ESR_HIP_LIBRARY=explorable-super-resolution_amd/esr_hip/libesr_hip_trace.so).  Per op and for the whole projection at the configs[1] and configs[4] sizes:
 time (GPU events over back-to-back launches) and the largest difference between the two forms.
@@ -43,6 +43,7 @@ for name, sf, kernel, B, lr_size in CASES:
            ('upscale  g + U(e), cropped', lambda: cem_ops.upscale_raw(e, tu, sf, pre, g=g, crop=sf * m, mode=1)),
            ('upscale  U(e)', lambda: cem_ops.upscale_raw(e, tu, sf, pre)),
            ('upscale  tanh form (two inputs)', lambda: cem_ops.upscale_raw(e, tu, sf, pre, f2=e * 0.5, g=g, crop=sf * m, mode=2, rng=0.3)),
+           ('LR filter  K(e)', lambda: cem_ops.lr_filter_raw(e, ti)),
            ('projection', lambda: cem_ops.project(lr, g, td, ti, tu, sf, pre, lr_pad=m, crop=sf * m)))
     with torch.no_grad():
         for what, f in ops:
