@@ -9,8 +9,9 @@
 // Index conventions (bit-exact with the reference): LR sample (i,j) sits at HR (sf*i+pre, sf*j+pre), pre = sf - floor(sf/2) - 1
 // (codes/CEM/imresize_CEM.py:99-101); filter centre = floor(k/2); the replicate pad of the zero-stuffed image replicates
 // whatever its first/last row is (a sample row only when pre == 0, i.e. sf == 2).
-// These are HBM/L2-bound streaming kernels (<= 0.1 % of the generator's FLOPs): one output per thread, coalesced along W,
-// taps through the scalar cache.
+// Forms (esr_cem_sep_form): general k^2 kernels (one output per thread; anisotropic taps), separable tile kernels (a workgroup stages a
+// window in LDS: small images), a streaming tile kernel (x8 downscale of small images) and — large images, where the tile kernels are bound by their own
+// instruction stream — separable WAVE-streaming kernels: a wave walks down a strip of the image with the vertical pass in registers.
 #include "esr_common.h"
 #include <type_traits>
 
