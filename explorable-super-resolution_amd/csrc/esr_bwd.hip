@@ -130,9 +130,19 @@ __global__ void unpack_grad_kernel(DView G, float* __restrict__ dst, long long d
             for (int xx = x_lo; xx <= x_hi; ++xx) add_at(yy, xx, 1.f);
     } else {
         // forward: lr(i) = (1-l)*hr(y0) + l*hr(y1), src = (i+0.5)*down-0.5, y0 = floor(src), y1 = min(y0+1, hp-1), l = src - y0
+        // Even `down` (the x2 / x4 / x8 generators): src = down i + down / 2 - 0.5, so LR pixel i reads exactly the two central rows of its block with
+        // weight 0.5 each (l = 0.5 exactly, never clamped) — row yy has ONE contributor (i = yy / down) when yy mod down is down/2 - 1 or down/2 and none
+        // otherwise: the same (index, weight) the search below finds, without its ~20 candidate evaluations per pixel (the Z gradient calls of a configs[3]
+        // iteration: 5.7 -> 3.6 ms of this kernel per iteration).
+        const bool even = (down & 1) == 0;
         for (int yy = y_lo; yy <= y_hi; ++yy) {
             // LR pixels whose taps include padded-HR row yy: at most two
             float wy[2]; int iy[2]; int ny = 0;
+            if (even) {
+                const int i = yy / down, r = yy - i * down;
+                if (r == down / 2 - 1 || r == down / 2) { wy[0] = 0.5f; iy[0] = i; ny = 1; }
+                if (ny == 0) continue;
+            } else
             for (int i = (yy - 1) / down - 1; i <= yy / down + 1; ++i) {
                 if (i < 0 || i >= Hd) continue;
                 const float src = fmaxf((i + 0.5f) * (float)down - 0.5f, 0.f);
@@ -145,6 +155,10 @@ __global__ void unpack_grad_kernel(DView G, float* __restrict__ dst, long long d
             }
             for (int xx = x_lo; xx <= x_hi; ++xx) {
                 float wx[2]; int ix[2]; int nx = 0;
+                if (even) {
+                    const int j = xx / down, r = xx - j * down;
+                    if (r == down / 2 - 1 || r == down / 2) { wx[0] = 0.5f; ix[0] = j; nx = 1; }
+                } else
                 for (int j = (xx - 1) / down - 1; j <= xx / down + 1; ++j) {
                     if (j < 0 || j >= Wd) continue;
                     const float src = fmaxf((j + 0.5f) * (float)down - 0.5f, 0.f);
