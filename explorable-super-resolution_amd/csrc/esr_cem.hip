@@ -20,7 +20,7 @@ namespace {
 // wave-streaming separable kernels on (the shipping behaviour); the instrumented build can switch them off for A/B runs (esr_debug_cem_wave)
 bool g_cem_wave = true;
 int g_cem_wave_target = 0;          // > 0 (instrumented build only): strips a launch aims for, instead of 0.9 x the chip's wave slots
-int g_cem_wave_rmin = 8;            // shortest downscale strip, output rows
+int g_cem_wave_rmin = 0;            // > 0 (instrumented build only): downscale strip height, output rows
 int g_cem_filt_rmin = 18;           // shortest LR-filter strip (a strip starts K - 1 rows early: 26 / 18 / 13 rows 25 / 21 / 24 us at configs[1])
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -900,9 +900,19 @@ __global__ __launch_bounds__(256) void cem_downscale_wave_kernel(const float* __
         const int c = 4 * lane + t - off;
         slot[t] = (c >= 0 && c < cols) ? (c % sf) * QP + c / sf : -1;
     }
+    // Odd strips walk UP: a strip and its lower neighbour then finish on their shared window rows at the same time, a strip and its upper neighbour
+    // start on theirs together — the k - sf rows two strips share are in the XCD's L2 when the second one asks (with all strips walking down the second
+    // request came a whole strip later: 1.36 x the image from HBM).  Walking up = the same loop over the mirrored window with the vertical taps
+    // reversed; an output row of an odd strip sums its vertical taps in descending order (fp32 rounding) — which is why strips are cut by the image
+    // height alone (esr_cem_downscale_sep): every output's arithmetic is the same whatever the batch.
+    const bool up = __builtin_amdgcn_readfirstlane(st & 1) != 0;         // (scalar: the tap loads below stay scalar loads)
     float tvv[NT], thv[NT];
 #pragma unroll
-    for (int a = 0; a < NT; ++a) { tvv[a] = a < k ? tv[a] : 0.f; thv[a] = a < k ? th[a] : 0.f; }
+    for (int a = 0; a < NT; ++a) {
+        const int av = up ? NT - 1 - a : a;
+        tvv[a] = av < k ? tv[av < k ? av : 0] : 0.f;
+        thv[a] = a < k ? th[a] : 0.f;
+    }
     // (the zero taps of the padded horizontal pass multiply image words past the strip's last window column: they have to be finite)
     for (int e = lane; e < SFT * QP; e += 64) L[e] = 0.f;
     const int nwin = (nrow - 1) * sf + k;                     // window rows of the strip
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(256) void cem_downscale_wave_kernel(const float* __
     auto load_blk = [&](float4 (&dst)[SFT], const int m) {
 #pragma unroll
         for (int ph = 0; ph < sf; ++ph) {
-            const int wr = sf * m + ph;
+            const int wr = up ? sf * nblk - 1 - (sf * m + ph) : sf * m + ph;
             dst[ph] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (wr < nwin && need) {
                 const float* const rowp = src + (long long)clampi(Yb + wr, 0, Hh - 1) * Wh;
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(256) void cem_downscale_wave_kernel(const float* __
                 float o = 0.f;
 #pragma unroll
                 for (int b = 0; b < NT; ++b) o = fmaf(thv[b], L[(b % sf) * QP + lane + b / sf], o);
-                const int i = i0 + il, j = j0 + lane;
+                const int i = i0 + (up ? nrow - 1 - il : il), j = j0 + lane;
                 if (lr) o = lr[(bc * h0 + clampi(i - lr_pad, 0, h0 - 1)) * w0 + clampi(j - lr_pad, 0, w0 - 1)] - o;
                 d[(bc * h + i) * (long long)w + j] = o;
             }
@@ -1379,16 +1389,14 @@ extern "C" int esr_cem_downscale_sep(const float* y, int B, int C, int h, int w,
 #define ESR_DW_PICK(SF_) (na == 4 ? cem_downscale_wave_kernel<SF_, 4> : na == 5 ? cem_downscale_wave_kernel<SF_, 5> : cem_downscale_wave_kernel<SF_, 6>)
             const wk_t wk = sf == 2 ? ESR_DW_PICK(2) : sf == 3 ? ESR_DW_PICK(3) : sf == 4 ? ESR_DW_PICK(4) : ESR_DW_PICK(8);
 #undef ESR_DW_PICK
-            // rows per strip: one resident round of strips (wave_strips_target), at least 8 rows (a strip re-reads the k - sf window rows above it),
-            // strips of equal height
+            // strips of 12-14 output rows, cut by the image height ALONE: odd strips walk up (their outputs sum the vertical taps in the other
+            // order), so the cut must not depend on the batch
             const long long cols_total = (long long)B * C * nct;
-            int nst = (int)(wave_strips_target((const void*)wk) / cols_total);
-            if (nst < 1) nst = 1;
-            int R = (h + nst - 1) / nst;
-            if (R < g_cem_wave_rmin) R = g_cem_wave_rmin;
-            if (R > h) R = h;
+            // (configs[1], h = 148: 10 / 12 / 14 / 16 / 20 rows 45 / 34.5 / 37 / 35 / 42 us; configs[4], h = 280: 275 / 289 / 270 / 285 / 273 us)
+            const int rows = g_cem_wave_rmin > 0 ? g_cem_wave_rmin : (h < 256 ? 12 : 14);
+            int nst = (h + rows - 1) / rows;
+            const int R = (h + nst - 1) / nst;
             nst = (h + R - 1) / R;
-            R = (h + nst - 1) / nst;
             const long long nitems = cols_total * nst;
             const unsigned nwg = (unsigned)((nitems + 3) / 4);
             ESR_CLEAR_ERR();
