@@ -553,7 +553,10 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
         # exposed_comm_ms = (a) - (c): the part of the collectives that the step's own work does not hide.
         model.timing = None
 
-        def arm(nsteps=5, nwarm=2):
+        # (ESR_BENCH_SHARE_GPU, the tests' ranks-on-one-GPU switch: gloo stages every bucket through the host, ~1 s per step — two steps per arm)
+        ARM_STEPS, ARM_WARM = (2, 1) if os.environ.get('ESR_BENCH_SHARE_GPU') == '1' else (5, 2)
+
+        def arm(nsteps=ARM_STEPS, nwarm=ARM_WARM):
             for _ in range(nwarm):
                 model.feed_data(data); model.optimize_parameters()
             sync()
@@ -586,9 +589,9 @@ def run_c3(args, dev, rank, world, dist, sync, max_over_ranks):
                 'exposed_comm_ms_inside_backward': early_ms - none_ms, 'early_buckets': other_buckets if not was else model.grad_reducer.early_buckets,
                 'timed_region_used': 'inside the backward' if was else 'after the backward',
                 'G_gradient_bytes': int(sum(p.numel() * 4 for p in real_G.params)), 'D_gradient_bytes': int(sum(p.numel() * 4 for p in real_D.params)) if real_D is not None else 0,
-                'backend': dist.get_backend(), 'steps_per_arm': 5,
-                'note': 'same model, same data, arms back to back: (the timed region), the other exchange form (2 warm-up + 5 steps), no exchange '
-                        '(2 + 5; replicas drift: diagnosis only).  exposed_comm_ms = timed form minus no exchange'}
+                'backend': dist.get_backend(), 'steps_per_arm': ARM_STEPS,
+                'note': 'same model, same data, arms back to back: (the timed region), the other exchange form (%d warm-up + %d steps), no exchange '
+                        '(the same; replicas drift: diagnosis only).  exposed_comm_ms = timed form minus no exchange' % (ARM_WARM, ARM_STEPS)}
     if rank != 0:
         return None
     log = model.get_current_log()
