@@ -421,6 +421,29 @@ def run_c2(args, dev, rank, world, dist, sync, max_over_ranks):
                      'mfma_bf16_issue_frac_of_measured_1.79PF': terms * FLOP_PER_FWD / (conv_ms * 1e-3) / 1.79e15},
         'cem_consistency_rmse_interior': cons,
     }
+    if BATCH == 32:
+        # The wrapping CEM projection alone (A6-A8: out = g + U(K(x - D(g))), cropped), timed live with events over 20 back-to-back projections of the
+        # generator's output, against SURVEY section 8(a) A8's algorithmic minimum (read g 134.6 MB + x 8.4 MB, write out 100.7 MB)
+        from esr_hip import cem_ops
+        with torch.no_grad():
+            gimg = net(x, pad=m)
+            proj = lambda: cem_ops.project(x, gimg, G.DownscaleOP.taps(), G.Conv_LR_with_Inv_hTh_OP.taps(), G.Upscale_OP.taps(), SF, G.pre_stride,
+                                           lr_pad=m, crop=SF * m)
+            for _ in range(3):
+                proj()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(20):
+                proj()
+            c1.record()
+            torch.cuda.synchronize()
+            del gimg
+        cem_s = c0.elapsed_time(c1) / 20 * 1e-3
+        cem_bytes = 134.6e6 + 8.4e6 + 100.7e6
+        out['cem_projection'] = {'kernels': 'cem_downscale_wave_kernel, cem_lrfilter_wave_kernel, cem_upscale_wave_kernel (3 launches)', 'us': cem_s * 1e6,
+                                 'bound': 'hbm', 'algorithmic_bytes': cem_bytes, 'achieved': cem_bytes / cem_s / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                 'frac': cem_bytes / cem_s / HBM_PEAK, 'traffic': None,
+                                 'traffic_source': 'not collected by this run; committed counters of 20 such projections: profiles/r06_cem_wave_pmc.json (0.389 GB per projection)'}
     if traffic:
         out['roofline']['frac_physical_static'] = traffic / t_launch / HBM_PEAK      # bytes the mode really moves (static PMC figure) / measured time
     pm, pm_src = newest_pmc_mfma(precision) if BATCH == 32 else (None, None)
