@@ -381,7 +381,8 @@ def test_streaming_downscale_matches_the_2d_kernel_over_several_strips(kernel):
 
 
 @pytest.mark.parametrize('sf,kernel,hw,B', [(4, None, (148, 148), 2), (4, None, (131, 270), 1), (4, None, (70, 131), 1), (4, None, (65, 67), 3), (3, None, (70, 67), 2), (3, None, (64, 64), 1),
-                                            (8, None, (64, 64), 1), (8, 'blurry_cubic_2.0', (150, 70), 2), (4, 'blurry_cubic_1.0', (64, 80), 2), (2, None, (80, 90), 2)])
+                                            (8, None, (64, 64), 1), (8, 'blurry_cubic_2.0', (150, 70), 2), (4, 'blurry_cubic_1.0', (64, 80), 2), (4, 'blurry_cubic_1.0', (129, 134), 1),
+                                            (2, None, (80, 90), 2)])
 def test_wave_streaming_cem_kernels_match_the_2d_kernels(sf, kernel, hw, B):
     """Low-resolution images of at least 64 x 64 pixels take the wave-streaming separable kernels (round 6; csrc/esr_cem.hip cem_downscale_wave_kernel /
     cem_lrfilter_wave_kernel / cem_upscale_wave_kernel: a wave walks down a strip of the image, vertical pass in registers, no workgroup barrier) — checked,
