@@ -259,6 +259,12 @@ def test_hip_graph_replay_is_bit_identical():
         for p in G.generated_image_model.parameters():
             p.mul_(0.5)
         assert torch.equal(G(xs[0]), fast(xs[0]))
+        # an image whose CEM projection takes the wave-streaming kernels (their strip count is asked of the occupancy API at launch: also under capture)
+        big = seeded_uniform((1, 3, 112, 120), 404).to(DEV)
+        assert G.DownscaleOP.taps() is not None and __import__('esr_hip')._lib.lib.esr_cem_sep_form(2, 4, 27, 1, 132, 140) == 2
+        fast_big = GraphedForward(G)
+        ref = G(big)
+        assert torch.equal(ref, fast_big(big)) and torch.equal(ref, fast_big(big))
 
 
 @pytest.mark.parametrize('sf,kernel', [(4, None), (2, None), (4, 'blurry_cubic_1.0')])
